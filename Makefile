@@ -1,0 +1,27 @@
+# Builds libsgf.so (the gfx950 C-ABI library) and the C oracle.  hipcc cross-compiles without a GPU.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function \
+            -fhip-fp32-correctly-rounded-divide-sqrt
+CSRC := sgformer_amd/csrc
+SRCS := $(CSRC)/capi.hip $(CSRC)/csr.hip $(CSRC)/spmm.hip $(CSRC)/attn.hip $(CSRC)/fused.hip
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+LIB  := sgformer_amd/lib/libsgf.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sgf.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB) oracle/_build oracle/_ref
+
+.PHONY: all oracle clean

@@ -1,0 +1,211 @@
+/*
+ * sgf.h — C ABI of libsgf.so: the MI355X (gfx950) hot path of SGFormer forward/backward.
+ *
+ * This is the drop-in boundary.  The reference (qitianwu/SGFormer) has no FFI of
+ * its own: its hot path is a chain of stock PyTorch / torch_sparse calls inside large/ours.py,
+ * medium/ours.py and 100M/ours.py.  Every entry point below names the reference lines whose
+ * arithmetic it replaces.  The host-side mirror of the reference's nn.Module surface
+ * (sgformer_amd/ours.py) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / HIP types in any signature
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - the caller allocates and owns every buffer, including outputs and workspaces
+ *     (sizes from the *_workspace_bytes queries).  No hidden allocation, no host sync,
+ *     no thread-local state: calls are re-entrant and may come from the autograd thread.
+ *   - return value: 0 = ok, negative = error (SGF_E_*); sgf_last_error() gives the text of the
+ *     most recent failure on the calling thread's process (best effort, not thread-local).
+ *   - matrices are row-major with an explicit leading dimension `ld*` counted in ELEMENTS.
+ *   - dtype codes: SGF_F32 = 0 (fp32 storage), SGF_BF16 = 1 (bf16 storage, fp32 accumulate).
+ */
+#ifndef SGF_H_
+#define SGF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGF_VERSION 100 /* 0.1.0 */
+
+#define SGF_F32 0
+#define SGF_BF16 1
+
+#define SGF_OK 0
+#define SGF_E_INVALID (-1)   /* bad argument (shape, alignment, dtype)            */
+#define SGF_E_WORKSPACE (-2) /* workspace too small                                */
+#define SGF_E_HIP (-3)       /* a HIP runtime call or kernel launch failed         */
+#define SGF_E_UNSUPPORTED (-4) /* shape outside what the gfx950 kernels implement  */
+
+int sgf_version(void);
+const char* sgf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * T1 — adjacency normalisation + CSR build.   Replaces large/ours.py:26-33
+ * (= 100M/ours.py:72-79): degree(col, N); value = sqrt(1/d[col]) * sqrt(1/d[row]);
+ * nan_to_num(->0); SparseTensor(row=col, col=row, value) i.e. A[col_e, row_e] = v_e with entries
+ * ordered by (target, source), duplicates kept.  In the reference this (an argsort over all nnz
+ * edges) is redone in every layer of every forward; here it is built once and cached by the
+ * caller.
+ *
+ *   edge_index : int64 [2, nnz] row-major (edge_index[0] = source "row", edge_index[1] = target "col")
+ *   rowptr     : int64 [n+1]   out — CSR row pointer over TARGET nodes
+ *   colind     : int32 [nnz]   out — source node of each stored entry, ascending inside a row
+ *   val        : fp32  [nnz]   out — sqrtf(1.0f/deg[tgt]) * sqrtf(1.0f/deg[src]), non-finite -> 0
+ *   deg        : int32 [n]     out — in-degree (count of edges whose target is i)
+ * Bit-exact contract: rowptr / colind equal a stable sort of the edges by key tgt*N+src; val is the
+ * IEEE fp32 product of two correctly rounded sqrt(1/d) terms.  Requires 0 <= node id < n < 2^31.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_csr_workspace_bytes(int64_t nnz, int64_t n);
+int sgf_csr_build(const int64_t* edge_index, int64_t nnz, int64_t n, int64_t* rowptr,
+                  int32_t* colind, float* val, int32_t* deg, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* CSR of A^T (needed by the SpMM backward, dX = A^T dY, large/ours.py:34 under autograd, whenever
+ * A is not symmetric: neighbour-sampled batches 100M/nb-sample.py:125-133, --directed runs,
+ * ogbn-proteins).  `deg` is the in-degree array produced by sgf_csr_build.  `is_symmetric`
+ * (int32[1], device) is set to 1 when A^T == A entry for entry, in which case the caller may
+ * reuse the forward CSR and drop the transposed arrays. */
+int sgf_csr_transpose(const int64_t* edge_index, int64_t nnz, int64_t n, const int32_t* deg,
+                      const int64_t* rowptr, const int32_t* colind, int64_t* t_rowptr,
+                      int32_t* t_colind, float* t_val, int32_t* is_symmetric, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T2 — sum-reduce CSR SpMM.   Replaces torch_sparse.matmul(adj, x) at large/ours.py:34
+ * (third-party torch_sparse 0.6.10 spmm, reduce="sum"):  Y[i,:] = sum_e val[e] * X[colind[e],:]
+ * for e in [rowptr[i], rowptr[i+1]), accumulated in fp32 in stored order.
+ * Backward (dX = A^T dY) is the same call on the transposed CSR (or the same CSR if symmetric).
+ *   x : [n_cols_of_A, d] dtype, leading dim ldx;  y : [n_rows, d] dtype, leading dim ldy.
+ * d, ldx, ldy must be multiples of 4 elements; x and y aligned to 4 elements.
+ * ------------------------------------------------------------------------------------------ */
+int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
+             int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
+             void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T3 — linear global attention core.   Replaces large/ours.py:130-149,157
+ * (= medium/ours.py:14-46 full_attention_conv, 100M/ours.py:12-53), per head h:
+ *     qn = Q/||Q||_F ; kn = K/||K||_F            (Frobenius norms over the WHOLE [N,H,d] tensors)
+ *     S = kn^T V ; z = sum_l kn_l ; num = qn S + N V ; den = qn z + N ; out = mean_h(num/den)
+ * The library never writes normalised copies of Q/K: it reduces the un-normalised partials
+ *     stats = [ S0 = K^T V  (H*d*d) | z0 = sum_l K_l (H*d) | ssq_q | ssq_k ]       (fp32)
+ * in one streaming pass (sgf_attn_fwd_reduce), which is also exactly the buffer a node-sharded
+ * multi-GPU run all-reduces, and applies them in a second pass
+ * (sgf_attn_fwd_apply) with  c = 1/(||Q|| ||K||):
+ *     den_n = c * Q_n.z0 + Ntot ;  out_n = (1/H) sum_h (c * Q_n S0 + Ntot * V_n) / den_n
+ *
+ *   q,k  : [n, H, d] (leading dims ldq/ldk >= H*d);   v : [n, Hv, d], Hv = H or 1 (Hv = 1 is the
+ *          use_weight=False broadcast of large/ours.py:128,138)
+ *   stats: fp32 [H*d*d + H*d + 2]  (sgf_attn_stats_len)
+ *   n_total : the N that appears in num/den (global node count when node-sharded)
+ *   den  : fp32 [n, H] out (saved for backward);  o_heads : [n, H, d] per-head outputs, required
+ *          (non-NULL) when H > 1, ignored when H == 1 (then o == out).
+ * Supported: d % 4 == 0 and d <= 256 (all reference recipes use 64 / 128 / 256).
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgf_attn_stats_len(int32_t heads, int32_t d);
+size_t sgf_attn_workspace_bytes(int64_t n, int32_t heads, int32_t d);
+
+int sgf_attn_fwd_reduce(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                        int64_t ldv, int64_t n, int32_t heads, int32_t v_heads, int32_t d,
+                        int32_t dtype, float* stats, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+int sgf_attn_fwd_apply(const void* q, int64_t ldq, const void* v, int64_t ldv, int64_t n,
+                       double n_total, int32_t heads, int32_t v_heads, int32_t d, int32_t dtype,
+                       const float* stats, void* out, int64_t ldo, float* den, void* o_heads,
+                       void* stream);
+
+/* Backward of the above (hand-derived), given g = dL/dout [n, d]:
+ *     dnum = (g/H)/den ; dden = -((g/H).o)/den                              (row-local)
+ *     bstats = [ dS0 = sum_n Q_n^T dnum_n (H*d*d) | dz0 = sum_n Q_n dden_n (H*d) ]   (fp32)
+ * (sgf_attn_bwd_reduce; again the all-reduce payload when node-sharded), then with
+ *     s = c * (<S0,dS0> + <z0,dz0>)        (= <qn,dqn> = <kn,dkn>, both radial terms)
+ *     dQ = c (dnum S0^T + dden z0) - s Q/||Q||^2
+ *     dK = c (V dS0^T + dz0)       - s K/||K||^2
+ *     dV = Ntot dnum + c K dS0                       (summed over heads when Hv == 1)
+ * (sgf_attn_bwd_apply).  `o` is o_heads when H > 1 and `out` when H == 1.
+ * bstats has H*d*d + H*d + 1 floats: the last slot is zeroed by sgf_attn_bwd_reduce (so the whole
+ * buffer can be all-reduced) and filled with <S0,dS0> + <z0,dz0> by sgf_attn_bwd_apply. */
+int64_t sgf_attn_bstats_len(int32_t heads, int32_t d);
+
+int sgf_attn_bwd_reduce(const void* q, int64_t ldq, const void* g, int64_t ldg, const void* o,
+                        int64_t ldo, const float* den, int64_t n, int32_t heads, int32_t d,
+                        int32_t dtype, float* bstats, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+int sgf_attn_bwd_apply(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                       int64_t ldv, const void* g, int64_t ldg, const void* o, int64_t ldo,
+                       const float* den, int64_t n, double n_total, int32_t heads,
+                       int32_t v_heads, int32_t d, int32_t dtype, const float* stats,
+                       float* bstats, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                       void* dv, int64_t lddv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T5 — TransConv glue.   Replaces large/ours.py:198-202 and :210-216 (medium/ours.py:150-156,
+ * 100M/ours.py:262-268):   y = [relu]( LayerNorm( a * x + b * res ) )   row-wise
+ * (large: a = b = 1/2; medium / 100M: a = alpha, b = 1 - alpha; input stem: a = 1, res = NULL).
+ * res NULL = no residual; gamma NULL = no LayerNorm (use_bn False; beta then ignored).
+ * Saves mean / rstd per row (fp32 [n] each, may be NULL when gamma is NULL) for the backward.
+ * d % 4 == 0, d <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int sgf_ln_fwd(const void* x, int64_t ldx, const void* res, int64_t ldr, float a, float b,
+               const float* gamma, const float* beta, int32_t relu, float eps, int64_t n,
+               int32_t d, int32_t dtype, void* y, int64_t ldy, float* mean, float* rstd,
+               void* stream);
+
+/* Backward: dz = dy masked by relu (y > 0);  LayerNorm backward to dpre;  dx = a * dpre,
+ * dres = b * dpre (dres may be NULL);  dgamma / dbeta (fp32 [d], may be NULL when gamma is NULL)
+ * are reduced deterministically through per-block partials in `workspace`. */
+size_t sgf_ln_bwd_workspace_bytes(int64_t n, int32_t d);
+int sgf_ln_bwd(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x,
+               int64_t ldx, const void* res, int64_t ldr, float a, float b, const float* gamma,
+               int32_t relu, const float* mean, const float* rstd, int64_t n, int32_t d,
+               int32_t dtype, void* dx, int64_t lddx, void* dres, int64_t lddres, float* dgamma,
+               float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T6 — GraphConv glue.   Replaces large/ours.py:77-81 and :87-93:
+ *     y = [relu]( BatchNorm1d(x) ) [+ res]          (dropout, when p > 0, stays in the caller)
+ * BatchNorm1d statistics in training mode are over ALL rows — a hidden global reduction — so the
+ * op is split at the reduction, which is also where a node-sharded run all-reduces:
+ *     sgf_colstats     : stats = [ sum_n (x[n,j]-shift[j]) | sum_n (x[n,j]-shift[j])^2 ]  fp32 [2*d]
+ *                        (shift NULL = 0).  Two calls give a two-pass mean / variance.
+ *     sgf_bn_apply     : y = [relu]((x - mean[j]) * rstd[j] * gamma[j] + beta[j]) [+ res]
+ *     sgf_bn_bwd_stats : stats = [ sum_n dz[n,j] | sum_n dz[n,j] * xhat[n,j] ]   (= dbeta | dgamma)
+ *                        dz = dy masked by the recomputed relu, xhat = (x - mean) * rstd
+ *     sgf_bn_bwd_apply : dx = gamma*rstd * (dz - [training](stats0*inv_n + xhat*stats1*inv_n))
+ * The residual gradient is dy itself.  gamma / beta NULL = 1 / 0.  d % 4 == 0, d <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_colstats_workspace_bytes(int64_t n, int32_t d);
+int sgf_colstats(const void* x, int64_t ldx, const float* shift, int64_t n, int32_t d,
+                 int32_t dtype, float* stats, void* workspace, size_t workspace_bytes,
+                 void* stream);
+int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const float* rstd,
+                 const float* gamma, const float* beta, const void* res, int64_t ldr,
+                 int32_t relu, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,
+                 void* stream);
+int sgf_bn_bwd_stats(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                     int64_t n, int32_t d, int32_t dtype, float* stats, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                     const float* stats, float inv_n, int32_t training, int64_t n, int32_t d,
+                     int32_t dtype, void* dx, int64_t lddx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T7 — branch combine.   Replaces large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.
+ * (generic axpby: y = a * x1 + b * x2; the 'cat' aggregate is a plain copy done by the caller.)
+ * ------------------------------------------------------------------------------------------ */
+int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+              int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGF_H_ */

@@ -1,0 +1,97 @@
+"""ctypes binding of libsgf.so (the C ABI declared in include/sgf.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, the product
+path raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsgf.so")
+
+SGF_F32 = 0
+SGF_BF16 = 1
+
+_lib = None
+
+# name -> (restype, argtypes).  Order and types mirror include/sgf.h exactly.
+_P = c_void_p
+SIGNATURES = {
+    "sgf_version": (c_int32, []),
+    "sgf_last_error": (c_char_p, []),
+    "sgf_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgf_csr_build": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_csr_transpose": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_spmm": (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P]),
+    "sgf_attn_stats_len": (c_int64, [c_int32, c_int32]),
+    "sgf_attn_bstats_len": (c_int64, [c_int32, c_int32]),
+    "sgf_attn_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "sgf_attn_fwd_reduce": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32,
+                                      c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_attn_fwd_apply": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_double, c_int32, c_int32,
+                                     c_int32, c_int32, _P, _P, c_int64, _P, _P, _P]),
+    "sgf_attn_bwd_reduce": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32,
+                                      c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_attn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
+                                     _P, c_int64, c_double, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                     _P, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "sgf_ln_fwd": (c_int32, [_P, c_int64, _P, c_int64, c_float, c_float, _P, _P, c_int32, c_float,
+                             c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
+    "sgf_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "sgf_ln_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_float, c_float, _P,
+                             c_int32, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P,
+                             _P, _P, c_size_t, _P]),
+    "sgf_colstats_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "sgf_colstats": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_bn_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
+                               c_int32, _P, c_int64, _P]),
+    "sgf_bn_bwd_stats": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, c_int64, c_int32,
+                                   c_int32, _P, _P, c_size_t, _P]),
+    "sgf_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float,
+                                   c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
+    "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
+                            c_int64, _P]),
+}
+
+
+class SgfError(RuntimeError):
+    """A libsgf call returned a non-zero status (mirrors PyTorch: RuntimeError)."""
+
+
+def load():
+    """dlopen libsgf.so (after torch, so both bind the same libamdhip64.so.7) and type its symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgfError(
+            f"libsgf.so not found at {LIB_PATH}: build it with `make` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`).  sgformer_amd has no CPU / "
+            "eager fallback by design.")
+    import torch  # noqa: F401  (loads torch's bundled HIP runtime first; same SONAME)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sgf_last_error()
+        raise SgfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise SgfError on failure."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,126 @@
+// common.h — shared helpers for the gfx950 kernels of libsgf (not part of the C ABI).
+#pragma once
+#include <cstring>  // must precede rocprim (host memset)
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+
+#include "../../include/sgf.h"
+
+namespace sgf {
+
+// ---- error reporting -----------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define SGF_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::sgf::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return SGF_E_HIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+#define SGF_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::sgf::set_error(__VA_ARGS__);      \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+#define SGF_LAUNCH_CHECK()                                                          \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) {                                                         \
+      ::sgf::set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__,            \
+                       hipGetErrorString(_e));                                      \
+      return SGF_E_HIP;                                                             \
+    }                                                                               \
+  } while (0)
+
+// ---- chip constants (MI355X / gfx950) ------------------------------------------------------
+constexpr int kWave = 64;      // wavefront width
+constexpr int kNumCU = 256;    // 8 XCDs x 32 CUs
+constexpr int kNumXCD = 8;
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- bf16 <-> fp32 (storage format only; all arithmetic is fp32) ----------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+  return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+// round-to-nearest-even, NaN preserved (same rule as torch.bfloat16 casts)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+struct alignas(8) bf16x4 {
+  uint16_t v[4];
+};
+
+// 4-element vector load/store in the storage dtype, fp32 in registers.
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+template <>
+__device__ __forceinline__ float4 load4<uint16_t>(const uint16_t* p) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  float4 f;
+  f.x = __uint_as_float(r.x << 16);
+  f.y = __uint_as_float(r.x & 0xffff0000u);
+  f.z = __uint_as_float(r.y << 16);
+  f.w = __uint_as_float(r.y & 0xffff0000u);
+  return f;
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float4 f);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float4 f) {
+  *reinterpret_cast<float4*>(p) = f;
+}
+template <>
+__device__ __forceinline__ void store4<uint16_t>(uint16_t* p, float4 f) {
+  uint2 r;
+  r.x = static_cast<uint32_t>(f32_to_bf16(f.x)) | (static_cast<uint32_t>(f32_to_bf16(f.y)) << 16);
+  r.y = static_cast<uint32_t>(f32_to_bf16(f.z)) | (static_cast<uint32_t>(f32_to_bf16(f.w)) << 16);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+template <typename T>
+__device__ __forceinline__ float load1(const T* p);
+template <>
+__device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load1<uint16_t>(const uint16_t* p) { return bf16_to_f32(*p); }
+template <typename T>
+__device__ __forceinline__ void store1(T* p, float f);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float f) { *p = f; }
+template <>
+__device__ __forceinline__ void store1<uint16_t>(uint16_t* p, float f) { *p = f32_to_bf16(f); }
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- MFMA (exact-fp32 matrix cores; cdna_hip_programming.md §3) ------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// C/D layout of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int mfma32_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+}  // namespace sgf

@@ -1,0 +1,672 @@
+// fused.hip — T5/T6/T7: the HBM-bound glue around the two branches, one pass each.
+//
+//   sgf_ln_fwd / sgf_ln_bwd : y = [relu](LayerNorm(a*x + b*res))    large/ours.py:198-202,210-216
+//   sgf_colstats / sgf_bn_* : y = [relu](BatchNorm1d(x)) [+ res]    large/ours.py:77-81,87-93
+//   sgf_axpby               : y = a*x1 + b*x2                        large/ours.py:269-270
+//
+// The reference runs each of these as 3-6 separate ATen passes over [N, d]; here each is one read
+// of its inputs and one write of its output, 16 B per lane, fp32 arithmetic whatever the storage
+// dtype.  Cross-row reductions (BatchNorm statistics, dgamma / dbeta) are two-stage and
+// deterministic: per-block partials in a caller-provided workspace, then a fixed-order sum.
+#include "common.h"
+
+namespace sgf {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxD = 1024;
+constexpr int kMaxStatBlocks = 1024;
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+inline int lanes_per_row(int d) {
+  int l = 16;
+  while (l * 4 < d && l < 64) l <<= 1;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward:  LPR lanes per row, NC float4 chunks per lane (d <= 4*LPR*NC)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR, int NC>
+__global__ __launch_bounds__(kThreads) void k_ln_fwd(
+    const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldr, float a, float b,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, float eps, int64_t n,
+    int d, T* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd) {
+  constexpr int RPB = kThreads / LPR;
+  const int sl = threadIdx.x % LPR;
+  const int sr = threadIdx.x / LPR;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * RPB; row0 < n;
+       row0 += static_cast<int64_t>(gridDim.x) * RPB) {
+    const int64_t row = row0 + sr;
+    const bool rok = row < n;
+    float4 pre[NC];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * LPR + sl) * 4;
+      const bool ok = rok && col < d;
+      float4 v = ok ? load4<T>(x + row * ldx + col) : zero4();
+      v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+      if (res != nullptr && ok) {
+        const float4 r = load4<T>(res + row * ldr + col);
+        v.x = fmaf(b, r.x, v.x); v.y = fmaf(b, r.y, v.y);
+        v.z = fmaf(b, r.z, v.z); v.w = fmaf(b, r.w, v.w);
+      }
+      pre[c] = v;
+      sum += v.x + v.y + v.z + v.w;
+    }
+    float mu = 0.f, rs = 1.f;
+    if (gamma != nullptr) {
+      mu = group_sum<LPR>(sum) / static_cast<float>(d);
+      float sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = (c * LPR + sl) * 4;
+        if (col < d) {
+          const float dx = pre[c].x - mu, dy = pre[c].y - mu, dz = pre[c].z - mu, dw = pre[c].w - mu;
+          sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+      }
+      const float var = group_sum<LPR>(sq) / static_cast<float>(d);
+      rs = 1.0f / sqrtf(var + eps);
+      if (sl == 0 && rok) {
+        mean[row] = mu;
+        rstd[row] = rs;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * LPR + sl) * 4;
+      if (rok && col < d) {
+        float4 o = pre[c];
+        if (gamma != nullptr) {
+          const float4 g = ld4f(gamma + col);
+          const float4 be = ld4f(beta + col);
+          o.x = (o.x - mu) * rs * g.x + be.x;
+          o.y = (o.y - mu) * rs * g.y + be.y;
+          o.z = (o.z - mu) * rs * g.z + be.z;
+          o.w = (o.w - mu) * rs * g.w + be.w;
+        }
+        if (relu) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        store4<T>(y + row * ldy + col, o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  Per-block partial dgamma/dbeta: part[blk][2][d].
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR, int NC>
+__global__ __launch_bounds__(kThreads) void k_ln_bwd(
+    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ y, int64_t ldy,
+    const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldr, float a, float b,
+    const float* __restrict__ gamma, int relu, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int64_t n, int d, T* __restrict__ dxo, int64_t lddx,
+    T* __restrict__ dro, int64_t lddr, float* __restrict__ part) {
+  constexpr int RPB = kThreads / LPR;
+  __shared__ float red[2 * RPB * LPR * NC * 4];
+  const int sl = threadIdx.x % LPR;
+  const int sr = threadIdx.x / LPR;
+  float4 dg[NC], db[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    dg[c] = zero4();
+    db[c] = zero4();
+  }
+  const bool ln = gamma != nullptr;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * RPB; row0 < n;
+       row0 += static_cast<int64_t>(gridDim.x) * RPB) {
+    const int64_t row = row0 + sr;
+    const bool rok = row < n;
+    const float mu = (ln && rok) ? mean[row] : 0.f;
+    const float rs = (ln && rok) ? rstd[row] : 1.f;
+    float4 dz[NC], xh[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * LPR + sl) * 4;
+      const bool ok = rok && col < d;
+      float4 g = ok ? load4<T>(dy + row * lddy + col) : zero4();
+      if (relu && ok) {
+        const float4 yy = load4<T>(y + row * ldy + col);
+        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+        g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+      }
+      float4 h = zero4();
+      if (ln && ok) {
+        float4 v = load4<T>(x + row * ldx + col);
+        v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+        if (res != nullptr) {
+          const float4 r = load4<T>(res + row * ldr + col);
+          v.x = fmaf(b, r.x, v.x); v.y = fmaf(b, r.y, v.y);
+          v.z = fmaf(b, r.z, v.z); v.w = fmaf(b, r.w, v.w);
+        }
+        h = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+        const float4 gm = ld4f(gamma + col);
+        dg[c].x += g.x * h.x; dg[c].y += g.y * h.y; dg[c].z += g.z * h.z; dg[c].w += g.w * h.w;
+        db[c].x += g.x; db[c].y += g.y; db[c].z += g.z; db[c].w += g.w;
+        g.x *= gm.x; g.y *= gm.y; g.z *= gm.z; g.w *= gm.w;  // dxhat
+        s1 += g.x + g.y + g.z + g.w;
+        s2 += g.x * h.x + g.y * h.y + g.z * h.z + g.w * h.w;
+      }
+      dz[c] = g;
+      xh[c] = h;
+    }
+    float m1 = 0.f, m2 = 0.f;
+    if (ln) {
+      m1 = group_sum<LPR>(s1) / static_cast<float>(d);
+      m2 = group_sum<LPR>(s2) / static_cast<float>(d);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * LPR + sl) * 4;
+      if (rok && col < d) {
+        float4 dp = dz[c];
+        if (ln) {
+          dp.x = rs * (dp.x - m1 - xh[c].x * m2);
+          dp.y = rs * (dp.y - m1 - xh[c].y * m2);
+          dp.z = rs * (dp.z - m1 - xh[c].z * m2);
+          dp.w = rs * (dp.w - m1 - xh[c].w * m2);
+        }
+        store4<T>(dxo + row * lddx + col, make_float4(a * dp.x, a * dp.y, a * dp.z, a * dp.w));
+        if (dro != nullptr)
+          store4<T>(dro + row * lddr + col, make_float4(b * dp.x, b * dp.y, b * dp.z, b * dp.w));
+      }
+    }
+  }
+  if (!ln) return;
+  // block reduce of dg / db over the RPB row-slots (fixed order)
+  constexpr int W = LPR * NC * 4;  // padded width
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (c * LPR + sl) * 4;
+    *reinterpret_cast<float4*>(&red[(0 * RPB + sr) * W + col]) = dg[c];
+    *reinterpret_cast<float4*>(&red[(1 * RPB + sr) * W + col]) = db[c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * d; j += kThreads) {
+    const int which = j / d, col = j % d;
+    float s = 0.f;
+    for (int r = 0; r < RPB; ++r) s += red[(which * RPB + r) * W + col];
+    part[static_cast<int64_t>(blockIdx.x) * 2 * d + j] = s;
+  }
+}
+
+// out[j] = sum_b part[b][j], j < width (fixed order)
+__global__ void k_sum_partials(const float* __restrict__ part, int nblk, int width,
+                               float* __restrict__ out0, float* __restrict__ out1, int split) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[static_cast<int64_t>(b) * width + j];
+  if (j < split) {
+    if (out0) out0[j] = s;
+  } else {
+    if (out1) out1[j - split] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column statistics skeleton: each thread owns one float4 column chunk and a row slot; functor F
+// maps (row, col) -> two float4 contributions.  part[blk][2][d].
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+__global__ __launch_bounds__(kThreads) void k_colreduce(F f, int64_t n, int d,
+                                                        float* __restrict__ part) {
+  __shared__ float red[2 * kThreads * 4];
+  const int f4 = d / 4;
+  const int rpp = kThreads / f4;  // row slots per pass (>= 1 since d <= 1024)
+  const int c4 = threadIdx.x % f4;
+  const int sr = threadIdx.x / f4;
+  const bool act = sr < rpp;
+  const int col = c4 * 4;
+  float4 s0 = zero4(), s1 = zero4();
+  if (act) {
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    for (int64_t row = r0 + sr; row < r1; row += rpp) {
+      float4 v0, v1;
+      f(row, col, v0, v1);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[threadIdx.x * 4]) = s0;
+  *reinterpret_cast<float4*>(&red[(kThreads + threadIdx.x) * 4]) = s1;
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * d; j += kThreads) {
+    const int which = j / d, cc = j % d;
+    float s = 0.f;
+    for (int r = 0; r < rpp; ++r) s += red[(which * kThreads + r * f4 + cc / 4) * 4 + (cc & 3)];
+    part[static_cast<int64_t>(blockIdx.x) * 2 * d + j] = s;
+  }
+}
+
+template <typename T>
+struct ColStatsF {
+  const T* x; int64_t ldx; const float* shift;
+  __device__ void operator()(int64_t row, int col, float4& v0, float4& v1) const {
+    float4 v = load4<T>(x + row * ldx + col);
+    if (shift) {
+      const float4 s = ld4f(shift + col);
+      v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w;
+    }
+    v0 = v;
+    v1 = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+  }
+};
+
+struct BnParams {
+  const float *mean, *rstd, *gamma, *beta;
+};
+__device__ __forceinline__ void bn_coeffs(const BnParams& p, int col, float4& mu, float4& rs,
+                                          float4& ga, float4& be) {
+  mu = ld4f(p.mean + col);
+  rs = ld4f(p.rstd + col);
+  ga = p.gamma ? ld4f(p.gamma + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+  be = p.beta ? ld4f(p.beta + col) : zero4();
+}
+
+template <typename T>
+struct BnBwdStatsF {
+  const T* dy; int64_t lddy; const T* x; int64_t ldx; BnParams p; int relu;
+  __device__ void operator()(int64_t row, int col, float4& v0, float4& v1) const {
+    float4 mu, rs, ga, be;
+    bn_coeffs(p, col, mu, rs, ga, be);
+    const float4 xv = load4<T>(x + row * ldx + col);
+    float4 g = load4<T>(dy + row * lddy + col);
+    const float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z,
+                                  (xv.w - mu.w) * rs.w);
+    if (relu) {
+      g.x = (xh.x * ga.x + be.x) > 0.f ? g.x : 0.f;
+      g.y = (xh.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+      g.z = (xh.z * ga.z + be.z) > 0.f ? g.z : 0.f;
+      g.w = (xh.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+    }
+    v0 = g;
+    v1 = make_float4(g.x * xh.x, g.y * xh.y, g.z * xh.z, g.w * xh.w);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// elementwise: BN apply / BN backward apply / axpby.  One float4 per thread per step.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const T* __restrict__ x, int64_t ldx,
+                                                       BnParams p, const T* __restrict__ res,
+                                                       int64_t ldr, int relu, int64_t n, int d,
+                                                       T* __restrict__ y, int64_t ldy) {
+  const int f4 = d / 4;
+  const int64_t total = n * f4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / f4;
+    const int col = static_cast<int>(i % f4) * 4;
+    float4 mu, rs, ga, be;
+    bn_coeffs(p, col, mu, rs, ga, be);
+    const float4 xv = load4<T>(x + row * ldx + col);
+    float4 o = make_float4((xv.x - mu.x) * rs.x * ga.x + be.x, (xv.y - mu.y) * rs.y * ga.y + be.y,
+                           (xv.z - mu.z) * rs.z * ga.z + be.z, (xv.w - mu.w) * rs.w * ga.w + be.w);
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    if (res != nullptr) {
+      const float4 r = load4<T>(res + row * ldr + col);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    store4<T>(y + row * ldy + col, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
+    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, BnParams p,
+    int relu, const float* __restrict__ stats, float inv_n, int training, int64_t n, int d,
+    T* __restrict__ dx, int64_t lddx) {
+  const int f4 = d / 4;
+  const int64_t total = n * f4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / f4;
+    const int col = static_cast<int>(i % f4) * 4;
+    float4 mu, rs, ga, be;
+    bn_coeffs(p, col, mu, rs, ga, be);
+    const float4 xv = load4<T>(x + row * ldx + col);
+    float4 g = load4<T>(dy + row * lddy + col);
+    const float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z,
+                                  (xv.w - mu.w) * rs.w);
+    if (relu) {
+      g.x = (xh.x * ga.x + be.x) > 0.f ? g.x : 0.f;
+      g.y = (xh.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+      g.z = (xh.z * ga.z + be.z) > 0.f ? g.z : 0.f;
+      g.w = (xh.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+    }
+    if (training) {
+      const float4 s0 = ld4f(stats + col);
+      const float4 s1 = ld4f(stats + d + col);
+      g.x -= s0.x * inv_n + xh.x * s1.x * inv_n;
+      g.y -= s0.y * inv_n + xh.y * s1.y * inv_n;
+      g.z -= s0.z * inv_n + xh.z * s1.z * inv_n;
+      g.w -= s0.w * inv_n + xh.w * s1.w * inv_n;
+    }
+    store4<T>(dx + row * lddx + col,
+              make_float4(ga.x * rs.x * g.x, ga.y * rs.y * g.y, ga.z * rs.z * g.z, ga.w * rs.w * g.w));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_axpby(const T* __restrict__ x1, int64_t ld1, float a,
+                                                    const T* __restrict__ x2, int64_t ld2, float b,
+                                                    int64_t n, int d, T* __restrict__ y,
+                                                    int64_t ldy) {
+  const int f4 = d / 4;
+  const int64_t total = n * f4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / f4;
+    const int col = static_cast<int>(i % f4) * 4;
+    const float4 u = load4<T>(x1 + row * ld1 + col);
+    const float4 v = load4<T>(x2 + row * ld2 + col);
+    store4<T>(y + row * ldy + col,
+              make_float4(a * u.x + b * v.x, a * u.y + b * v.y, a * u.z + b * v.z, a * u.w + b * v.w));
+  }
+}
+
+inline int ew_grid(int64_t total_vec) {
+  int64_t b = (total_vec + kThreads - 1) / kThreads;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+inline int stat_blocks(int64_t n) {
+  int64_t b = (n + 63) / 64;  // >= 64 rows per block
+  if (b > kMaxStatBlocks) b = kMaxStatBlocks;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+int check_ew(const char* fn, int64_t n, int d, int dtype) {
+  SGF_REQUIRE(n >= 0 && d >= 1, SGF_E_INVALID, "%s: bad sizes n=%lld d=%d", fn,
+              static_cast<long long>(n), d);
+  SGF_REQUIRE(d % 4 == 0 && d <= kMaxD, SGF_E_UNSUPPORTED,
+              "%s: d=%d unsupported (need d %% 4 == 0 and d <= %d)", fn, d, kMaxD);
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "%s: unknown dtype %d", fn,
+              dtype);
+  return SGF_OK;
+}
+
+template <typename T, typename... Args>
+int launch_ln_fwd(int lpr, int nc, dim3 grid, hipStream_t st, Args... args) {
+#define SGF_LN(L, C)                                                                   \
+  if (lpr == L && nc == C) {                                                           \
+    hipLaunchKernelGGL((k_ln_fwd<T, L, C>), grid, dim3(kThreads), 0, st, args...);     \
+    SGF_LAUNCH_CHECK();                                                                \
+    return SGF_OK;                                                                     \
+  }
+  SGF_LN(16, 1) SGF_LN(32, 1) SGF_LN(64, 1) SGF_LN(64, 2) SGF_LN(64, 3) SGF_LN(64, 4)
+#undef SGF_LN
+  set_error("sgf_ln_fwd: no kernel for lpr=%d nc=%d", lpr, nc);
+  return SGF_E_UNSUPPORTED;
+}
+template <typename T, typename... Args>
+int launch_ln_bwd(int lpr, int nc, dim3 grid, hipStream_t st, Args... args) {
+#define SGF_LN(L, C)                                                                   \
+  if (lpr == L && nc == C) {                                                           \
+    hipLaunchKernelGGL((k_ln_bwd<T, L, C>), grid, dim3(kThreads), 0, st, args...);     \
+    SGF_LAUNCH_CHECK();                                                                \
+    return SGF_OK;                                                                     \
+  }
+  SGF_LN(16, 1) SGF_LN(32, 1) SGF_LN(64, 1) SGF_LN(64, 2) SGF_LN(64, 3) SGF_LN(64, 4)
+#undef SGF_LN
+  set_error("sgf_ln_bwd: no kernel for lpr=%d nc=%d", lpr, nc);
+  return SGF_E_UNSUPPORTED;
+}
+
+inline int ln_grid(int64_t n, int lpr) {
+  const int rpb = kThreads / lpr;
+  int64_t b = (n + rpb - 1) / rpb;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+inline int ln_bwd_grid(int64_t n, int lpr) {
+  const int rpb = kThreads / lpr;
+  int64_t b = (n + rpb - 1) / rpb;
+  if (b > kMaxStatBlocks) b = kMaxStatBlocks;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+template <typename T>
+int ln_fwd_t(const void* x, int64_t ldx, const void* res, int64_t ldr, float a, float b,
+             const float* gamma, const float* beta, int relu, float eps, int64_t n, int d, void* y,
+             int64_t ldy, float* mean, float* rstd, hipStream_t st) {
+  const int lpr = lanes_per_row(d);
+  const int nc = (d + 4 * lpr - 1) / (4 * lpr);
+  return launch_ln_fwd<T>(lpr, nc, dim3(ln_grid(n, lpr)), st, static_cast<const T*>(x), ldx,
+                          static_cast<const T*>(res), ldr, a, b, gamma, beta, relu, eps, n, d,
+                          static_cast<T*>(y), ldy, mean, rstd);
+}
+
+template <typename T>
+int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx,
+             const void* res, int64_t ldr, float a, float b, const float* gamma, int relu,
+             const float* mean, const float* rstd, int64_t n, int d, void* dx, int64_t lddx,
+             void* dres, int64_t lddres, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+  const int lpr = lanes_per_row(d);
+  const int nc = (d + 4 * lpr - 1) / (4 * lpr);
+  const int nblk = ln_bwd_grid(n, lpr);
+  float* part = static_cast<float*>(ws);
+  int rc = launch_ln_bwd<T>(lpr, nc, dim3(nblk), st, static_cast<const T*>(dy), lddy,
+                            static_cast<const T*>(y), ldy, static_cast<const T*>(x), ldx,
+                            static_cast<const T*>(res), ldr, a, b, gamma, relu, mean, rstd, n, d,
+                            static_cast<T*>(dx), lddx, static_cast<T*>(dres), lddres, part);
+  if (rc != SGF_OK) return rc;
+  if (gamma != nullptr && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, nblk,
+                       2 * d, dgamma, dbeta, d);
+    SGF_LAUNCH_CHECK();
+  }
+  return SGF_OK;
+}
+
+template <typename F>
+int colreduce(F f, int64_t n, int d, float* stats, void* ws, hipStream_t st) {
+  const int nblk = stat_blocks(n);
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL((k_colreduce<F>), dim3(nblk), dim3(kThreads), 0, st, f, n, d, part);
+  SGF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, nblk, 2 * d,
+                     stats, stats + d, d);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+}  // namespace
+}  // namespace sgf
+
+using namespace sgf;
+
+extern "C" int sgf_ln_fwd(const void* x, int64_t ldx, const void* res, int64_t ldr, float a,
+                          float b, const float* gamma, const float* beta, int32_t relu, float eps,
+                          int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, float* mean,
+                          float* rstd, void* stream) {
+  int rc = check_ew("sgf_ln_fwd", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(x && y && (!gamma || (beta && mean && rstd)), SGF_E_INVALID, "sgf_ln_fwd: null pointer");
+  SGF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SGF_E_INVALID,
+              "sgf_ln_fwd: leading dims must be multiples of 4");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32)
+    return ln_fwd_t<float>(x, ldx, res, ldr, a, b, gamma, beta, relu, eps, n, d, y, ldy, mean, rstd, st);
+  return ln_fwd_t<uint16_t>(x, ldx, res, ldr, a, b, gamma, beta, relu, eps, n, d, y, ldy, mean, rstd, st);
+}
+
+extern "C" size_t sgf_ln_bwd_workspace_bytes(int64_t n, int32_t d) {
+  (void)n;
+  if (d < 1) return 0;
+  return static_cast<size_t>(kMaxStatBlocks) * 2 * d * sizeof(float);
+}
+
+extern "C" int sgf_ln_bwd(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x,
+                          int64_t ldx, const void* res, int64_t ldr, float a, float b,
+                          const float* gamma, int32_t relu, const float* mean, const float* rstd,
+                          int64_t n, int32_t d, int32_t dtype, void* dx, int64_t lddx, void* dres,
+                          int64_t lddres, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  int rc = check_ew("sgf_ln_bwd", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (gamma && dgamma) SGF_CHECK_HIP(hipMemsetAsync(dgamma, 0, d * sizeof(float), st));
+    if (gamma && dbeta) SGF_CHECK_HIP(hipMemsetAsync(dbeta, 0, d * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(dy && dx && (!relu || y) && (!gamma || (x && mean && rstd)), SGF_E_INVALID,
+              "sgf_ln_bwd: null pointer");
+  SGF_REQUIRE(!gamma || (workspace && workspace_bytes >= sgf_ln_bwd_workspace_bytes(n, d)),
+              SGF_E_WORKSPACE, "sgf_ln_bwd: workspace too small");
+  if (dtype == SGF_F32)
+    return ln_bwd_t<float>(dy, lddy, y, ldy, x, ldx, res, ldr, a, b, gamma, relu, mean, rstd, n, d,
+                           dx, lddx, dres, lddres, dgamma, dbeta, workspace, st);
+  return ln_bwd_t<uint16_t>(dy, lddy, y, ldy, x, ldx, res, ldr, a, b, gamma, relu, mean, rstd, n, d,
+                            dx, lddx, dres, lddres, dgamma, dbeta, workspace, st);
+}
+
+extern "C" size_t sgf_colstats_workspace_bytes(int64_t n, int32_t d) {
+  (void)n;
+  if (d < 1) return 0;
+  return static_cast<size_t>(kMaxStatBlocks) * 2 * d * sizeof(float);
+}
+
+extern "C" int sgf_colstats(const void* x, int64_t ldx, const float* shift, int64_t n, int32_t d,
+                            int32_t dtype, float* stats, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  int rc = check_ew("sgf_colstats", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SGF_REQUIRE(stats, SGF_E_INVALID, "sgf_colstats: null stats");
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * d * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(x && ldx % 4 == 0, SGF_E_INVALID, "sgf_colstats: bad x / ldx");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_colstats_workspace_bytes(n, d), SGF_E_WORKSPACE,
+              "sgf_colstats: workspace too small");
+  if (dtype == SGF_F32)
+    return colreduce(ColStatsF<float>{static_cast<const float*>(x), ldx, shift}, n, d, stats,
+                     workspace, st);
+  return colreduce(ColStatsF<uint16_t>{static_cast<const uint16_t*>(x), ldx, shift}, n, d, stats,
+                   workspace, st);
+}
+
+extern "C" int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, const void* res, int64_t ldr,
+                            int32_t relu, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,
+                            void* stream) {
+  int rc = check_ew("sgf_bn_apply", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(x && y && mean && rstd, SGF_E_INVALID, "sgf_bn_apply: null pointer");
+  SGF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SGF_E_INVALID,
+              "sgf_bn_apply: leading dims must be multiples of 4");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const BnParams p{mean, rstd, gamma, beta};
+  const dim3 grid(ew_grid(n * (d / 4)));
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_bn_apply<float>), grid, dim3(kThreads), 0, st,
+                       static_cast<const float*>(x), ldx, p, static_cast<const float*>(res), ldr,
+                       relu, n, d, static_cast<float*>(y), ldy);
+  else
+    hipLaunchKernelGGL((k_bn_apply<uint16_t>), grid, dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(x), ldx, p, static_cast<const uint16_t*>(res),
+                       ldr, relu, n, d, static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_bn_bwd_stats(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int32_t relu, int64_t n, int32_t d,
+                                int32_t dtype, float* stats, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  int rc = check_ew("sgf_bn_bwd_stats", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SGF_REQUIRE(stats, SGF_E_INVALID, "sgf_bn_bwd_stats: null stats");
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * d * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(dy && x && mean && rstd && lddy % 4 == 0 && ldx % 4 == 0, SGF_E_INVALID,
+              "sgf_bn_bwd_stats: bad pointer / ld");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_colstats_workspace_bytes(n, d), SGF_E_WORKSPACE,
+              "sgf_bn_bwd_stats: workspace too small");
+  const BnParams p{mean, rstd, gamma, beta};
+  if (dtype == SGF_F32)
+    return colreduce(BnBwdStatsF<float>{static_cast<const float*>(dy), lddy,
+                                        static_cast<const float*>(x), ldx, p, relu},
+                     n, d, stats, workspace, st);
+  return colreduce(BnBwdStatsF<uint16_t>{static_cast<const uint16_t*>(dy), lddy,
+                                         static_cast<const uint16_t*>(x), ldx, p, relu},
+                   n, d, stats, workspace, st);
+}
+
+extern "C" int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int32_t relu, const float* stats, float inv_n,
+                                int32_t training, int64_t n, int32_t d, int32_t dtype, void* dx,
+                                int64_t lddx, void* stream) {
+  int rc = check_ew("sgf_bn_bwd_apply", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(dy && x && dx && mean && rstd && (!training || stats), SGF_E_INVALID,
+              "sgf_bn_bwd_apply: null pointer");
+  SGF_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, SGF_E_INVALID,
+              "sgf_bn_bwd_apply: leading dims must be multiples of 4");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const BnParams p{mean, rstd, gamma, beta};
+  const dim3 grid(ew_grid(n * (d / 4)));
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_bn_bwd_apply<float>), grid, dim3(kThreads), 0, st,
+                       static_cast<const float*>(dy), lddy, static_cast<const float*>(x), ldx, p,
+                       relu, stats, inv_n, training, n, d, static_cast<float*>(dx), lddx);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<uint16_t>), grid, dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(x), ldx,
+                       p, relu, stats, inv_n, training, n, d, static_cast<uint16_t*>(dx), lddx);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                         int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream) {
+  int rc = check_ew("sgf_axpby", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(x1 && x2 && y && ld1 % 4 == 0 && ld2 % 4 == 0 && ldy % 4 == 0, SGF_E_INVALID,
+              "sgf_axpby: bad pointer / ld");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(ew_grid(n * (d / 4)));
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_axpby<float>), grid, dim3(kThreads), 0, st, static_cast<const float*>(x1),
+                       ld1, a, static_cast<const float*>(x2), ld2, b, n, d, static_cast<float*>(y), ldy);
+  else
+    hipLaunchKernelGGL((k_axpby<uint16_t>), grid, dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(x1), ld1, a, static_cast<const uint16_t*>(x2),
+                       ld2, b, n, d, static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}

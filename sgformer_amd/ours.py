@@ -1,0 +1,360 @@
+"""Drop-in for the reference's `large/ours.py` (and, via `variant`, `100M/ours.py`).
+
+Same public surface — class names, constructor keywords, attribute names, `state_dict` keys and
+parameter-creation order (hence the same seeded initialisation), `params1` / `params2`,
+`reset_parameters`, `get_attentions`, train/eval semantics — so `large/main.py` runs unchanged
+once this module is registered as `sys.modules['ours']` (see sgformer_amd/launch.py and
+SURVEY.md §8b).  Everything between the parameters and the output is different: the forward and
+backward run on the hand-written gfx950 kernels behind include/sgf.h.
+
+    reference                                   here
+    ----------------------------------------    ---------------------------------------------------
+    large/ours.py:26-33  degree+argsort / layer one cached CSR per edge_index   (ops.CSRGraph)
+    large/ours.py:34     torch_sparse.matmul    ops.spmm            (k_spmm_wave / k_spmm_sub)
+    large/ours.py:123-128 three Linear calls    one [d -> 3Hd] GEMM (hipBLASLt via F.linear)
+    large/ours.py:130-157 2 norms + 4 einsums   ops.attention       (k_attn_reduce / k_attn_apply)
+    large/ours.py:198-216 LN / relu / residual  ops.ln_res_act      (k_ln_fwd / k_ln_bwd)
+    large/ours.py:77-93  BN / relu / residual   ops.batch_stats + ops.bn_act_res
+    large/ours.py:269-270 weighted add          ops.axpby
+
+GPU only: a CPU tensor raises (no eager fallback by design).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+__all__ = ["GraphConvLayer", "GraphConv", "TransConvLayer", "TransConv", "SGFormer",
+           "full_attention_conv"]
+
+# Set by sgformer_amd.dist.shard_model(); None = single GPU.
+_NO_SHARD = None
+
+
+def _drop(x, p, training):
+    if training and p is not None and p > 0.0:
+        return F.dropout(x, p=p, training=True)
+    if p is None:
+        # large/parse.py:95 leaves --trans_dropout without a default: the reference then crashes
+        # inside F.dropout(p=None); surface the same misuse early and clearly.
+        raise TypeError("dropout probability is None (pass --trans_dropout / --gnn_dropout)")
+    return x
+
+
+def full_attention_conv(qs, ks, vs, output_attn=False, shard=None):
+    """medium/ours.py:14-46 / 100M/ours.py:12-53 as a free function: qs, ks [N,H,M], vs [N,H|1,D].
+
+    Returns the per-head-MEAN-free tensor the reference returns ([N,H,D]) when H == 1, and in
+    general the head mean expanded back is not recoverable, so for H > 1 this returns [N,1,D] * 1
+    only through `TransConvLayer`; direct callers with H > 1 get the head-mean [N, D].
+    """
+    n, h, d = qs.shape
+    qk = torch.cat([qs.reshape(n, h * d), ks.reshape(n, h * d)], dim=1)
+    if vs.shape[1] == h:
+        qkv = torch.cat([qk, vs.reshape(n, h * d)], dim=1)
+        out = ops.attention(qkv, None, h, d, shard)
+    else:
+        out = ops.attention(qk, vs.reshape(n, d), h, d, shard)
+    out = out.unsqueeze(1) if h == 1 else out
+    if output_attn:
+        return out, _attention_matrix(qs, ks)
+    return out
+
+
+def _attention_matrix(qs, ks):
+    """O(N^2) visualisation branch (large/ours.py:152-155); plain PyTorch on purpose."""
+    n = qs.shape[0]
+    qn = qs / torch.norm(qs, p=2)
+    kn = ks / torch.norm(ks, p=2)
+    attention = torch.einsum("nhm,lhm->nlh", qn, kn).mean(dim=-1)
+    normalizer = (torch.einsum("nhm,hm->nh", qn, kn.sum(dim=0)) + n).mean(dim=-1, keepdim=True)
+    return attention / normalizer
+
+
+class GraphConvLayer(nn.Module):
+    """A_norm X -> [cat x0] -> Linear   (large/ours.py:10-42)."""
+
+    def __init__(self, in_channels, out_channels, use_weight=True, use_init=False):
+        super().__init__()
+        self.use_init = use_init
+        self.use_weight = use_weight
+        in_channels_ = 2 * in_channels if use_init else in_channels
+        self.W = nn.Linear(in_channels_, out_channels)  # always constructed (kept in state_dict)
+        self._shard = _NO_SHARD
+
+    def reset_parameters(self):
+        self.W.reset_parameters()
+
+    def forward(self, x, edge_index, x0):
+        shard = self._shard
+        if shard is not None:
+            graph = shard.graph_for(edge_index)
+        else:
+            graph = ops.graph_cache.get(edge_index, x.shape[0])
+        y = ops.spmm(graph, x, shard)
+        if self.use_init:
+            d = y.shape[1]
+            w = self.W.weight
+            # W [y | x0] + b without materialising the concatenation
+            y = torch.addmm(torch.addmm(self.W.bias, y, w[:, :d].t()), x0, w[:, d:].t())
+        elif self.use_weight:
+            y = self.W(y)
+        return y
+
+
+class GraphConv(nn.Module):
+    """fc -> BN -> relu -> dropout -> Lg x [conv -> BN -> relu -> dropout -> + layer_[0]]
+    (large/ours.py:45-94; the residual always adds the post-stem embedding, :83-93)."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers=2, dropout=0.5, use_bn=True,
+                 use_residual=True, use_weight=True, use_init=False, use_act=True):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        self.fcs = nn.ModuleList()
+        self.fcs.append(nn.Linear(in_channels, hidden_channels))
+        self.bns = nn.ModuleList()
+        self.bns.append(nn.BatchNorm1d(hidden_channels))
+        for _ in range(num_layers):
+            self.convs.append(GraphConvLayer(hidden_channels, hidden_channels, use_weight, use_init))
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+        self.dropout = dropout
+        self.activation = F.relu
+        self.use_bn = use_bn
+        self.use_residual = use_residual
+        self.use_act = use_act
+        self._shard = _NO_SHARD
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+        for fc in self.fcs:
+            fc.reset_parameters()
+
+    def _bn_act_res(self, bn: nn.BatchNorm1d, x, res, relu):
+        """[relu](BatchNorm1d(x)) [+ res] with nn.BatchNorm1d's train/eval + running-stat rules."""
+        shard = self._shard
+        use_batch = self.training or not bn.track_running_stats or bn.running_mean is None
+        if use_batch:
+            mean, var, n_tot = ops.batch_stats(x, shard)
+            if n_tot <= 1 and self.training:
+                raise ValueError("Expected more than 1 value per channel when training")
+            if self.training and bn.track_running_stats and bn.running_mean is not None:
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
+                    unbiased = var * (n_tot / max(n_tot - 1.0, 1.0))
+                    bn.running_var.mul_(1.0 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
+        else:
+            mean, var, n_tot = bn.running_mean.float(), bn.running_var.float(), float(x.shape[0])
+        rstd = torch.rsqrt(var + bn.eps)
+        return ops.bn_act_res(x, res, bn.weight, bn.bias, mean, rstd, relu, use_batch, n_tot, shard)
+
+    def _stage(self, bn, x, res, relu):
+        """BN -> act -> dropout -> + res, fused into one pass whenever dropout is inactive."""
+        drop_on = self.training and self.dropout is not None and self.dropout > 0.0
+        fuse_res = res is not None and not drop_on
+        if self.use_bn:
+            x = self._bn_act_res(bn, x, res if fuse_res else None, relu)
+        else:
+            if relu:
+                x = torch.relu(x)
+            if fuse_res:
+                x = x + res
+        x = _drop(x, self.dropout, self.training)
+        if res is not None and not fuse_res:
+            x = x + res
+        return x
+
+    def forward(self, x, edge_index):
+        ops._require_cuda(x, edge_index)
+        x = self.fcs[0](x)
+        x = self._stage(self.bns[0], x, None, True)
+        x0 = x
+        for i, conv in enumerate(self.convs):
+            x = conv(x, edge_index, x0)
+            x = self._stage(self.bns[i + 1], x, x0 if self.use_residual else None, self.use_act)
+        return x
+
+
+class TransConvLayer(nn.Module):
+    """Q/K/V projections + linear global attention (large/ours.py:96-162)."""
+
+    def __init__(self, in_channels, out_channels, num_heads, use_weight=True):
+        super().__init__()
+        self.Wk = nn.Linear(in_channels, out_channels * num_heads)
+        self.Wq = nn.Linear(in_channels, out_channels * num_heads)
+        if use_weight:
+            self.Wv = nn.Linear(in_channels, out_channels * num_heads)
+        self.out_channels = out_channels
+        self.num_heads = num_heads
+        self.use_weight = use_weight
+        self._shard = _NO_SHARD
+
+    def reset_parameters(self):
+        self.Wk.reset_parameters()
+        self.Wq.reset_parameters()
+        if self.use_weight:
+            self.Wv.reset_parameters()
+
+    def _project(self, query_input, source_input):
+        """[Q | K (| V)] in ONE buffer: a single [d -> 2Hd or 3Hd] GEMM when query is source."""
+        ws = [self.Wq.weight, self.Wk.weight] + ([self.Wv.weight] if self.use_weight else [])
+        bs = [self.Wq.bias, self.Wk.bias] + ([self.Wv.bias] if self.use_weight else [])
+        if query_input is source_input:
+            return F.linear(query_input, torch.cat(ws, 0), torch.cat(bs, 0))
+        q = F.linear(query_input, ws[0], bs[0])
+        kv = F.linear(source_input, torch.cat(ws[1:], 0), torch.cat(bs[1:], 0))
+        return torch.cat([q, kv], 1)
+
+    def forward(self, query_input, source_input, output_attn=False):
+        ops._require_cuda(query_input, source_input)
+        h, d = self.num_heads, self.out_channels
+        qkv = self._project(query_input, source_input)
+        v_ext = None
+        if not self.use_weight:
+            if source_input.shape[1] != d:
+                raise RuntimeError(f"use_weight=False needs in_channels == out_channels ({d})")
+            v_ext = source_input
+        final_output = ops.attention(qkv, v_ext, h, d, self._shard)
+        if output_attn:
+            n = qkv.shape[0]
+            qs = qkv[:, :h * d].reshape(n, h, d)
+            ks = qkv[:, h * d:2 * h * d].reshape(n, h, d)
+            return final_output, _attention_matrix(qs, ks)
+        return final_output
+
+
+class TransConv(nn.Module):
+    """fc -> LN -> relu -> dropout -> Lt x [attn -> mix residual -> LN -> act -> dropout]
+    (large/ours.py:165-219; `bns` are LayerNorms, :174,178).  `alpha` = None is the large
+    variant's (x + res)/2; a float is the 100M / medium variant's alpha*x + (1-alpha)*res."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers=2, num_heads=1, dropout=0.5,
+                 use_bn=True, use_residual=True, use_weight=True, use_act=True, alpha=None):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        self.fcs = nn.ModuleList()
+        self.fcs.append(nn.Linear(in_channels, hidden_channels))
+        self.bns = nn.ModuleList()
+        self.bns.append(nn.LayerNorm(hidden_channels))
+        for _ in range(num_layers):
+            self.convs.append(TransConvLayer(hidden_channels, hidden_channels, num_heads=num_heads,
+                                             use_weight=use_weight))
+            self.bns.append(nn.LayerNorm(hidden_channels))
+        self.dropout = dropout
+        self.activation = F.relu
+        self.use_bn = use_bn
+        self.use_residual = use_residual
+        self.use_act = use_act
+        self.alpha = alpha
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+        for fc in self.fcs:
+            fc.reset_parameters()
+
+    def _mix(self):
+        return (0.5, 0.5) if self.alpha is None else (float(self.alpha), 1.0 - float(self.alpha))
+
+    def _ln(self, ln: nn.LayerNorm, x, res, a, b, relu):
+        if res is None and not self.use_bn and not relu:
+            return x
+        gamma, beta = (ln.weight, ln.bias) if self.use_bn else (None, None)
+        return ops.ln_res_act(x, res, a, b, gamma, beta, relu, ln.eps)
+
+    def _embed(self, x, training):
+        x = self.fcs[0](x)
+        x = self._ln(self.bns[0], x, None, 1.0, 0.0, True)
+        return _drop(x, self.dropout, training)
+
+    def forward(self, x):
+        ops._require_cuda(x)
+        x = self._embed(x, self.training)
+        layer_ = [x]
+        a, b = self._mix()
+        for i, conv in enumerate(self.convs):
+            h = conv(x, x)
+            if self.use_residual:
+                x = self._ln(self.bns[i + 1], h, layer_[i], a, b, self.use_act)
+            else:
+                x = self._ln(self.bns[i + 1], h, None, 1.0, 0.0, self.use_act)
+            x = _drop(x, self.dropout, self.training)
+            layer_.append(x)
+        return x
+
+    def get_attentions(self, x):
+        """[Lt, N, N] attention maps (large/ours.py:221-239): no dropout, and — as there — no
+        activation after the first layer unless use_act."""
+        x = self._embed(x, False)
+        layer_, attentions = [x], []
+        a, b = self._mix()
+        for i, conv in enumerate(self.convs):
+            h, attn = conv(x, x, output_attn=True)
+            attentions.append(attn)
+            res = layer_[i] if self.use_residual else None
+            x = self._ln(self.bns[i + 1], h, res, a if res is not None else 1.0,
+                         b if res is not None else 0.0, self.use_act)
+            layer_.append(x)
+        return torch.stack(attentions, dim=0)
+
+
+class SGFormer(nn.Module):
+    """Two branches -> weighted add / concat -> fc   (large/ours.py:242-286)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels,
+                 trans_num_layers=1, trans_num_heads=1, trans_dropout=0.5, trans_use_bn=True,
+                 trans_use_residual=True, trans_use_weight=True, trans_use_act=True,
+                 gnn_num_layers=1, gnn_dropout=0.5, gnn_use_weight=True, gnn_use_init=False,
+                 gnn_use_bn=True, gnn_use_residual=True, gnn_use_act=True,
+                 use_graph=True, graph_weight=0.8, aggregate='add', alpha=None):
+        super().__init__()
+        self.trans_conv = TransConv(in_channels, hidden_channels, trans_num_layers, trans_num_heads,
+                                    trans_dropout, trans_use_bn, trans_use_residual,
+                                    trans_use_weight, trans_use_act, alpha=alpha)
+        self.graph_conv = GraphConv(in_channels, hidden_channels, gnn_num_layers, gnn_dropout,
+                                    gnn_use_bn, gnn_use_residual, gnn_use_weight, gnn_use_init,
+                                    gnn_use_act)
+        self.use_graph = use_graph
+        self.graph_weight = graph_weight
+        self.aggregate = aggregate
+        if aggregate == 'add':
+            self.fc = nn.Linear(hidden_channels, out_channels)
+        elif aggregate == 'cat':
+            self.fc = nn.Linear(2 * hidden_channels, out_channels)
+        else:
+            raise ValueError(f'Invalid aggregate type:{aggregate}')
+        self.params1 = list(self.trans_conv.parameters())
+        self.params2 = list(self.graph_conv.parameters()) if self.graph_conv is not None else []
+        self.params2.extend(list(self.fc.parameters()))
+
+    def forward(self, x, edge_index):
+        ops._require_cuda(x, edge_index)
+        x1 = self.trans_conv(x)
+        if self.use_graph:
+            x2 = self.graph_conv(x, edge_index)
+            if self.aggregate == 'add':
+                gw = float(self.graph_weight)
+                x = ops.axpby(x2, x1, gw, 1.0 - gw)
+            else:
+                x = torch.cat((x1, x2), dim=1)
+        else:
+            x = x1
+        return self.fc(x)
+
+    def get_attentions(self, x):
+        return self.trans_conv.get_attentions(x)
+
+    def reset_parameters(self):
+        # as in the reference (large/ours.py:283-286): `fc` is never reset
+        self.trans_conv.reset_parameters()
+        if self.use_graph:
+            self.graph_conv.reset_parameters()

@@ -1,0 +1,283 @@
+"""Kernel-level parity: every libsgf entry point against the fp64 oracle (oracle/sgformer_oracle.py).
+
+Integer work (CSR build) is checked bit-exact; floating point against fp64 with the tolerance
+written at each check.  SURVEY.md §0.5: the attention all-pair term is ~1/(N sqrt(d)) of N*V, so
+the attention tests look at the raw partials and at runs with a small `n_total`, where a kernel
+that returned V would fail by orders of magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+# ------------------------------------------------------------------------------------------------
+# T1 CSR build: bit-exact
+# ------------------------------------------------------------------------------------------------
+def _graphs():
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    out["sym_random"] = (O.synthetic_graph(500, 8.0, seed=3), 500)
+    out["directed"] = (O.synthetic_graph(300, 5.0, seed=4, directed=True), 300)
+    # raw multigraph: duplicates, self loops, isolated nodes, sources with zero in-degree
+    src = torch.randint(0, 200, (3000,), generator=g)
+    dst = torch.randint(50, 150, (3000,), generator=g)          # nodes <50 and >=150 have in-degree 0
+    out["multigraph"] = (torch.stack([src, dst]), 230)            # nodes 200..229 isolated
+    out["single_edge"] = (torch.tensor([[1], [0]]), 3)
+    out["empty"] = (torch.zeros((2, 0), dtype=torch.int64), 5)
+    out["cora_shaped"] = (O.synthetic_graph(2708, 3.9, seed=5), 2708)
+    return out
+
+
+@pytest.mark.parametrize("name", list(_graphs().keys()))
+def test_csr_build_bit_exact(cuda, name):
+    from sgformer_amd import ops
+    ei, n = _graphs()[name]
+    rowptr, colind, val, deg = O.csr_build(ei.numpy(), n)
+    g = ops.CSRGraph(ei.to(cuda), n)
+    assert np.array_equal(g.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(g.colind.cpu().numpy().astype(np.int64), colind)
+    assert np.array_equal(g.deg.cpu().numpy().astype(np.int64), deg)
+    # fp32 values: bit pattern equality (IEEE div, sqrt, mul; non-finite -> 0)
+    assert np.array_equal(g.val.cpu().numpy().view(np.uint32), val.view(np.uint32))
+    t_rowptr, t_colind, t_val, sym = O.csr_transpose(ei.numpy(), n)
+    rp, ci, va = g.transposed()
+    assert g.symmetric == sym
+    assert np.array_equal(rp.cpu().numpy(), t_rowptr)
+    assert np.array_equal(ci.cpu().numpy().astype(np.int64), t_colind)
+    assert np.array_equal(va.cpu().numpy().view(np.uint32), t_val.view(np.uint32))
+
+
+def test_csr_rejects_bad_ids(cuda):
+    from sgformer_amd import ops
+    with pytest.raises(IndexError):
+        ops.CSRGraph(torch.tensor([[0, 5], [1, 2]], device=cuda), 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# T2 SpMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [4, 32, 64, 100, 128, 256, 512])
+@pytest.mark.parametrize("gname", ["sym_random", "multigraph"])
+def test_spmm_fp32(cuda, d, gname):
+    from sgformer_amd import ops
+    ei, n = _graphs()[gname]
+    torch.manual_seed(d)
+    x = torch.randn(n, d)
+    rowptr, colind, val, _ = O.csr_build(ei.numpy(), n)
+    ref = O.spmm(rowptr, colind, val, x.double())
+    g = ops.CSRGraph(ei.to(cuda), n)
+    y = ops.spmm(g, x.to(cuda))
+    assert _rel(y, ref) <= 1e-6      # fp32 accumulate vs fp64: ~1e-7 observed
+    # backward = A^T dY
+    xg = x.to(cuda).requires_grad_(True)
+    w = torch.randn(n, d)
+    (ops.spmm(g, xg) * w.to(cuda)).sum().backward()
+    t_rowptr, t_colind, t_val, _ = O.csr_transpose(ei.numpy(), n)
+    gref = O.spmm(t_rowptr, t_colind, t_val, w.double())
+    assert _rel(xg.grad, gref) <= 1e-6
+
+
+def test_spmm_bf16(cuda):
+    from sgformer_amd import ops
+    ei, n = _graphs()["sym_random"]
+    x = torch.randn(n, 256).bfloat16()
+    rowptr, colind, val, _ = O.csr_build(ei.numpy(), n)
+    ref = O.spmm(rowptr, colind, val, x.double())
+    y = ops.spmm(ops.CSRGraph(ei.to(cuda), n), x.to(cuda))
+    assert y.dtype == torch.bfloat16
+    assert _rel(y.float(), ref) <= 4e-3  # one bf16 rounding of the fp32 accumulator (2^-9)
+
+
+def test_spmm_empty_rows_and_n0(cuda):
+    from sgformer_amd import ops
+    ei, n = _graphs()["empty"]
+    y = ops.spmm(ops.CSRGraph(ei.to(cuda), n), torch.randn(n, 64, device=cuda))
+    assert torch.count_nonzero(y) == 0
+    g0 = ops.CSRGraph(torch.zeros((2, 0), dtype=torch.int64, device=cuda), 0)
+    assert ops.spmm(g0, torch.zeros(0, 64, device=cuda)).shape == (0, 64)
+
+
+# ------------------------------------------------------------------------------------------------
+# T3 attention
+# ------------------------------------------------------------------------------------------------
+ATTN_CASES = [  # (N, H, d, shared_v)
+    (50, 1, 64, False), (777, 1, 64, False), (2708, 1, 64, False), (1000, 1, 128, False),
+    (3000, 1, 256, False), (4099, 1, 256, False), (333, 2, 64, False), (333, 2, 64, True),
+    (515, 1, 100, False), (129, 3, 32, True), (20000, 1, 256, False),
+]
+
+
+def _qkv(n, h, d, shared_v, seed=0):
+    g = torch.Generator().manual_seed(seed + n + 7 * d)
+    q = torch.randn(n, h, d, generator=g) * 0.7 + 0.1
+    k = torch.randn(n, h, d, generator=g) * 1.3 - 0.2
+    v = torch.randn(n, 1 if shared_v else h, d, generator=g)
+    return q, k, v
+
+
+@pytest.mark.parametrize("n,h,d,shared_v", ATTN_CASES)
+def test_attention_raw_stats(cuda, n, h, d, shared_v):
+    from sgformer_amd import ops
+    q, k, v = _qkv(n, h, d, shared_v)
+    ref = O.attention_raw_stats(q.double(), k.double(), v.double())
+    got = ops.attention_stats(q.to(cuda), k.to(cuda), v.to(cuda))
+    nm = h * d * d
+    assert _rel(got[:nm], ref[:nm]) <= 2e-6          # S0 = K^T V   (fp32 MFMA chain, two-stage sum)
+    assert _rel(got[nm:nm + h * d], ref[nm:nm + h * d]) <= 2e-6   # z0
+    assert abs(float(got[-2]) / float(ref[-2]) - 1) <= 2e-6       # ||Q||^2
+    assert abs(float(got[-1]) / float(ref[-1]) - 1) <= 2e-6       # ||K||^2
+
+
+def _run_attention(cuda, q, k, v, n_total, need_grad=True):
+    from sgformer_amd import ops
+    n, h, d = q.shape
+    shared_v = v.shape[1] == 1 and h > 1 or (v.shape[1] == 1 and h == 1 and False)
+    qk = torch.cat([q.reshape(n, -1), k.reshape(n, -1)], 1)
+    if v.shape[1] == h:
+        qkv = torch.cat([qk, v.reshape(n, -1)], 1).to(cuda).requires_grad_(need_grad)
+        vx = None
+    else:
+        qkv = qk.to(cuda).requires_grad_(need_grad)
+        vx = v.reshape(n, d).to(cuda).requires_grad_(need_grad)
+    out = ops.attention(qkv, vx, h, d, None, n_total)
+    return out, qkv, vx
+
+
+@pytest.mark.parametrize("n,h,d,shared_v", ATTN_CASES)
+@pytest.mark.parametrize("small_n", [False, True])
+def test_attention_forward_backward(cuda, n, h, d, shared_v, small_n):
+    q, k, v = _qkv(n, h, d, shared_v, seed=1)
+    n_total = 0.05 if small_n else None      # small n_total: the Q (K^T V) term dominates N*V
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = O.attention(qd, kd, vd, n_total=n_total)
+    w = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).double()
+    (ref * w).sum().backward()
+
+    out, qkv, vx = _run_attention(cuda, q, k, v, n_total)
+    # forward: fp32 vs fp64.  abs tolerance scaled by max|out| (1e-5 relative to the output scale)
+    scale = float(ref.abs().max())
+    assert float((out.double().cpu() - ref.detach()).abs().max()) <= 1e-5 * scale
+    if small_n:
+        assert _rel(out, ref.detach()) <= 1e-5
+    (out * w.float().to(cuda)).sum().backward()
+    hd = h * d
+    gq, gk = qkv.grad[:, :hd].reshape(n, h, d), qkv.grad[:, hd:2 * hd].reshape(n, h, d)
+    gv = qkv.grad[:, 2 * hd:].reshape(n, h, d) if vx is None else vx.grad.reshape(n, 1, d)
+    # gradients: relative (Frobenius) error per tensor; dQ / dK are ~1/N of dV in magnitude
+    # (SURVEY.md App. B), so a relative check is the only meaningful one.
+    tol = 2e-4 if not small_n else 5e-5
+    assert _rel(gv, vd.grad) <= 1e-5
+    assert _rel(gq, qd.grad) <= tol
+    assert _rel(gk, kd.grad) <= tol
+
+
+def test_attention_bf16(cuda):
+    n, h, d = 3000, 1, 256
+    q, k, v = _qkv(n, h, d, False, seed=2)
+    qb, kb, vb = (t.bfloat16() for t in (q, k, v))
+    ref = O.attention(qb.double(), kb.double(), vb.double(), n_total=0.05)
+    out, _, _ = _run_attention(cuda, qb, kb, vb, 0.05, need_grad=False)
+    assert out.dtype == torch.bfloat16
+    assert _rel(out.float(), ref) <= 8e-3      # bf16 output rounding (2^-8) on fp32 arithmetic
+
+
+def test_attention_n0(cuda):
+    from sgformer_amd import ops
+    out = ops.attention(torch.zeros(0, 3 * 64, device=cuda), None, 1, 64)
+    assert out.shape == (0, 64)
+
+
+# ------------------------------------------------------------------------------------------------
+# T5 / T6 / T7 fused glue
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [64, 100, 256, 512])
+@pytest.mark.parametrize("relu,use_ln,use_res", [(True, True, True), (False, True, True),
+                                                  (True, True, False), (True, False, True)])
+def test_ln_res_act(cuda, d, relu, use_ln, use_res):
+    from sgformer_amd import ops
+    torch.manual_seed(d)
+    n = 777
+    x, r = torch.randn(n, d) * 2 + 0.3, torch.randn(n, d)
+    gamma, beta = 1 + 0.1 * torch.randn(d), 0.1 * torch.randn(d)
+    a, b = 0.3, 0.7
+    w = torch.randn(n, d)
+
+    def ref_fn(x, r, gamma, beta):
+        pre = a * x + (b * r if use_res else 0)
+        if use_ln:
+            pre = torch.nn.functional.layer_norm(pre, (d,), gamma, beta, 1e-5)
+        return torch.relu(pre) if relu else pre
+
+    xs = [t.double().requires_grad_(True) for t in (x, r, gamma, beta)]
+    (ref_fn(*xs) * w.double()).sum().backward()
+    gs = [t.to(cuda).requires_grad_(True) for t in (x, r, gamma, beta)]
+    y = ops.ln_res_act(gs[0], gs[1] if use_res else None, a, b, gs[2] if use_ln else None,
+                       gs[3] if use_ln else None, relu, 1e-5)
+    assert float((y.double().cpu() - ref_fn(*[t.detach() for t in xs])).abs().max()) <= 2e-5
+    (y * w.to(cuda)).sum().backward()
+    assert _rel(gs[0].grad, xs[0].grad) <= 1e-5
+    if use_res:
+        assert _rel(gs[1].grad, xs[1].grad) <= 1e-5
+    if use_ln:
+        assert _rel(gs[2].grad, xs[2].grad) <= 1e-5
+        assert _rel(gs[3].grad, xs[3].grad) <= 1e-5
+
+
+@pytest.mark.parametrize("d", [64, 100, 256])
+@pytest.mark.parametrize("relu,use_res,training", [(True, True, True), (False, False, True),
+                                                   (True, True, False)])
+def test_bn_act_res(cuda, d, relu, use_res, training):
+    from sgformer_amd import ops
+    torch.manual_seed(d + 1)
+    n = 1531
+    x, r = torch.randn(n, d) * 1.7 + 5.0, torch.randn(n, d)     # large mean: two-pass variance
+    gamma, beta = 1 + 0.1 * torch.randn(d), 0.1 * torch.randn(d)
+    rm, rv = 5 + 0.1 * torch.randn(d), 2.5 + 0.2 * torch.rand(d)
+    w = torch.randn(n, d)
+
+    def ref_fn(x, r, gamma, beta):
+        y = torch.nn.functional.batch_norm(x, rm.double(), rv.double(), gamma, beta, training, 0.0, 1e-5)
+        if relu:
+            y = torch.relu(y)
+        return y + r if use_res else y
+
+    xs = [t.double().requires_grad_(True) for t in (x, r, gamma, beta)]
+    (ref_fn(*xs) * w.double()).sum().backward()
+    gs = [t.to(cuda).requires_grad_(True) for t in (x, r, gamma, beta)]
+    if training:
+        mean, var, n_tot = ops.batch_stats(gs[0].detach())
+        assert _rel(mean, x.double().mean(0)) <= 1e-6
+        assert _rel(var, x.double().var(0, unbiased=False)) <= 1e-5
+    else:
+        mean, var, n_tot = rm.to(cuda), rv.to(cuda), float(n)
+    rstd = torch.rsqrt(var + 1e-5)
+    y = ops.bn_act_res(gs[0], gs[1] if use_res else None, gs[2], gs[3], mean, rstd, relu, training, n_tot)
+    assert float((y.double().cpu() - ref_fn(*[t.detach() for t in xs])).abs().max()) <= 2e-5
+    (y * w.to(cuda)).sum().backward()
+    assert _rel(gs[0].grad, xs[0].grad) <= 2e-5
+    assert _rel(gs[2].grad, xs[2].grad) <= 1e-5
+    assert _rel(gs[3].grad, xs[3].grad) <= 1e-5
+    if use_res:
+        assert _rel(gs[1].grad, xs[1].grad) <= 1e-6
+
+
+def test_axpby(cuda):
+    from sgformer_amd import ops
+    a, b = torch.randn(1000, 256, device=cuda), torch.randn(1000, 256, device=cuda)
+    y = ops.axpby(a, b, 0.8, 0.2)
+    assert torch.allclose(y, 0.8 * a + 0.2 * b, atol=1e-6)
+
+
+def test_cpu_tensor_is_rejected():
+    from sgformer_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.attention(torch.zeros(4, 192), None, 1, 64)

@@ -1,0 +1,163 @@
+"""End-to-end parity of the drop-in module (sgformer_amd/ours.py) against the oracle restatement of
+large/ours.py: logits, loss, every parameter gradient, BatchNorm running statistics, a short
+training trajectory, and state_dict interchange.  Tolerance: 1e-4 absolute on fp32 logits
+(BASELINE.json north_star), relative on gradients.
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import sgformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # large/run.sh:2-5 (ogbn-arxiv recipe; dropout off for parity)
+    "arxiv": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                  trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
+                  gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=False, gnn_use_act=True,
+                  graph_weight=0.5, aggregate="add"),
+    # large/run.sh:15-19 (amazon2m / products recipe): use_init
+    "products": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                     trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
+                     gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
+                     graph_weight=0.5, aggregate="add"),
+    "heads_cat": dict(trans_num_layers=2, trans_num_heads=2, trans_use_act=True, gnn_num_layers=1,
+                      aggregate="cat"),
+    "bare": dict(trans_use_weight=False, trans_use_bn=False, trans_use_residual=False,
+                 trans_use_act=False, gnn_use_weight=False, gnn_use_bn=False, gnn_use_residual=False,
+                 gnn_use_act=False, gnn_num_layers=2),
+    "no_graph": dict(use_graph=False, trans_num_layers=2),
+    "alpha_100m": dict(alpha=0.3, trans_num_layers=1, gnn_num_layers=2, gnn_use_init=True),
+}
+
+
+def _build(cfg, f, d, c, cuda, seed=0):
+    from sgformer_amd.ours import SGFormer
+    p = O.init_params(cfg, f, d, c, seed=seed)
+    m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+    sd = m.state_dict()
+    for k, v in p.items():
+        assert sd[k].shape == v.shape, k
+    missing = [k for k in sd if k not in p and "num_batches_tracked" not in k]
+    assert not missing, missing
+    m.load_state_dict({**sd, **p})
+    return m.to(cuda), p
+
+
+@pytest.mark.parametrize("name", list(CONFIGS.keys()))
+@pytest.mark.parametrize("shape", [(700, 24, 64, 7), (1500, 36, 128, 5), (2100, 40, 256, 10)])
+def test_forward_backward_parity(cuda, name, shape):
+    cfg = CONFIGS[name]
+    n, f, d, c = shape
+    torch.manual_seed(n)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 7.0, seed=n)
+    y = torch.randint(0, c, (n,))
+    idx = torch.randperm(n)[: n // 2]
+    m, p = _build(cfg, f, d, c, cuda)
+
+    # oracle in fp64 (training mode: batch statistics)
+    p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    stats = {}
+    logits_ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True, bn_stats=stats)
+    loss_ref = O.nll_loss(logits_ref, y, idx)
+    loss_ref.backward()
+
+    m.train()
+    logits = m(x.to(cuda), ei.to(cuda))
+    loss = O.nll_loss(logits, y.to(cuda), idx.to(cuda))
+    loss.backward()
+    assert float((logits.double().cpu() - logits_ref.detach()).abs().max()) <= 1e-4
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5
+    for k, prm in m.named_parameters():
+        g_ref = p64[k].grad
+        if g_ref is None:              # unused W of GraphConvLayer (large/ours.py:20 vs :36-40)
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+            continue
+        num = float((prm.grad.double().cpu() - g_ref).norm())
+        den = float(g_ref.norm())
+        assert num <= 2e-4 * den + 1e-9, (k, num, den)
+    # BatchNorm running statistics after one step (momentum 0.1 from the init_params values)
+    if cfg.get("gnn_use_bn", True) and cfg.get("use_graph", True):
+        for key, (mu, var_unb) in stats.items():
+            rm = 0.9 * p[key + ".running_mean"].double() + 0.1 * mu
+            rv = 0.9 * p[key + ".running_var"].double() + 0.1 * var_unb
+            sd = m.state_dict()
+            assert float((sd[key + ".running_mean"].double().cpu() - rm).abs().max()) <= 1e-5
+            assert float((sd[key + ".running_var"].double().cpu() - rv).abs().max()) <= 1e-5
+
+    # eval mode: running statistics, no dropout
+    m.eval()
+    with torch.no_grad():
+        logits_e = m(x.to(cuda), ei.to(cuda))
+    pe = {k: v.double().cpu() for k, v in m.state_dict().items()}
+    ref_e = O.sgformer_forward(pe, x.double(), ei, cfg, training=False)
+    assert float((logits_e.double().cpu() - ref_e).abs().max()) <= 1e-4
+
+
+def test_training_trajectory(cuda):
+    """5 Adam steps with the reference's two parameter groups (large/main.py:114-119): the loss
+    curve of the GPU module tracks the fp32 CPU oracle."""
+    cfg = CONFIGS["arxiv"]
+    n, f, d, c = 1200, 32, 64, 6
+    torch.manual_seed(1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 6.0, seed=9)
+    y = torch.randint(0, c, (n,))
+    idx = torch.arange(0, n, 2)
+    m, p = _build(cfg, f, d, c, cuda)
+    pc = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    opt_g = torch.optim.Adam([{"params": m.params1, "weight_decay": 1e-3},
+                              {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
+    names1 = [k for k, _ in m.trans_conv.named_parameters(prefix="trans_conv")]
+    names2 = [k for k, _ in m.graph_conv.named_parameters(prefix="graph_conv")] + ["fc.weight", "fc.bias"]
+    opt_c = torch.optim.Adam([{"params": [pc[k] for k in names1], "weight_decay": 1e-3},
+                              {"params": [pc[k] for k in names2], "weight_decay": 5e-4}], lr=0.01)
+    m.train()
+    for step in range(5):
+        opt_g.zero_grad()
+        lg = O.nll_loss(m(x.to(cuda), ei.to(cuda)), y.to(cuda), idx.to(cuda))
+        lg.backward()
+        opt_g.step()
+        opt_c.zero_grad()
+        stats = {}
+        lc = O.nll_loss(O.sgformer_forward(pc, x, ei, cfg, training=True, bn_stats=stats), y, idx)
+        lc.backward()
+        opt_c.step()
+        with torch.no_grad():
+            for key, (mu, vu) in stats.items():
+                pc[key + ".running_mean"].mul_(0.9).add_(0.1 * mu)
+                pc[key + ".running_var"].mul_(0.9).add_(0.1 * vu)
+        assert abs(float(lg) - float(lc)) <= 2e-4 * max(1.0, abs(float(lc))), (step, float(lg), float(lc))
+
+
+def test_surface_matches_reference_contract(cuda):
+    """ctor keywords, state_dict keys / shapes, params1 / params2, reset_parameters."""
+    from sgformer_amd.ours import SGFormer
+    kw = dict(trans_num_layers=1, trans_num_heads=1, trans_dropout=0.5, trans_use_bn=True,
+              trans_use_residual=True, trans_use_weight=True, trans_use_act=False, gnn_num_layers=3,
+              gnn_dropout=0.5, gnn_use_weight=True, gnn_use_init=True, gnn_use_bn=True,
+              gnn_use_residual=True, gnn_use_act=True, use_graph=True, graph_weight=0.5, aggregate="add")
+    m = SGFormer(128, 256, 40, **kw)
+    sd = m.state_dict()
+    assert len(sd) == 42
+    assert sum(p.numel() for p in m.parameters()) == 670760
+    assert len(m.params1) == 12 and len(m.params2) == 18
+    assert sd["graph_conv.convs.0.W.weight"].shape == (256, 512)
+    assert sd["trans_conv.convs.0.Wq.weight"].shape == (256, 256)
+    before = copy.deepcopy(sd)
+    m.reset_parameters()
+    after = m.state_dict()
+    assert torch.equal(before["fc.weight"], after["fc.weight"])          # fc is never reset
+    assert not torch.equal(before["trans_conv.fcs.0.weight"], after["trans_conv.fcs.0.weight"])
+    m = m.to(cuda)
+    x = torch.randn(300, 128, device=cuda)
+    ei = O.synthetic_graph(300, 5.0, seed=2).to(cuda)
+    m.train()
+    out = m(x, ei)                                                          # dropout 0.5 active
+    assert out.shape == (300, 40) and torch.isfinite(out).all()
+    out.sum().backward()
+    att = m.get_attentions(x)
+    assert att.shape == (1, 300, 300)

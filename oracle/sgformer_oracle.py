@@ -86,8 +86,20 @@ def spmm(rowptr: np.ndarray, colind: np.ndarray, val: np.ndarray, x: Tensor) -> 
     return a @ x
 
 
-def gcn_propagate(x: Tensor, edge_index: Tensor) -> Tensor:
-    """large/ours.py:26-34 end to end, differentiable (index_add form, any dtype)."""
+def build_adj(edge_index: Tensor, n: int, dtype=torch.float32):
+    """The normalised adjacency of :26-33 as a torch sparse-CSR tensor (MKL SpMM on CPU).  Used by
+    the timed CPU baseline so that it is not a straw man; built once per graph,
+    which is kinder to the CPU than the reference, which re-sorts the edges in every layer."""
+    rowptr, colind, val, _ = csr_build(edge_index.cpu().numpy(), n)
+    return torch.sparse_csr_tensor(torch.from_numpy(rowptr), torch.from_numpy(colind),
+                                   torch.from_numpy(val).to(dtype), size=(n, n))
+
+
+def gcn_propagate(x: Tensor, edge_index, adj=None) -> Tensor:
+    """large/ours.py:26-34 end to end, differentiable (index_add form, any dtype); with a prebuilt
+    `adj` (build_adj) the product is one sparse-CSR matmul instead."""
+    if adj is not None:
+        return torch.sparse.mm(adj, x)
     n = x.shape[0]
     row, col = edge_index[0], edge_index[1]
     d = torch.zeros(n, dtype=torch.float32).index_add_(0, col, torch.ones(col.numel(), dtype=torch.float32))
@@ -200,7 +212,7 @@ def trans_conv(p: Dict[str, Tensor], x: Tensor, cfg: dict, parts: Optional[dict]
 
 
 def graph_conv(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict, training: bool,
-               bn_stats: Optional[dict] = None) -> Tensor:
+               bn_stats: Optional[dict] = None, adj=None) -> Tensor:
     """GraphConv.forward with dropout inactive (large/ours.py:74-94)."""
     pre = "graph_conv."
     x = _linear(p, pre + "fcs.0", x)                               # :77
@@ -209,7 +221,7 @@ def graph_conv(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict, t
     x = torch.relu(x)                                              # :80
     x0 = x                                                         # layer_[0], never extended (:83)
     for i in range(cfg["gnn_num_layers"]):
-        y = gcn_propagate(x, edge_index)                           # GraphConvLayer :26-34
+        y = gcn_propagate(x, edge_index, adj)                      # GraphConvLayer :26-34
         if cfg["gnn_use_init"]:
             y = _linear(p, f"{pre}convs.{i}.W", torch.cat([y, x0], 1))   # :36-38
         elif cfg["gnn_use_weight"]:
@@ -226,13 +238,13 @@ def graph_conv(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict, t
 
 def sgformer_forward(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict,
                      training: bool = True, parts: Optional[dict] = None,
-                     bn_stats: Optional[dict] = None) -> Tensor:
+                     bn_stats: Optional[dict] = None, adj=None) -> Tensor:
     """SGFormer.forward (large/ours.py:265-276) with dropout p = 0."""
     c = dict(DEFAULT_CFG)
     c.update(cfg)
     x1 = trans_conv(p, x, c, parts)
     if c["use_graph"]:
-        x2 = graph_conv(p, x, edge_index, c, training, bn_stats)
+        x2 = graph_conv(p, x, edge_index, c, training, bn_stats, adj)
         if c["aggregate"] == "add":
             gw = c["graph_weight"]
             xx = gw * x2 + (1 - gw) * x1                           # :270
@@ -254,22 +266,10 @@ def nll_loss(logits: Tensor, y: Tensor, idx: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # synthetic inputs shared by tests, smoke() and bench.py
 # ------------------------------------------------------------------------------------------------
-def synthetic_graph(n: int, avg_deg: float, seed: int = 123, directed: bool = False,
-                    device: str = "cpu") -> Tensor:
-    """Uniform random graph + the trainer prologue of large/main.py:75-79: symmetrise + coalesce,
-    drop self-loops, append one self-loop per node.  Returns int64 [2, nnz]."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    m = int(n * avg_deg / 2)
-    src = torch.randint(0, n, (m,), generator=g)
-    dst = torch.randint(0, n, (m,), generator=g)
-    src, dst = src.to(device), dst.to(device)
-    if not directed:
-        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
-    keep = src != dst
-    key = torch.unique(src[keep] * n + dst[keep])          # coalesce: sorted, duplicates dropped
-    src, dst = key // n, key % n
-    loops = torch.arange(n, device=device)
-    return torch.stack([torch.cat([src, loops]), torch.cat([dst, loops])])
+def synthetic_graph(n, avg_deg, seed=123, directed=False, device="cpu"):
+    """The product-side generator (sgformer_amd/synth.py), re-exported for the tests."""
+    from sgformer_amd.synth import synthetic_graph as _g
+    return _g(n, avg_deg, seed=seed, directed=directed, device=device)
 
 
 def init_params(cfg: dict, f: int, d: int, c: int, seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:

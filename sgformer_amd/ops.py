@@ -1,9 +1,15 @@
 """Autograd-level operators over the libsgf C ABI (include/sgf.h).
 
 Each operator is the reference arithmetic of one row of SURVEY.md §8a, forward and backward, as a
-`torch.autograd.Function` whose forward/backward call the HIP kernels on the current stream.
-PyTorch is used for memory, streams and autograd bookkeeping only; there is no eager fallback — a
-CPU tensor or a missing library raises.
+`torch.autograd.Function`.  The Functions own the autograd bookkeeping, the multi-GPU exchange
+points and nothing else; every tensor-to-tensor computation goes through the kernel table `K`
+(class `HipKernels`), whose methods are thin ctypes calls into libsgf.so on the current stream.
+PyTorch is used for memory, streams and autograd only; there is no eager fallback — a CPU tensor
+or a missing library raises.
+
+(The kernel table is a seam for tests: tests/ may install a CPU table built on oracle/ with
+`set_kernels()` to exercise this file, ours.py and dist.py under gloo without a GPU.  No such
+table ships in the package.)
 
 Node-sharded multi-GPU runs (sgformer_amd/dist.py) pass a `ShardContext`; the operators then
 all-reduce exactly the partial-sum buffers the kernels were designed around (attention stats,
@@ -42,20 +48,17 @@ def _code(t: torch.Tensor) -> int:
     raise TypeError(f"sgformer_amd kernels take float32 or bfloat16 storage, got {t.dtype}")
 
 
-def _require_cuda(*tensors):
-    for t in tensors:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError(
-                "sgformer_amd runs on MI355X only: got a CPU tensor.  There is no CPU fallback; "
-                "move the model and its inputs to the GPU (the reference's CPU evaluation path, "
-                "large/eval.py:36-65, is outside this library's scope).")
+def _ld(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.stride(0)
 
 
-def _rows(t: torch.Tensor) -> torch.Tensor:
-    """Return a view/copy of a 2-D tensor whose rows are contiguous and 4-element aligned."""
+def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A view/copy of a 2-D tensor whose rows are contiguous and 4-element aligned."""
+    if t is None:
+        return None
     if t.stride(-1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % (4 * t.element_size()) != 0:
         t = t.contiguous()
-        if t.stride(0) % 4 != 0:
+        if t.shape[0] > 1 and t.stride(0) % 4 != 0:
             raise ValueError(f"feature dimension {t.shape[-1]} must be a multiple of 4")
     return t
 
@@ -64,13 +67,223 @@ _workspaces: "dict[tuple, torch.Tensor]" = {}
 
 
 def _workspace(device, name: str, nbytes: int) -> torch.Tensor:
-    """Per-device scratch reused across calls (all users run on the current stream, in order)."""
+    """Per-device, per-stream scratch reused across calls (users run on that stream, in order)."""
     key = (device.index, name, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+# ------------------------------------------------------------------------------------------------
+# the kernel table: one method per C-ABI entry point, tensors in / tensors out
+# ------------------------------------------------------------------------------------------------
+class HipKernels:
+    """libsgf.so on the current HIP stream.  Inputs must be GPU tensors."""
+
+    name = "hip"
+
+    @staticmethod
+    def check(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError(
+                    "sgformer_amd runs on MI355X only: got a CPU tensor.  There is no CPU fallback; "
+                    "move the model and its inputs to the GPU (the reference's CPU evaluation path, "
+                    "large/eval.py:36-65, is outside this library's scope).")
+
+    # ---- T1 ----
+    @staticmethod
+    def csr_build(ei: torch.Tensor, n: int):
+        dev, nnz = ei.device, int(ei.shape[1])
+        rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+        val = torch.empty(nnz, dtype=_F32, device=dev)
+        deg = torch.empty(n, dtype=torch.int32, device=dev)
+        nbytes = _lib.load().sgf_csr_workspace_bytes(nnz, n)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_csr_build", _ptr(ei), nnz, n, _ptr(rowptr), _ptr(colind), _ptr(val),
+                      _ptr(deg), _ptr(ws), ws.numel(), _stream(dev))
+        return rowptr, colind, val, deg
+
+    @staticmethod
+    def csr_transpose(ei: torch.Tensor, n: int, deg, rowptr, colind):
+        dev, nnz = ei.device, int(ei.shape[1])
+        t_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        t_colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+        t_val = torch.empty(nnz, dtype=_F32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        nbytes = _lib.load().sgf_csr_workspace_bytes(nnz, n)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_csr_transpose", _ptr(ei), nnz, n, _ptr(deg), _ptr(rowptr), _ptr(colind),
+                      _ptr(t_rowptr), _ptr(t_colind), _ptr(t_val), _ptr(flag), _ptr(ws), ws.numel(),
+                      _stream(dev))
+        return t_rowptr, t_colind, t_val, bool(int(flag.item()))  # one host sync, once per graph
+
+    # ---- T2 ----
+    @staticmethod
+    def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int) -> torch.Tensor:
+        x = _rows(x)
+        d = x.shape[1]
+        y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device)
+        if n_rows == 0 or d == 0:
+            return y
+        with torch.cuda.device(x.device):
+            _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
+                      _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
+        return y
+
+    # ---- T3 ----  q, k: [n, H*d] views (ld = stride(0)); v: [n, Hv*d]
+    @staticmethod
+    def attn_fwd_reduce(q, k, v, heads: int, v_heads: int, d: int) -> torch.Tensor:
+        n, dev = q.shape[0], q.device
+        lib = _lib.load()
+        stats = torch.empty(lib.sgf_attn_stats_len(heads, d), dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_fwd_reduce", _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), n,
+                      heads, v_heads, d, _code(q), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
+        return stats
+
+    @staticmethod
+    def attn_fwd_apply(q, v, stats, n_total: float, heads: int, v_heads: int, d: int):
+        n, dev = q.shape[0], q.device
+        out = torch.empty((n, d), dtype=q.dtype, device=dev)
+        den = torch.empty((n, heads), dtype=_F32, device=dev)
+        o_heads = torch.empty((n, heads * d), dtype=q.dtype, device=dev) if heads > 1 else None
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_fwd_apply", _ptr(q), _ld(q), _ptr(v), _ld(v), n, float(n_total),
+                      heads, v_heads, d, _code(q), _ptr(stats), _ptr(out), out.stride(0), _ptr(den),
+                      _ptr(o_heads), _stream(dev))
+        return out, den, o_heads
+
+    @staticmethod
+    def attn_bwd_reduce(q, g, o, den, heads: int, d: int) -> torch.Tensor:
+        n, dev = q.shape[0], q.device
+        lib = _lib.load()
+        bstats = torch.empty(lib.sgf_attn_bstats_len(heads, d), dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_bwd_reduce", _ptr(q), _ld(q), _ptr(g), _ld(g), _ptr(o), _ld(o),
+                      _ptr(den), n, heads, d, _code(q), _ptr(bstats), _ptr(ws), ws.numel(),
+                      _stream(dev))
+        return bstats
+
+    @staticmethod
+    def attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total: float, heads: int, v_heads: int,
+                       d: int, dq, dk, dv):
+        """Writes dq, dk, dv (views with row stride = stride(0)) in place."""
+        n, dev = q.shape[0], q.device
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_bwd_apply", _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(g),
+                      _ld(g), _ptr(o), _ld(o), _ptr(den), n, float(n_total), heads, v_heads, d,
+                      _code(q), _ptr(stats), _ptr(bstats), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk),
+                      _ptr(dv), _ld(dv), _stream(dev))
+
+    # ---- T5 ----
+    @staticmethod
+    def ln_fwd(x, res, a: float, b: float, gamma, beta, relu: bool, eps: float):
+        n, d = x.shape
+        dev = x.device
+        y = torch.empty((n, d), dtype=x.dtype, device=dev)
+        mean = torch.empty(n, dtype=_F32, device=dev) if gamma is not None else None
+        rstd = torch.empty(n, dtype=_F32, device=dev) if gamma is not None else None
+        with torch.cuda.device(dev):
+            _lib.call("sgf_ln_fwd", _ptr(x), _ld(x), _ptr(res), _ld(res), float(a), float(b),
+                      _ptr(gamma), _ptr(beta), int(relu), float(eps), n, d, _code(x), _ptr(y),
+                      y.stride(0), _ptr(mean), _ptr(rstd), _stream(dev))
+        return y, mean, rstd
+
+    @staticmethod
+    def ln_bwd(gy, y, x, res, a: float, b: float, gamma, relu: bool, mean, rstd):
+        n, d = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(res) if res is not None else None
+        dgamma = torch.empty(d, dtype=_F32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(d, dtype=_F32, device=dev) if gamma is not None else None
+        ws = _workspace(dev, "ln", _lib.load().sgf_ln_bwd_workspace_bytes(n, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_ln_bwd", _ptr(gy), _ld(gy), _ptr(y), _ld(y), _ptr(x), _ld(x), _ptr(res),
+                      _ld(res), float(a), float(b), _ptr(gamma), int(relu), _ptr(mean), _ptr(rstd), n,
+                      d, _code(x), _ptr(dx), _ld(dx), _ptr(dres), _ld(dres), _ptr(dgamma), _ptr(dbeta),
+                      _ptr(ws), ws.numel(), _stream(dev))
+        return dx, dres, dgamma, dbeta
+
+    # ---- T6 ----
+    @staticmethod
+    def colstats(x, shift) -> torch.Tensor:
+        n, d = x.shape
+        dev = x.device
+        stats = torch.empty(2 * d, dtype=_F32, device=dev)
+        ws = _workspace(dev, "col", _lib.load().sgf_colstats_workspace_bytes(n, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_colstats", _ptr(x), _ld(x), _ptr(shift), n, d, _code(x), _ptr(stats),
+                      _ptr(ws), ws.numel(), _stream(dev))
+        return stats
+
+    @staticmethod
+    def bn_apply(x, mean, rstd, gamma, beta, res, relu: bool) -> torch.Tensor:
+        n, d = x.shape
+        dev = x.device
+        y = torch.empty((n, d), dtype=x.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_bn_apply", _ptr(x), _ld(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                      _ptr(res), _ld(res), int(relu), n, d, _code(x), _ptr(y), y.stride(0),
+                      _stream(dev))
+        return y
+
+    @staticmethod
+    def bn_bwd_stats(gy, x, mean, rstd, gamma, beta, relu: bool) -> torch.Tensor:
+        n, d = x.shape
+        dev = x.device
+        stats = torch.empty(2 * d, dtype=_F32, device=dev)
+        ws = _workspace(dev, "col", _lib.load().sgf_colstats_workspace_bytes(n, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_bn_bwd_stats", _ptr(gy), _ld(gy), _ptr(x), _ld(x), _ptr(mean), _ptr(rstd),
+                      _ptr(gamma), _ptr(beta), int(relu), n, d, _code(x), _ptr(stats), _ptr(ws),
+                      ws.numel(), _stream(dev))
+        return stats
+
+    @staticmethod
+    def bn_bwd_apply(gy, x, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float,
+                     training: bool) -> torch.Tensor:
+        n, d = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_bn_bwd_apply", _ptr(gy), _ld(gy), _ptr(x), _ld(x), _ptr(mean), _ptr(rstd),
+                      _ptr(gamma), _ptr(beta), int(relu), _ptr(stats), float(inv_n), int(training), n,
+                      d, _code(x), _ptr(dx), _ld(dx), _stream(dev))
+        return dx
+
+    # ---- T7 ----
+    @staticmethod
+    def axpby(x1, a: float, x2, b: float) -> torch.Tensor:
+        n, d = x1.shape
+        y = torch.empty((n, d), dtype=x1.dtype, device=x1.device)
+        with torch.cuda.device(x1.device):
+            _lib.call("sgf_axpby", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), n, d,
+                      _code(x1), _ptr(y), y.stride(0), _stream(x1.device))
+        return y
+
+
+K = HipKernels()
+
+
+def set_kernels(table):
+    """Install a kernel table (tests only; see module docstring).  Returns the previous one."""
+    global K
+    prev, K = K, table
+    graph_cache.clear()
+    return prev
+
+
+def _require_cuda(*tensors):
+    K.check(*tensors)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -84,54 +297,30 @@ class CSRGraph:
     """
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, validate: bool = True):
-        _require_cuda(edge_index)
+        K.check(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be an int64 tensor of shape [2, nnz]")
         if num_nodes >= 2 ** 31:
             raise ValueError("num_nodes must be < 2^31 (int32 column indices)")
         ei = edge_index.contiguous()
-        dev = ei.device
-        nnz = int(ei.shape[1])
         n = int(num_nodes)
-        if validate and nnz > 0:
+        if validate and ei.shape[1] > 0:
             lo, hi = torch.aminmax(ei)
             if int(lo) < 0 or int(hi) >= n:
                 raise IndexError(f"edge_index has node ids outside [0, {n})")
-        self.n, self.nnz, self.device = n, nnz, dev
+        self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
-        self.rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        self.colind = torch.empty(nnz, dtype=torch.int32, device=dev)
-        self.val = torch.empty(nnz, dtype=_F32, device=dev)
-        self.deg = torch.empty(n, dtype=torch.int32, device=dev)
-        lib = _lib.load()
-        nbytes = lib.sgf_csr_workspace_bytes(nnz, n)
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            _lib.call("sgf_csr_build", _ptr(ei), nnz, n, _ptr(self.rowptr), _ptr(self.colind),
-                      _ptr(self.val), _ptr(self.deg), _ptr(ws), ws.numel(), _stream(dev))
+        self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None
 
     def transposed(self):
-        """CSR of A^T for dX = A^T dY; the same arrays when A is symmetric (one host sync, once)."""
+        """CSR of A^T for dX = A^T dY; the same arrays when A is symmetric."""
         if self._t is None:
-            dev, n, nnz = self.device, self.n, self.nnz
-            t_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-            t_colind = torch.empty(nnz, dtype=torch.int32, device=dev)
-            t_val = torch.empty(nnz, dtype=_F32, device=dev)
-            flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib = _lib.load()
-            nbytes = lib.sgf_csr_workspace_bytes(nnz, n)
-            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _lib.call("sgf_csr_transpose", _ptr(self.edge_index), nnz, n, _ptr(self.deg),
-                          _ptr(self.rowptr), _ptr(self.colind), _ptr(t_rowptr), _ptr(t_colind),
-                          _ptr(t_val), _ptr(flag), _ptr(ws), ws.numel(), _stream(dev))
-            self.symmetric = bool(int(flag.item()))
-            if self.symmetric:
-                self._t = (self.rowptr, self.colind, self.val)
-            else:
-                self._t = (t_rowptr, t_colind, t_val)
+            t_rowptr, t_colind, t_val, sym = K.csr_transpose(self.edge_index, self.n, self.deg,
+                                                             self.rowptr, self.colind)
+            self.symmetric = sym
+            self._t = (self.rowptr, self.colind, self.val) if sym else (t_rowptr, t_colind, t_val)
         return self._t
 
 
@@ -144,14 +333,14 @@ class _GraphCache:
         self.capacity = capacity
         self._d: "OrderedDict[tuple, CSRGraph]" = OrderedDict()
 
-    def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+    def get(self, edge_index: torch.Tensor, num_nodes: int, factory=None):
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
                tuple(edge_index.stride()), str(edge_index.device), int(num_nodes))
         g = self._d.get(key)
         if g is not None:  # the entry pins its tensor, so an equal key means the same live memory
             self._d.move_to_end(key)
             return g
-        g = CSRGraph(edge_index, num_nodes)
+        g = (factory or CSRGraph)(edge_index, num_nodes)
         g.edge_index_ref = edge_index
         self._d[key] = g
         while len(self._d) > self.capacity:
@@ -168,42 +357,30 @@ graph_cache = _GraphCache()
 # ------------------------------------------------------------------------------------------------
 # T2: SpMM (large/ours.py:34)
 # ------------------------------------------------------------------------------------------------
-def _spmm_raw(rowptr, colind, val, x: torch.Tensor, n_rows: int) -> torch.Tensor:
-    x = _rows(x)
-    d = x.shape[1]
-    y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device)
-    if n_rows == 0 or d == 0:
-        return y
-    with torch.cuda.device(x.device):
-        _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), _ptr(y),
-                  y.stride(0), n_rows, d, _code(x), _stream(x.device))
-    return y
-
-
 class _SpMM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, graph: CSRGraph, shard):
-        _require_cuda(x)
+    def forward(ctx, x, graph, shard):
+        K.check(x)
         ctx.graph, ctx.shard = graph, shard
         if shard is not None:
             # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
             xg = shard.all_gather_rows(x)
-            return _spmm_raw(graph.rowptr, graph.colind, graph.val, xg, graph.n_local)
-        return _spmm_raw(graph.rowptr, graph.colind, graph.val, x, graph.n)
+            return K.spmm(graph.rowptr, graph.colind, graph.val, xg, graph.n_local)
+        return K.spmm(graph.rowptr, graph.colind, graph.val, x, graph.n)
 
     @staticmethod
     def backward(ctx, gy):
         graph, shard = ctx.graph, ctx.shard
         if shard is not None:
-            # dX_local = (A^T dY)[local rows]; A symmetric => A^T's local rows = local rows of A
+            # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the gathered dY
             gyg = shard.all_gather_rows(gy.contiguous())
-            rp, ci, va = graph.transposed_local()
-            return _spmm_raw(rp, ci, va, gyg, graph.n_local), None, None
+            rp, ci, va = graph.transposed()
+            return K.spmm(rp, ci, va, gyg, graph.n_local), None, None
         rp, ci, va = graph.transposed()
-        return _spmm_raw(rp, ci, va, gy.contiguous(), graph.n), None, None
+        return K.spmm(rp, ci, va, gy.contiguous(), graph.n), None, None
 
 
-def spmm(graph: CSRGraph, x: torch.Tensor, shard=None) -> torch.Tensor:
+def spmm(graph, x: torch.Tensor, shard=None) -> torch.Tensor:
     """Y = A X with A the cached normalised adjacency (torch_sparse.matmul(adj, x) in the reference)."""
     return _SpMM.apply(x, graph, shard)
 
@@ -211,44 +388,31 @@ def spmm(graph: CSRGraph, x: torch.Tensor, shard=None) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # T3: linear global attention (large/ours.py:130-157)
 # ------------------------------------------------------------------------------------------------
+def _split(qkv, v_ext, heads, d):
+    hd = heads * d
+    q, k = qkv[:, :hd], qkv[:, hd:2 * hd]
+    if v_ext is None:
+        return q, k, qkv[:, 2 * hd:], heads
+    return q, k, v_ext, 1
+
+
 class _Attention(torch.autograd.Function):
-    """qk: [N, 2*H*d] = [Q | K] (or qkv: [N, 3*H*d] = [Q | K | V]); v: [N, d] when V is not projected."""
+    """qkv: [N, 3*H*d] = [Q | K | V], or [N, 2*H*d] = [Q | K] with v_ext: [N, d] (V not projected)."""
 
     @staticmethod
     def forward(ctx, qkv, v_ext, heads: int, d: int, shard, n_override=None):
-        _require_cuda(qkv, v_ext)
-        qkv = _rows(qkv)
-        n = qkv.shape[0]
-        hd = heads * d
-        dev = qkv.device
-        if v_ext is None:
-            assert qkv.shape[1] == 3 * hd
-            v, ldv, v_heads = qkv[:, 2 * hd:], qkv.stride(0), heads
-        else:
-            assert qkv.shape[1] == 2 * hd
-            v_ext = _rows(v_ext)
-            v, ldv, v_heads = v_ext, v_ext.stride(0), 1
-        q, k = qkv[:, :hd], qkv[:, hd:2 * hd]
-        ld = qkv.stride(0)
-        lib = _lib.load()
-        code = _code(qkv)
-        slen = lib.sgf_attn_stats_len(heads, d)
-        stats = torch.empty(slen, dtype=_F32, device=dev)
-        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
-        st = _stream(dev)
+        K.check(qkv, v_ext)
+        qkv, v_ext = _rows(qkv), _rows(v_ext)
+        n, hd = qkv.shape[0], heads * d
+        assert qkv.shape[1] == (3 * hd if v_ext is None else 2 * hd)
+        q, k, v, v_heads = _split(qkv, v_ext, heads, d)
+        stats = K.attn_fwd_reduce(q, k, v, heads, v_heads, d)
         n_total = float(n) if n_override is None else float(n_override)
-        with torch.cuda.device(dev):
-            _lib.call("sgf_attn_fwd_reduce", _ptr(q), ld, _ptr(k), ld, _ptr(v), ldv, n, heads,
-                      v_heads, d, code, _ptr(stats), _ptr(ws), ws.numel(), st)
-            if shard is not None:
-                shard.all_reduce(stats)
-                if n_override is None:
-                    n_total = float(shard.n_global)
-            out = torch.empty((n, d), dtype=qkv.dtype, device=dev)
-            den = torch.empty((n, heads), dtype=_F32, device=dev)
-            o_heads = torch.empty((n, heads, d), dtype=qkv.dtype, device=dev) if heads > 1 else None
-            _lib.call("sgf_attn_fwd_apply", _ptr(q), ld, _ptr(v), ldv, n, n_total, heads, v_heads, d,
-                      code, _ptr(stats), _ptr(out), out.stride(0), _ptr(den), _ptr(o_heads), st)
+        if shard is not None:
+            shard.all_reduce(stats)
+            if n_override is None:
+                n_total = float(shard.n_global)
+        out, den, o_heads = K.attn_fwd_apply(q, v, stats, n_total, heads, v_heads, d)
         ctx.save_for_backward(qkv, v_ext, out, den, o_heads, stats)
         ctx.meta = (heads, d, n_total, shard)
         return out
@@ -258,38 +422,17 @@ class _Attention(torch.autograd.Function):
         qkv, v_ext, out, den, o_heads, stats = ctx.saved_tensors
         heads, d, n_total, shard = ctx.meta
         g = _rows(g.contiguous())
-        n = qkv.shape[0]
         hd = heads * d
-        dev = qkv.device
-        ld = qkv.stride(0)
-        q, k = qkv[:, :hd], qkv[:, hd:2 * hd]
-        if v_ext is None:
-            v, ldv, v_heads = qkv[:, 2 * hd:], ld, heads
-        else:
-            v, ldv, v_heads = v_ext, v_ext.stride(0), 1
-        o, ldo = (out, out.stride(0)) if heads == 1 else (o_heads, hd)
-        lib = _lib.load()
-        code = _code(qkv)
-        blen = lib.sgf_attn_bstats_len(heads, d)
-        bstats = torch.empty(blen, dtype=_F32, device=dev)
-        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
-        st = _stream(dev)
+        q, k, v, v_heads = _split(qkv, v_ext, heads, d)
+        o = out if heads == 1 else o_heads
+        bstats = K.attn_bwd_reduce(q, g, o, den, heads, d)
+        if shard is not None:
+            shard.all_reduce(bstats)
         dqkv = torch.empty_like(qkv)
-        dq, dk = dqkv[:, :hd], dqkv[:, hd:2 * hd]
-        if v_ext is None:
-            dv, lddv, dv_ext = dqkv[:, 2 * hd:], dqkv.stride(0), None
-        else:
-            dv_ext = torch.empty_like(v_ext)
-            dv, lddv = dv_ext, dv_ext.stride(0)
-        with torch.cuda.device(dev):
-            _lib.call("sgf_attn_bwd_reduce", _ptr(q), ld, _ptr(g), g.stride(0), _ptr(o), ldo,
-                      _ptr(den), n, heads, d, code, _ptr(bstats), _ptr(ws), ws.numel(), st)
-            if shard is not None:
-                shard.all_reduce(bstats)
-            _lib.call("sgf_attn_bwd_apply", _ptr(q), ld, _ptr(k), ld, _ptr(v), ldv, _ptr(g),
-                      g.stride(0), _ptr(o), ldo, _ptr(den), n, n_total, heads, v_heads, d, code,
-                      _ptr(stats), _ptr(bstats), _ptr(dq), dqkv.stride(0), _ptr(dk), dqkv.stride(0),
-                      _ptr(dv), lddv, st)
+        dv_ext = torch.empty_like(v_ext) if v_ext is not None else None
+        dv = dqkv[:, 2 * hd:] if v_ext is None else dv_ext
+        K.attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total, heads, v_heads, d,
+                         dqkv[:, :hd], dqkv[:, hd:2 * hd], dv)
         return dqkv, dv_ext, None, None, None, None
 
 
@@ -302,18 +445,10 @@ def attention(qkv: torch.Tensor, v_ext: Optional[torch.Tensor], heads: int, d: i
 
 def attention_stats(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
     """Un-normalised partials [S0 | z0 | ssq_q | ssq_k] (test / inspection helper, no autograd)."""
-    _require_cuda(q, k, v)
+    K.check(q, k, v)
     n, heads, d = q.shape
-    v_heads = v.shape[1]
     q2, k2, v2 = (_rows(t.reshape(n, -1)) for t in (q, k, v))
-    lib = _lib.load()
-    stats = torch.empty(lib.sgf_attn_stats_len(heads, d), dtype=_F32, device=q.device)
-    ws = _workspace(q.device, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
-    with torch.cuda.device(q.device):
-        _lib.call("sgf_attn_fwd_reduce", _ptr(q2), q2.stride(0), _ptr(k2), k2.stride(0), _ptr(v2),
-                  v2.stride(0), n, heads, v_heads, d, _code(q2), _ptr(stats), _ptr(ws), ws.numel(),
-                  _stream(q.device))
-    return stats
+    return K.attn_fwd_reduce(q2, k2, v2, heads, v.shape[1], d)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -322,21 +457,12 @@ def attention_stats(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
 class _LNResAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, a: float, b: float, gamma, beta, relu: bool, eps: float):
-        _require_cuda(x, res, gamma)
-        x = _rows(x)
-        res = None if res is None else _rows(res)
-        n, d = x.shape
-        dev = x.device
-        y = torch.empty((n, d), dtype=x.dtype, device=dev)
+        K.check(x, res, gamma)
+        x, res = _rows(x), _rows(res)
         has_ln = gamma is not None
-        g32 = gamma.float().contiguous() if has_ln else None
-        b32 = beta.float().contiguous() if has_ln else None
-        mean = torch.empty(n, dtype=_F32, device=dev) if has_ln else None
-        rstd = torch.empty(n, dtype=_F32, device=dev) if has_ln else None
-        with torch.cuda.device(dev):
-            _lib.call("sgf_ln_fwd", _ptr(x), x.stride(0), _ptr(res), 0 if res is None else res.stride(0),
-                      float(a), float(b), _ptr(g32), _ptr(b32), int(relu), float(eps), n, d, _code(x),
-                      _ptr(y), y.stride(0), _ptr(mean), _ptr(rstd), _stream(dev))
+        g32 = gamma.detach().float().contiguous() if has_ln else None
+        b32 = beta.detach().float().contiguous() if has_ln else None
+        y, mean, rstd = K.ln_fwd(x, res, a, b, g32, b32, relu, eps)
         ctx.save_for_backward(x, res, y if relu else None, g32, mean, rstd)
         ctx.meta = (float(a), float(b), bool(relu), gamma.dtype if has_ln else None)
         return y
@@ -346,22 +472,8 @@ class _LNResAct(torch.autograd.Function):
         x, res, y, g32, mean, rstd = ctx.saved_tensors
         a, b, relu, pdtype = ctx.meta
         gy = _rows(gy.contiguous())
-        n, d = x.shape
-        dev = x.device
-        has_ln = g32 is not None
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(res) if res is not None else None
-        dgamma = torch.empty(d, dtype=_F32, device=dev) if has_ln else None
-        dbeta = torch.empty(d, dtype=_F32, device=dev) if has_ln else None
-        lib = _lib.load()
-        ws = _workspace(dev, "ln", lib.sgf_ln_bwd_workspace_bytes(n, d))
-        with torch.cuda.device(dev):
-            _lib.call("sgf_ln_bwd", _ptr(gy), gy.stride(0), _ptr(y), 0 if y is None else y.stride(0),
-                      _ptr(x), x.stride(0), _ptr(res), 0 if res is None else res.stride(0), a, b,
-                      _ptr(g32), int(relu), _ptr(mean), _ptr(rstd), n, d, _code(x), _ptr(dx),
-                      dx.stride(0), _ptr(dres), 0 if dres is None else dres.stride(0), _ptr(dgamma),
-                      _ptr(dbeta), _ptr(ws), ws.numel(), _stream(dev))
-        if has_ln:
+        dx, dres, dgamma, dbeta = K.ln_bwd(gy, y, x, res, a, b, g32, relu, mean, rstd)
+        if g32 is not None:
             dgamma, dbeta = dgamma.to(pdtype), dbeta.to(pdtype)
         return dx, dres, None, None, dgamma, dbeta, None, None
 
@@ -373,34 +485,21 @@ def ln_res_act(x, res, a, b, gamma, beta, relu, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # T6: y = [relu](BatchNorm1d(x)) [+ res]   (large/ours.py:77-81, 87-93)
 # ------------------------------------------------------------------------------------------------
-def _colstats(x: torch.Tensor, shift: Optional[torch.Tensor]) -> torch.Tensor:
-    n, d = x.shape
-    dev = x.device
-    lib = _lib.load()
-    stats = torch.empty(2 * d, dtype=_F32, device=dev)
-    ws = _workspace(dev, "col", lib.sgf_colstats_workspace_bytes(n, d))
-    with torch.cuda.device(dev):
-        _lib.call("sgf_colstats", _ptr(x), x.stride(0), _ptr(shift), n, d, _code(x), _ptr(stats),
-                  _ptr(ws), ws.numel(), _stream(dev))
-    return stats
-
-
 def batch_stats(x: torch.Tensor, shard=None):
     """Two-pass column mean / biased variance over all rows (all ranks when sharded)."""
-    x = _rows(x)
+    K.check(x)
+    x = _rows(x.detach())
     n, d = x.shape
-    s1 = _colstats(x, None)[:d]
+    s1 = K.colstats(x, None)[:d].contiguous()
     n_tot = float(n)
     if shard is not None:
-        s1 = s1.contiguous()
         shard.all_reduce(s1)
         n_tot = float(shard.n_global)
-    mean = s1 / n_tot
-    s2 = _colstats(x, mean.contiguous())[d:]
+    mean = s1 / max(n_tot, 1.0)
+    s2 = K.colstats(x, mean)[d:].contiguous()
     if shard is not None:
-        s2 = s2.contiguous()
         shard.all_reduce(s2)
-    var = s2 / n_tot
+    var = s2 / max(n_tot, 1.0)
     return mean, var, n_tot
 
 
@@ -408,20 +507,13 @@ class _BNActRes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, mean, rstd, relu: bool, training: bool, n_tot: float,
                 shard):
-        _require_cuda(x, res)
-        x = _rows(x)
-        res = None if res is None else _rows(res)
-        n, d = x.shape
-        dev = x.device
-        g32 = gamma.float().contiguous() if gamma is not None else None
-        b32 = beta.float().contiguous() if beta is not None else None
-        mean = mean.float().contiguous()
-        rstd = rstd.float().contiguous()
-        y = torch.empty((n, d), dtype=x.dtype, device=dev)
-        with torch.cuda.device(dev):
-            _lib.call("sgf_bn_apply", _ptr(x), x.stride(0), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(b32),
-                      _ptr(res), 0 if res is None else res.stride(0), int(relu), n, d, _code(x),
-                      _ptr(y), y.stride(0), _stream(dev))
+        K.check(x, res)
+        x, res = _rows(x), _rows(res)
+        g32 = gamma.detach().float().contiguous() if gamma is not None else None
+        b32 = beta.detach().float().contiguous() if beta is not None else None
+        mean = mean.detach().float().contiguous()
+        rstd = rstd.detach().float().contiguous()
+        y = K.bn_apply(x, mean, rstd, g32, b32, res, relu)
         ctx.save_for_backward(x, g32, b32, mean, rstd)
         ctx.meta = (bool(relu), bool(training), float(n_tot), shard, res is not None,
                     gamma.dtype if gamma is not None else None)
@@ -432,25 +524,15 @@ class _BNActRes(torch.autograd.Function):
         x, g32, b32, mean, rstd = ctx.saved_tensors
         relu, training, n_tot, shard, has_res, pdtype = ctx.meta
         gy = _rows(gy.contiguous())
-        n, d = x.shape
-        dev = x.device
-        lib = _lib.load()
-        stats = torch.empty(2 * d, dtype=_F32, device=dev)
-        ws = _workspace(dev, "col", lib.sgf_colstats_workspace_bytes(n, d))
-        dx = torch.empty_like(x)
-        with torch.cuda.device(dev):
-            _lib.call("sgf_bn_bwd_stats", _ptr(gy), gy.stride(0), _ptr(x), x.stride(0), _ptr(mean),
-                      _ptr(rstd), _ptr(g32), _ptr(b32), int(relu), n, d, _code(x), _ptr(stats), _ptr(ws),
-                      ws.numel(), _stream(dev))
-            if shard is not None:
-                shard.all_reduce(stats)  # also makes dgamma / dbeta the global sums
-            _lib.call("sgf_bn_bwd_apply", _ptr(gy), gy.stride(0), _ptr(x), x.stride(0), _ptr(mean),
-                      _ptr(rstd), _ptr(g32), _ptr(b32), int(relu), _ptr(stats), 1.0 / max(n_tot, 1.0),
-                      int(training), n, d, _code(x), _ptr(dx), dx.stride(0), _stream(dev))
+        d = x.shape[1]
+        stats = K.bn_bwd_stats(gy, x, mean, rstd, g32, b32, relu)
+        if shard is not None:
+            shard.all_reduce(stats)  # also makes dgamma / dbeta the global sums
+        dx = K.bn_bwd_apply(gy, x, mean, rstd, g32, b32, relu, stats, 1.0 / max(n_tot, 1.0), training)
         dgamma = stats[d:].to(pdtype) if g32 is not None else None
         dbeta = stats[:d].to(pdtype) if b32 is not None else None
         if shard is not None and g32 is not None:
-            # parameter grads are all-reduced (averaged) again by the shard's grad sync: pre-divide
+            # parameter grads are summed over ranks again by ShardContext.sync_grads: pre-divide
             dgamma, dbeta = shard.unsum(dgamma), shard.unsum(dbeta)
         return dx, (gy if has_res else None), dgamma, dbeta, None, None, None, None, None, None
 
@@ -465,15 +547,9 @@ def bn_act_res(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard=Non
 class _Axpby(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, a: float, b: float):
-        _require_cuda(x1, x2)
-        x1, x2 = _rows(x1), _rows(x2)
-        n, d = x1.shape
-        y = torch.empty((n, d), dtype=x1.dtype, device=x1.device)
-        with torch.cuda.device(x1.device):
-            _lib.call("sgf_axpby", _ptr(x1), x1.stride(0), float(a), _ptr(x2), x2.stride(0), float(b),
-                      n, d, _code(x1), _ptr(y), y.stride(0), _stream(x1.device))
+        K.check(x1, x2)
         ctx.ab = (float(a), float(b))
-        return y
+        return K.axpby(_rows(x1), a, _rows(x2), b)
 
     @staticmethod
     def backward(ctx, g):

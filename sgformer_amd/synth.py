@@ -1,0 +1,63 @@
+"""Synthetic inputs with the shapes of the reference's datasets.
+
+There is no network, so tests, smoke() and bench.py run on synthetic graphs.  The generator applies
+the trainer prologue of large/main.py:75-79 (to_undirected = symmetrise + coalesce, remove
+self-loops, add one self-loop per node), so `edge_index` looks exactly like what the reference
+hands to `model(x, edge_index)`.
+"""
+from __future__ import annotations
+
+import torch
+
+# name -> (N, average degree of the symmetrised graph before self-loops, features, classes, hidden)
+SHAPES = {
+    "cora": (2708, 3.9, 1433, 7, 64),
+    "ogbn-arxiv": (169343, 13.7, 128, 40, 256),
+    "ogbn-products": (2449029, 50.5, 100, 47, 256),
+    "pokec": (1632803, 27.3, 65, 2, 256),
+}
+
+# constructor keywords of the large/run.sh recipes (dropout overridden by the caller)
+RECIPES = {
+    # large/run.sh:2-5
+    "ogbn-arxiv": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                       trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
+                       gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=False, gnn_use_act=True,
+                       use_graph=True, graph_weight=0.5, aggregate="add"),
+    # large/run.sh:15-19 (amazon2m = the ogbn-products graph)
+    "ogbn-products": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                          trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
+                          gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
+                          use_graph=True, graph_weight=0.5, aggregate="add"),
+    # large/run.sh:22-26
+    "pokec": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                  trans_use_weight=True, trans_use_act=False, gnn_num_layers=2, gnn_use_bn=True,
+                  gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
+                  use_graph=True, graph_weight=0.5, aggregate="add"),
+}
+
+
+def synthetic_graph(n: int, avg_deg: float, seed: int = 123, directed: bool = False,
+                    device="cpu") -> torch.Tensor:
+    """Uniform random graph + trainer prologue.  int64 [2, nnz], coalesced edges then N self-loops."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    m = int(n * avg_deg / 2)
+    src = torch.randint(0, n, (m,), generator=g).to(device)
+    dst = torch.randint(0, n, (m,), generator=g).to(device)
+    if not directed:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])          # coalesce: sorted, duplicates dropped
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
+def synthetic_task(n: int, f: int, c: int, seed: int = 123, device="cpu", dtype=torch.float32):
+    """randn features, uniform labels, first half of a seeded permutation as the training split
+    (rand_train_test_idx, large/data_utils.py:13-37, with train_prop = 0.5)."""
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    x = torch.randn(n, f, generator=g).to(device=device, dtype=dtype)
+    y = torch.randint(0, c, (n,), generator=g).to(device)
+    train_idx = torch.randperm(n, generator=g)[: n // 2].to(device)
+    return x, y, train_idx

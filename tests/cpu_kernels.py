@@ -1,0 +1,174 @@
+"""A CPU kernel table with the exact contract of sgformer_amd.ops.HipKernels — TEST ONLY.
+
+Installed with `ops.set_kernels(CpuKernels())` by the CPU tests so that the host logic above the
+C ABI (ops.py autograd wiring, ours.py module surface, dist.py sharding and collectives under
+gloo) can be exercised without a GPU.  Every method restates what the corresponding libsgf entry
+point computes (same decomposition into un-normalised partials, same buffer layouts), on top of
+the oracle package; it is therefore also an executable specification of include/sgf.h.  It lives
+under tests/ and is never imported by the product.
+"""
+import numpy as np
+import torch
+
+from oracle import sgformer_oracle as O
+
+
+class CpuKernels:
+    name = "cpu-oracle"
+
+    @staticmethod
+    def check(*tensors):
+        return None
+
+    # ---- T1 ----
+    @staticmethod
+    def csr_build(ei, n):
+        rowptr, colind, val, deg = O.csr_build(ei.cpu().numpy(), n)
+        return (torch.from_numpy(rowptr), torch.from_numpy(colind.astype(np.int32)),
+                torch.from_numpy(val), torch.from_numpy(deg.astype(np.int32)))
+
+    @staticmethod
+    def csr_transpose(ei, n, deg, rowptr, colind):
+        t_rowptr, t_colind, t_val, sym = O.csr_transpose(ei.cpu().numpy(), n)
+        return (torch.from_numpy(t_rowptr), torch.from_numpy(t_colind.astype(np.int32)),
+                torch.from_numpy(t_val), sym)
+
+    # ---- T2 ----
+    @staticmethod
+    def spmm(rowptr, colind, val, x, n_rows):
+        y = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
+        if n_rows == 0 or colind.numel() == 0:
+            return y
+        counts = (rowptr[1:] - rowptr[:-1])
+        rows = torch.repeat_interleave(torch.arange(n_rows), counts)
+        return y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
+
+    # ---- T3 ----
+    @staticmethod
+    def _unpack(stats, heads, d):
+        nm = heads * d * d
+        return stats[:nm].reshape(heads, d, d), stats[nm:nm + heads * d].reshape(heads, d)
+
+    @staticmethod
+    def attn_fwd_reduce(q, k, v, heads, v_heads, d):
+        n = q.shape[0]
+        return O.attention_raw_stats(q.reshape(n, heads, d).float(), k.reshape(n, heads, d).float(),
+                                     v.reshape(n, v_heads, d).float())
+
+    @staticmethod
+    def attn_fwd_apply(q, v, stats, n_total, heads, v_heads, d):
+        n = q.shape[0]
+        s0, z0 = CpuKernels._unpack(stats, heads, d)
+        c = 1.0 / (torch.sqrt(stats[-2]) * torch.sqrt(stats[-1]))
+        qh = q.reshape(n, heads, d).float()
+        vh = v.reshape(n, v_heads, d).float().expand(-1, heads, -1)
+        den = c * torch.einsum("nhm,hm->nh", qh, z0) + n_total
+        num = c * torch.einsum("nhm,hmd->nhd", qh, s0) + n_total * vh
+        o = num / den.unsqueeze(-1)
+        out = o.mean(dim=1).to(q.dtype)
+        return out, den.contiguous(), (o.reshape(n, heads * d).to(q.dtype) if heads > 1 else None)
+
+    @staticmethod
+    def attn_bwd_reduce(q, g, o, den, heads, d):
+        n = q.shape[0]
+        qh = q.reshape(n, heads, d).float()
+        oh = o.reshape(n, heads, d).float()
+        gh = (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
+        dnum = gh / den.unsqueeze(-1)
+        dden = -(gh * oh).sum(-1) / den
+        ds0 = torch.einsum("nhm,nhd->hmd", qh, dnum)
+        dz0 = torch.einsum("nhm,nh->hm", qh, dden)
+        return torch.cat([ds0.reshape(-1), dz0.reshape(-1), torch.zeros(1)])
+
+    @staticmethod
+    def attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total, heads, v_heads, d, dq, dk, dv):
+        n = q.shape[0]
+        s0, z0 = CpuKernels._unpack(stats, heads, d)
+        ds0, dz0 = CpuKernels._unpack(bstats, heads, d)
+        ssq_q, ssq_k = stats[-2], stats[-1]
+        c = 1.0 / (torch.sqrt(ssq_q) * torch.sqrt(ssq_k))
+        sdot = (s0 * ds0).sum() + (z0 * dz0).sum()
+        bstats[-1] = sdot
+        s = c * sdot
+        qh, kh = q.reshape(n, heads, d).float(), k.reshape(n, heads, d).float()
+        vh = v.reshape(n, v_heads, d).float().expand(-1, heads, -1)
+        oh = o.reshape(n, heads, d).float()
+        gh = (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
+        dnum = gh / den.unsqueeze(-1)
+        dden = -(gh * oh).sum(-1) / den
+        gq = c * (torch.einsum("nhd,hmd->nhm", dnum, s0) + dden.unsqueeze(-1) * z0) - s * qh / ssq_q
+        gk = c * (torch.einsum("nhd,hmd->nhm", vh, ds0) + dz0) - s * kh / ssq_k
+        gv = n_total * dnum + c * torch.einsum("nhm,hmd->nhd", kh, ds0)
+        if v_heads == 1 and heads > 1:
+            gv = gv.sum(dim=1, keepdim=True)
+        dq.copy_(gq.reshape(n, -1).to(dq.dtype))
+        dk.copy_(gk.reshape(n, -1).to(dk.dtype))
+        dv.copy_(gv.reshape(n, -1).to(dv.dtype))
+
+    # ---- T5 ----
+    @staticmethod
+    def ln_fwd(x, res, a, b, gamma, beta, relu, eps):
+        pre = a * x.float() + (b * res.float() if res is not None else 0.0)
+        mean = rstd = None
+        if gamma is not None:
+            mean = pre.mean(dim=1)
+            rstd = 1.0 / torch.sqrt(((pre - mean[:, None]) ** 2).mean(dim=1) + eps)
+            pre = (pre - mean[:, None]) * rstd[:, None] * gamma + beta
+        y = torch.relu(pre) if relu else pre
+        return y.to(x.dtype), mean, rstd
+
+    @staticmethod
+    def ln_bwd(gy, y, x, res, a, b, gamma, relu, mean, rstd):
+        dz = gy.float()
+        if relu:
+            dz = dz * (y.float() > 0)
+        dgamma = dbeta = None
+        if gamma is not None:
+            pre = a * x.float() + (b * res.float() if res is not None else 0.0)
+            xh = (pre - mean[:, None]) * rstd[:, None]
+            dgamma, dbeta = (dz * xh).sum(0), dz.sum(0)
+            dxh = dz * gamma
+            dz = rstd[:, None] * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True))
+        dx = (a * dz).to(x.dtype)
+        dres = (b * dz).to(x.dtype) if res is not None else None
+        return dx, dres, dgamma, dbeta
+
+    # ---- T6 ----
+    @staticmethod
+    def colstats(x, shift):
+        v = x.float() - (shift if shift is not None else 0.0)
+        return torch.cat([v.sum(0), (v * v).sum(0)])
+
+    @staticmethod
+    def _bn(x, mean, rstd, gamma, beta):
+        xh = (x.float() - mean) * rstd
+        return xh, xh * (gamma if gamma is not None else 1.0) + (beta if beta is not None else 0.0)
+
+    @staticmethod
+    def bn_apply(x, mean, rstd, gamma, beta, res, relu):
+        _, y = CpuKernels._bn(x, mean, rstd, gamma, beta)
+        if relu:
+            y = torch.relu(y)
+        if res is not None:
+            y = y + res.float()
+        return y.to(x.dtype)
+
+    @staticmethod
+    def bn_bwd_stats(gy, x, mean, rstd, gamma, beta, relu):
+        xh, y = CpuKernels._bn(x, mean, rstd, gamma, beta)
+        dz = gy.float() * (y > 0) if relu else gy.float()
+        return torch.cat([dz.sum(0), (dz * xh).sum(0)])
+
+    @staticmethod
+    def bn_bwd_apply(gy, x, mean, rstd, gamma, beta, relu, stats, inv_n, training):
+        d = x.shape[1]
+        xh, y = CpuKernels._bn(x, mean, rstd, gamma, beta)
+        dz = gy.float() * (y > 0) if relu else gy.float()
+        if training:
+            dz = dz - stats[:d] * inv_n - xh * stats[d:] * inv_n
+        return ((gamma if gamma is not None else 1.0) * rstd * dz).to(x.dtype)
+
+    # ---- T7 ----
+    @staticmethod
+    def axpby(x1, a, x2, b):
+        return (a * x1.float() + b * x2.float()).to(x1.dtype)

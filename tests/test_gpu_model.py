@@ -69,8 +69,9 @@ def test_forward_backward_parity(cuda, name, shape):
     logits = m(x.to(cuda), ei.to(cuda))
     loss = O.nll_loss(logits, y.to(cuda), idx.to(cuda))
     loss.backward()
-    assert float((logits.double().cpu() - logits_ref.detach()).abs().max()) <= 1e-4
+    assert float((logits.detach().double().cpu() - logits_ref.detach()).abs().max()) <= 1e-4
     assert abs(float(loss) - float(loss_ref)) <= 1e-5
+    gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
     for k, prm in m.named_parameters():
         g_ref = p64[k].grad
         if g_ref is None:              # unused W of GraphConvLayer (large/ours.py:20 vs :36-40)
@@ -78,7 +79,8 @@ def test_forward_backward_parity(cuda, name, shape):
             continue
         num = float((prm.grad.double().cpu() - g_ref).norm())
         den = float(g_ref.norm())
-        assert num <= 2e-4 * den + 1e-9, (k, num, den)
+        # floor: a Linear bias in front of BatchNorm has an exactly-zero gradient in exact arithmetic
+        assert num <= 2e-4 * den + 1e-6 * gmax, (k, num, den)
     # BatchNorm running statistics after one step (momentum 0.1 from the init_params values)
     if cfg.get("gnn_use_bn", True) and cfg.get("use_graph", True):
         for key, (mu, var_unb) in stats.items():

@@ -1,0 +1,208 @@
+"""CPU tests of everything above the C ABI (no GPU, no kernels launched):
+  * the C-ABI library loads and exports every symbol include/sgf.h declares, with the arity the
+    ctypes binding uses;
+  * ops.py / ours.py host logic, driven by the CPU kernel table of tests/cpu_kernels.py, against
+    the oracle (forward, backward, BatchNorm bookkeeping, surface);
+  * the graph cache rules of SURVEY.md Appendix A.
+"""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import sgformer_oracle as O
+from tests.cpu_kernels import CpuKernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI
+# ------------------------------------------------------------------------------------------------
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "sgf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|size_t|int64_t|const char\*)\s+(sgf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_header_binding_and_library_agree():
+    from sgformer_amd import _lib
+    decls = _header_decls()
+    assert len(decls) >= 22
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name][1]) == n, name
+    if not _lib.available():
+        pytest.skip("libsgf.so not built (run `make`)")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decls:
+        assert hasattr(lib, name), f"{name} not exported"
+    lib.sgf_version.restype = ctypes.c_int
+    assert lib.sgf_version() == 100
+    # pure host queries are safe without a GPU
+    lib.sgf_attn_stats_len.restype = ctypes.c_int64
+    assert lib.sgf_attn_stats_len(2, 64) == 2 * 64 * 64 + 2 * 64 + 2
+    lib.sgf_attn_bstats_len.restype = ctypes.c_int64
+    assert lib.sgf_attn_bstats_len(1, 256) == 256 * 256 + 256 + 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from sgformer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsgf.so")
+    with pytest.raises(_lib.SgfError, match="no CPU"):
+        _lib.load()
+
+
+def test_product_has_no_cpu_path():
+    from sgformer_amd import ops
+    assert ops.K.name == "hip"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.attention(torch.zeros(4, 192), None, 1, 64)
+    from sgformer_amd.ours import SGFormer
+    m = SGFormer(8, 16, 3, trans_dropout=0.0, gnn_dropout=0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(5, 8), torch.zeros((2, 0), dtype=torch.int64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sgformer_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", open(os.path.join(pkg, fn)).read(), re.M), fn
+
+
+# ------------------------------------------------------------------------------------------------
+# host logic with the CPU kernel table
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def cpu_table():
+    from sgformer_amd import ops
+    prev = ops.set_kernels(CpuKernels())
+    yield
+    ops.set_kernels(prev)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("n,h,d,shared", [(60, 1, 16, False), (45, 2, 8, False), (45, 3, 8, True)])
+def test_attention_function_matches_autograd(cpu_table, n, h, d, shared):
+    """The un-normalised two-pass decomposition + hand-derived backward that the
+    HIP kernels implement equals autograd through the reference arithmetic."""
+    from sgformer_amd import ops
+    torch.manual_seed(0)
+    q, k = torch.randn(n, h, d, dtype=torch.float64), torch.randn(n, h, d, dtype=torch.float64)
+    v = torch.randn(n, 1 if shared else h, d, dtype=torch.float64)
+    qd, kd, vd = (t.clone().requires_grad_(True) for t in (q, k, v))
+    w = torch.randn(n, d, dtype=torch.float64)
+    (O.attention(qd, kd, vd) * w).sum().backward()
+    qk = torch.cat([q.reshape(n, -1), k.reshape(n, -1)], 1).float()
+    if shared:
+        qkv, vx = qk.requires_grad_(True), v.reshape(n, d).float().requires_grad_(True)
+    else:
+        qkv, vx = torch.cat([qk, v.reshape(n, -1).float()], 1).requires_grad_(True), None
+    out = ops.attention(qkv, vx, h, d)
+    (out * w.float()).sum().backward()
+    hd = h * d
+    assert _rel(out, O.attention(q, k, v)) < 1e-6
+    assert _rel(qkv.grad[:, :hd], qd.grad.reshape(n, -1)) < 1e-3
+    assert _rel(qkv.grad[:, hd:2 * hd], kd.grad.reshape(n, -1)) < 1e-3
+    gv = vx.grad if shared else qkv.grad[:, 2 * hd:]
+    assert _rel(gv, vd.grad.reshape(n, -1)) < 1e-5
+
+
+CONFIGS = {
+    "arxiv": dict(trans_num_layers=1, trans_use_act=False, gnn_num_layers=3, graph_weight=0.5),
+    "products": dict(trans_num_layers=1, trans_use_act=False, gnn_num_layers=2, gnn_use_init=True,
+                     graph_weight=0.5),
+    "heads_cat": dict(trans_num_layers=2, trans_num_heads=2, gnn_num_layers=1, aggregate="cat"),
+    "bare": dict(trans_use_weight=False, trans_use_bn=False, trans_use_residual=False, trans_use_act=False,
+                 gnn_use_weight=False, gnn_use_bn=False, gnn_use_residual=False, gnn_use_act=False,
+                 gnn_num_layers=2),
+    "alpha": dict(alpha=0.3, gnn_num_layers=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_module_host_logic_matches_oracle(cpu_table, name):
+    from sgformer_amd.ours import SGFormer
+    cfg = CONFIGS[name]
+    n, f, d, c = 180, 12, 16, 4
+    torch.manual_seed(1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 5.0, seed=3)
+    y = torch.randint(0, c, (n,))
+    idx = torch.arange(0, n, 2)
+    p = O.init_params(cfg, f, d, c, seed=2)
+    m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+    m.load_state_dict({**m.state_dict(), **p})
+    m.train()
+    logits = m(x, ei)
+    O.nll_loss(logits, y, idx).backward()
+    p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    stats = {}
+    ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True, bn_stats=stats)
+    O.nll_loss(ref, y, idx).backward()
+    assert float((logits.detach().double() - ref.detach()).abs().max()) < 2e-5
+    gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+    for k, prm in m.named_parameters():
+        if p64[k].grad is None:
+            assert prm.grad is None
+            continue
+        err = float((prm.grad.double() - p64[k].grad).norm())
+        assert err <= 2e-3 * float(p64[k].grad.norm()) + 1e-5 * gmax, k
+    for key, (mu, vu) in stats.items():
+        sd = m.state_dict()
+        assert torch.allclose(sd[key + ".running_mean"].double(), 0.9 * p[key + ".running_mean"].double() + 0.1 * mu, atol=1e-5)
+        assert torch.allclose(sd[key + ".running_var"].double(), 0.9 * p[key + ".running_var"].double() + 0.1 * vu, atol=1e-5)
+        assert int(sd[key + ".num_batches_tracked"]) == 1
+    m.eval()
+    with torch.no_grad():
+        le = m(x, ei)
+    pe = {k: v.double() for k, v in m.state_dict().items()}
+    assert float((le.double() - O.sgformer_forward(pe, x.double(), ei, cfg, training=False)).abs().max()) < 2e-5
+
+
+def test_dropout_and_attention_maps(cpu_table):
+    from sgformer_amd.ours import SGFormer
+    torch.manual_seed(0)
+    m = SGFormer(10, 16, 3, trans_num_layers=2, trans_dropout=0.5, gnn_dropout=0.5, gnn_num_layers=2)
+    x, ei = torch.randn(50, 10), O.synthetic_graph(50, 4.0, seed=1)
+    m.train()
+    a, b = m(x, ei), m(x, ei)
+    assert not torch.equal(a, b)                     # dropout active in training mode
+    m.eval()
+    assert torch.equal(m(x, ei), m(x, ei))           # and off in eval mode
+    att = m.get_attentions(x)
+    assert att.shape == (2, 50, 50)
+    with pytest.raises(TypeError):
+        SGFormer(10, 16, 3, trans_dropout=None)(x, ei)   # large/parse.py:95 hazard, surfaced
+
+
+def test_graph_cache_rules(cpu_table):
+    from sgformer_amd import ops
+    ei = O.synthetic_graph(40, 4.0, seed=1)
+    g1 = ops.graph_cache.get(ei, 40)
+    assert ops.graph_cache.get(ei, 40) is g1                     # same tensor -> cached
+    assert ops.graph_cache.get(ei[:, :], 40) is g1               # a view of the same memory too
+    ei2 = ei.clone()
+    assert ops.graph_cache.get(ei2, 40) is not g1                # new tensor (mini-batch trainers)
+    ei2[0, 0] = (ei2[0, 0] + 1) % 40                             # in-place edit bumps _version
+    g3 = ops.graph_cache.get(ei2, 40)
+    assert g3 is not ops.graph_cache._d.get(None) and g3.nnz == ei2.shape[1]
+    for s in range(10):                                          # bounded (LRU)
+        ops.graph_cache.get(O.synthetic_graph(30, 3.0, seed=s), 30)
+    assert len(ops.graph_cache._d) <= ops.graph_cache.capacity
+    with pytest.raises(IndexError):
+        ops.CSRGraph(torch.tensor([[0, 9], [1, 2]]), 4)
+    with pytest.raises(ValueError):
+        ops.CSRGraph(torch.zeros((2, 3), dtype=torch.int32), 4)

@@ -1,0 +1,121 @@
+"""Pins for the oracle (CPU, no GPU): oracle/sgformer_oracle.py against
+  (a) the committed golden vectors dumped from the LIVE reference by oracle/make_golden.py,
+  (b) the live reference itself when /root/reference is mounted (build container only).
+Everything is float64: agreement is to rounding (1e-12), not to a model tolerance.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_shim, sgformer_oracle as O
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_golden(path):
+    z, meta = _load(path)
+    cfg = meta["cfg"]
+    x = torch.from_numpy(z["x"])
+    ei = torch.from_numpy(z["edge_index"])
+    y = torch.from_numpy(z["y"])
+    idx = torch.from_numpy(z["train_idx"])
+    p = {k[6:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("param/")}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    parts, stats = {}, {}
+    logits = O.sgformer_forward(p, x, ei, cfg, training=True, parts=parts, bn_stats=stats)
+    assert np.abs(logits.detach().numpy() - z["logits_train"]).max() <= 1e-12
+    loss = O.nll_loss(logits, y, idx)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-12
+    loss.backward()
+    for k in z.files:
+        if k.startswith("grad/"):
+            g = p[k[5:]].grad
+            assert g is not None, k
+            assert np.abs(g.numpy() - z[k]).max() <= 1e-12 + 1e-9 * np.abs(z[k]).max(), k
+    # attention intermediates of the reference's einsum calls (large/ours.py:136-143)
+    for i in range(cfg.get("trans_num_layers", 1)):
+        pr = parts[f"attn{i}"]
+        assert np.abs(pr["kvs"].detach().numpy() - z[f"attn{i}/kvs"]).max() <= 1e-14
+        assert np.abs(pr["ks_sum"].detach().numpy() - z[f"attn{i}/ks_sum"]).max() <= 1e-14
+        n = x.shape[0]
+        q_kvs = (pr["num"] - n * pr["vs"]).detach().numpy()
+        assert np.abs(q_kvs - z[f"attn{i}/q_kvs"]).max() <= 1e-10
+        assert np.abs((pr["den"].squeeze(-1) - n).detach().numpy() - z[f"attn{i}/q_ks_sum"]).max() <= 1e-10
+        # the un-normalised partials libsgf reduces, rescaled, are the reference's kvs / ks_sum
+        raw = O.attention_raw_stats(pr["qs"], pr["ks"], pr["vs"]).detach()
+        h, d = pr["qs"].shape[1], pr["qs"].shape[2]
+        s0 = raw[: h * d * d].reshape(h, d, d) / torch.sqrt(raw[-1])
+        assert np.abs(s0.numpy() - z[f"attn{i}/kvs"]).max() <= 1e-13
+    # BatchNorm running statistics after the step (momentum 0.1)
+    for key, (mu, var_unb) in stats.items():
+        rm = 0.9 * p[key + ".running_mean"] + 0.1 * mu
+        rv = 0.9 * p[key + ".running_var"] + 0.1 * var_unb
+        assert np.abs(rm.numpy() - z["after/" + key + ".running_mean"]).max() <= 1e-12
+        assert np.abs(rv.numpy() - z["after/" + key + ".running_var"]).max() <= 1e-12
+    # eval mode on the updated running statistics
+    pe = {k: v.detach() for k, v in p.items()}
+    for k in z.files:
+        if k.startswith("after/"):
+            pe[k[6:]] = torch.from_numpy(z[k])
+    le = O.sgformer_forward(pe, x, ei, cfg, training=False)
+    assert np.abs(le.numpy() - z["logits_eval"]).max() <= 1e-12
+    # CSR arrays: the reference's sorted COO (target, source, fp32 value) bit for bit
+    if "coo/row" in z.files:
+        rowptr, colind, val, deg = O.csr_build(z["edge_index"], x.shape[0])
+        assert np.array_equal(np.repeat(np.arange(x.shape[0]), np.diff(rowptr)), z["coo/row"])
+        assert np.array_equal(colind, z["coo/col"])
+        assert np.array_equal(val.view(np.uint32), z["coo/value"].view(np.uint32))
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not mounted")
+@pytest.mark.parametrize("cfg", [
+    dict(trans_num_layers=1, gnn_num_layers=2, gnn_use_init=True, graph_weight=0.5, trans_use_act=False),
+    dict(trans_num_layers=2, trans_num_heads=2, gnn_num_layers=1, aggregate="cat"),
+    dict(trans_use_weight=False, trans_num_heads=2, gnn_use_weight=False, gnn_use_bn=False, trans_use_bn=False),
+    dict(use_graph=False),
+])
+def test_oracle_matches_live_reference(cfg):
+    ref = ref_shim.load_reference("large")
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(3)
+        n, f, d, c = 211, 18, 16, 5
+        m = ref.SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg).double()
+        x = torch.randn(n, f)
+        ei = O.synthetic_graph(n, 6.0, seed=8)
+        p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.train()
+        a = m(x, ei)
+        b = O.sgformer_forward(p, x, ei, cfg, training=True)
+        assert float((a - b).abs().max()) <= 1e-12
+        m.eval()
+        p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        assert float((m(x, ei) - O.sgformer_forward(p, x, ei, cfg, training=False)).abs().max()) <= 1e-12
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_csr_oracle_edge_cases():
+    # zero in-degree source -> inf -> 0 (large/ours.py:32); duplicates kept; isolated nodes
+    ei = np.array([[0, 0, 2, 2, 3], [1, 1, 1, 2, 1]])
+    rowptr, colind, val, deg = O.csr_build(ei, 5)
+    assert rowptr.tolist() == [0, 0, 4, 5, 5, 5]
+    assert colind.tolist() == [0, 0, 2, 3, 2]
+    assert deg.tolist() == [0, 4, 1, 0, 0]
+    assert val[0] == 0.0 and val[1] == 0.0 and val[3] == 0.0          # sources 0 and 3 have in-degree 0
+    assert val[2] == np.float32(np.sqrt(np.float32(1) / np.float32(4))) * np.float32(1.0)
+    t_rowptr, t_colind, t_val, sym = O.csr_transpose(ei, 5)
+    assert not sym and t_rowptr.tolist() == [0, 2, 2, 4, 5, 5]

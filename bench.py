@@ -187,7 +187,9 @@ def main():
     x, y, train_idx = x.to(dev, dtype), y.to(dev), train_idx.to(dev)
 
     torch.manual_seed(args.seed)
-    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg).to(dev, dtype)
+    # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
+                     compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
     if ctx is not None:
         shard_model(model, ctx)
     opt = torch.optim.Adam([{"params": model.params1, "weight_decay": 1e-5},

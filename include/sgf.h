@@ -205,6 +205,13 @@ int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
 int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
               int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
 
+/* Column sum out[j] = sum_n x[n,j] for ANY 1 <= d <= 256 (no multiple-of-4 requirement): the bias
+ * gradient of the output layer, large/ours.py:275 under autograd, where d = number of classes
+ * (47 for ogbn-products).  fp32 result, deterministic two-stage reduction. */
+size_t sgf_colsum_workspace_bytes(int64_t n, int32_t d);
+int sgf_colsum(const void* x, int64_t ldx, int64_t n, int32_t d, int32_t dtype, float* out,
+               void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

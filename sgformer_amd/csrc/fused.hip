@@ -198,17 +198,54 @@ __global__ __launch_bounds__(kThreads) void k_ln_bwd(
   }
 }
 
-// out[j] = sum_b part[b][j], j < width (fixed order)
-__global__ void k_sum_partials(const float* __restrict__ part, int nblk, int width,
-                               float* __restrict__ out0, float* __restrict__ out1, int split) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= width) return;
+// out[j] = sum_b part[b][j], j < width.  Fixed summation order (deterministic): 8 interleaved
+// partial chains per column (b = g, g+8, ...) combined in order g = 0..7 through LDS.
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nblk,
+                                                      int width, float* __restrict__ out0,
+                                                      float* __restrict__ out1, int split) {
+  __shared__ float red[256];
+  const int c = threadIdx.x & 31;
+  const int g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[static_cast<int64_t>(b) * width + j];
-  if (j < split) {
-    if (out0) out0[j] = s;
-  } else {
-    if (out1) out1[j - split] = s;
+  if (j < width)
+    for (int b = g; b < nblk; b += 8) s += part[static_cast<int64_t>(b) * width + j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && j < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k * 32 + c];
+    if (j < split) {
+      if (out0) out0[j] = t;
+    } else {
+      if (out1) out1[j - split] = t;
+    }
+  }
+}
+
+// generic column sum for ANY d (e.g. the [N, C] logits gradient, C = 47): part[blk][d]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_colsum_any(const T* __restrict__ x, int64_t ldx,
+                                                         int64_t n, int d, float* __restrict__ part) {
+  __shared__ float red[kThreads];
+  const int rpp = kThreads / d;            // row slots per pass (d <= 256)
+  const int c = threadIdx.x % d;
+  const int sr = threadIdx.x / d;
+  float s = 0.f;
+  if (sr < rpp) {
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    for (int64_t row = r0 + sr; row < r1; row += rpp) s += load1<T>(x + row * ldx + c);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < d) {
+    float t = 0.f;
+    for (int r = 0; r < rpp; ++r) t += red[r * d + threadIdx.x];
+    part[static_cast<int64_t>(blockIdx.x) * d + threadIdx.x] = t;
   }
 }
 
@@ -474,7 +511,7 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const voi
                             static_cast<T*>(dx), lddx, static_cast<T*>(dres), lddres, part);
   if (rc != SGF_OK) return rc;
   if (gamma != nullptr && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, nblk,
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, nblk,
                        2 * d, dgamma, dbeta, d);
     SGF_LAUNCH_CHECK();
   }
@@ -487,7 +524,7 @@ int colreduce(F f, int64_t n, int d, float* stats, void* ws, hipStream_t st) {
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL((k_colreduce<F>), dim3(nblk), dim3(kThreads), 0, st, f, n, d, part);
   SGF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, nblk, 2 * d,
+  hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, nblk, 2 * d,
                      stats, stats + d, d);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -667,6 +704,40 @@ extern "C" int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, i
     hipLaunchKernelGGL((k_axpby<uint16_t>), grid, dim3(kThreads), 0, st,
                        static_cast<const uint16_t*>(x1), ld1, a, static_cast<const uint16_t*>(x2),
                        ld2, b, n, d, static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" size_t sgf_colsum_workspace_bytes(int64_t n, int32_t d) {
+  (void)n;
+  if (d < 1) return 0;
+  return static_cast<size_t>(kMaxStatBlocks) * d * sizeof(float);
+}
+
+extern "C" int sgf_colsum(const void* x, int64_t ldx, int64_t n, int32_t d, int32_t dtype,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(n >= 0 && d >= 1 && d <= kThreads, SGF_E_UNSUPPORTED,
+              "sgf_colsum: need 1 <= d <= %d (d=%d)", kThreads, d);
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "sgf_colsum: unknown dtype");
+  SGF_REQUIRE(out, SGF_E_INVALID, "sgf_colsum: null out");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(out, 0, d * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(x && workspace && workspace_bytes >= sgf_colsum_workspace_bytes(n, d), SGF_E_WORKSPACE,
+              "sgf_colsum: null x or workspace too small");
+  const int nblk = stat_blocks(n);
+  float* part = static_cast<float*>(workspace);
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_colsum_any<float>), dim3(nblk), dim3(kThreads), 0, st,
+                       static_cast<const float*>(x), ldx, n, d, part);
+  else
+    hipLaunchKernelGGL((k_colsum_any<uint16_t>), dim3(nblk), dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(x), ldx, n, d, part);
+  SGF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_partials, dim3((d + 31) / 32), dim3(256), 0, st, part, nblk, d, out,
+                     static_cast<float*>(nullptr), d);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -260,6 +260,17 @@ class HipKernels:
                       d, _code(x), _ptr(dx), _ld(dx), _stream(dev))
         return dx
 
+    @staticmethod
+    def colsum(x) -> torch.Tensor:
+        n, d = x.shape
+        dev = x.device
+        out = torch.empty(d, dtype=_F32, device=dev)
+        ws = _workspace(dev, "colsum", _lib.load().sgf_colsum_workspace_bytes(n, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_colsum", _ptr(x), _ld(x), n, d, _code(x), _ptr(out), _ptr(ws), ws.numel(),
+                      _stream(dev))
+        return out
+
     # ---- T7 ----
     @staticmethod
     def axpby(x1, a: float, x2, b: float) -> torch.Tensor:
@@ -559,3 +570,32 @@ class _Axpby(torch.autograd.Function):
 
 def axpby(x1, x2, a, b):
     return _Axpby.apply(x1, x2, a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# output layer  x W^T + b  (large/ours.py:275).  The GEMMs stay on hipBLASLt; only the bias
+# gradient is ours: ATen's column reduction of a [N, C] tensor with C = 47 took 18.6 ms per step at
+# ogbn-products scale (profiles/r01_products_f32_kernel_stats.md), k_colsum_any takes < 0.5 ms.
+# ------------------------------------------------------------------------------------------------
+class _OutLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K.check(x)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ w if ctx.needs_input_grad[0] else None
+        dw = g.t() @ x if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = K.colsum(g).to(w.dtype) if g.shape[1] <= 256 else g.sum(0)
+        return dx, dw, db
+
+
+def out_linear(x, w, b):
+    return _OutLinear.apply(x, w, b)

@@ -34,6 +34,16 @@ __all__ = ["GraphConvLayer", "GraphConv", "TransConvLayer", "TransConv", "SGForm
 _NO_SHARD = None
 
 
+def _lin(x, lin: nn.Linear):
+    """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
+    with bf16 activations (`SGFormer.compute_dtype`); a no-op cast otherwise.  hipBLASLt GEMM."""
+    w = lin.weight if lin.weight.dtype == x.dtype else lin.weight.to(x.dtype)
+    b = lin.bias
+    if b is not None and b.dtype != x.dtype:
+        b = b.to(x.dtype)
+    return F.linear(x, w, b)
+
+
 def _drop(x, p, training):
     if training and p is not None and p > 0.0:
         return F.dropout(x, p=p, training=True)
@@ -47,11 +57,14 @@ def _drop(x, p, training):
 def full_attention_conv(qs, ks, vs, output_attn=False, shard=None):
     """medium/ours.py:14-46 / 100M/ours.py:12-53 as a free function: qs, ks [N,H,M], vs [N,H|1,D].
 
-    Returns the per-head-MEAN-free tensor the reference returns ([N,H,D]) when H == 1, and in
-    general the head mean expanded back is not recoverable, so for H > 1 this returns [N,1,D] * 1
-    only through `TransConvLayer`; direct callers with H > 1 get the head-mean [N, D].
+    Returns [N, H, D] like the reference for H == 1 (every recipe).  The kernels produce the head
+    MEAN (what every caller in the reference takes next, medium/ours.py:98); per-head outputs for
+    H > 1 are not exposed through this free function — use `TransConvLayer`.
     """
     n, h, d = qs.shape
+    if h != 1:
+        raise NotImplementedError("full_attention_conv: per-head outputs for H > 1 are not exposed; "
+                                  "call TransConvLayer (which returns the head mean, as the reference does)")
     qk = torch.cat([qs.reshape(n, h * d), ks.reshape(n, h * d)], dim=1)
     if vs.shape[1] == h:
         qkv = torch.cat([qk, vs.reshape(n, h * d)], dim=1)
@@ -97,11 +110,11 @@ class GraphConvLayer(nn.Module):
         y = ops.spmm(graph, x, shard)
         if self.use_init:
             d = y.shape[1]
-            w = self.W.weight
+            w, b = self.W.weight.to(y.dtype), self.W.bias.to(y.dtype)
             # W [y | x0] + b without materialising the concatenation
-            y = torch.addmm(torch.addmm(self.W.bias, y, w[:, :d].t()), x0, w[:, d:].t())
+            y = torch.addmm(torch.addmm(b, y, w[:, :d].t()), x0, w[:, d:].t())
         elif self.use_weight:
-            y = self.W(y)
+            y = _lin(y, self.W)
         return y
 
 
@@ -173,7 +186,7 @@ class GraphConv(nn.Module):
 
     def forward(self, x, edge_index):
         ops._require_cuda(x, edge_index)
-        x = self.fcs[0](x)
+        x = _lin(x, self.fcs[0])
         x = self._stage(self.bns[0], x, None, True)
         x0 = x
         for i, conv in enumerate(self.convs):
@@ -206,10 +219,11 @@ class TransConvLayer(nn.Module):
         """[Q | K (| V)] in ONE buffer: a single [d -> 2Hd or 3Hd] GEMM when query is source."""
         ws = [self.Wq.weight, self.Wk.weight] + ([self.Wv.weight] if self.use_weight else [])
         bs = [self.Wq.bias, self.Wk.bias] + ([self.Wv.bias] if self.use_weight else [])
+        dt = query_input.dtype
         if query_input is source_input:
-            return F.linear(query_input, torch.cat(ws, 0), torch.cat(bs, 0))
-        q = F.linear(query_input, ws[0], bs[0])
-        kv = F.linear(source_input, torch.cat(ws[1:], 0), torch.cat(bs[1:], 0))
+            return F.linear(query_input, torch.cat(ws, 0).to(dt), torch.cat(bs, 0).to(dt))
+        q = F.linear(query_input, ws[0].to(dt), bs[0].to(dt))
+        kv = F.linear(source_input, torch.cat(ws[1:], 0).to(dt), torch.cat(bs[1:], 0).to(dt))
         return torch.cat([q, kv], 1)
 
     def forward(self, query_input, source_input, output_attn=False):
@@ -272,7 +286,7 @@ class TransConv(nn.Module):
         return ops.ln_res_act(x, res, a, b, gamma, beta, relu, ln.eps)
 
     def _embed(self, x, training):
-        x = self.fcs[0](x)
+        x = _lin(x, self.fcs[0])
         x = self._ln(self.bns[0], x, None, 1.0, 0.0, True)
         return _drop(x, self.dropout, training)
 
@@ -315,8 +329,12 @@ class SGFormer(nn.Module):
                  trans_use_residual=True, trans_use_weight=True, trans_use_act=True,
                  gnn_num_layers=1, gnn_dropout=0.5, gnn_use_weight=True, gnn_use_init=False,
                  gnn_use_bn=True, gnn_use_residual=True, gnn_use_act=True,
-                 use_graph=True, graph_weight=0.8, aggregate='add', alpha=None):
+                 use_graph=True, graph_weight=0.8, aggregate='add', alpha=None, compute_dtype=None):
         super().__init__()
+        # None: activations in the dtype of the input / parameters (fp32 = the reference's numerics).
+        # torch.bfloat16: bf16 activation storage, fp32 master weights and fp32 accumulation in every
+        # kernel and GEMM (BASELINE.json config 3); logits are returned in fp32 either way.
+        self.compute_dtype = compute_dtype
         self.trans_conv = TransConv(in_channels, hidden_channels, trans_num_layers, trans_num_heads,
                                     trans_dropout, trans_use_bn, trans_use_residual,
                                     trans_use_weight, trans_use_act, alpha=alpha)
@@ -338,6 +356,9 @@ class SGFormer(nn.Module):
 
     def forward(self, x, edge_index):
         ops._require_cuda(x, edge_index)
+        out_dtype = x.dtype
+        if self.compute_dtype is not None and x.dtype != self.compute_dtype:
+            x = x.to(self.compute_dtype)
         x1 = self.trans_conv(x)
         if self.use_graph:
             x2 = self.graph_conv(x, edge_index)
@@ -348,7 +369,8 @@ class SGFormer(nn.Module):
                 x = torch.cat((x1, x2), dim=1)
         else:
             x = x1
-        return self.fc(x)
+        w, b = self.fc.weight.to(x.dtype), self.fc.bias.to(x.dtype)
+        return ops.out_linear(x, w, b).to(out_dtype)
 
     def get_attentions(self, x):
         return self.trans_conv.get_attentions(x)

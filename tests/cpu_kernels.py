@@ -168,6 +168,10 @@ class CpuKernels:
             dz = dz - stats[:d] * inv_n - xh * stats[d:] * inv_n
         return ((gamma if gamma is not None else 1.0) * rstd * dz).to(x.dtype)
 
+    @staticmethod
+    def colsum(x):
+        return x.float().sum(0)
+
     # ---- T7 ----
     @staticmethod
     def axpby(x1, a, x2, b):

@@ -282,3 +282,13 @@ def test_cpu_tensor_is_rejected():
     from sgformer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.attention(torch.zeros(4, 192), None, 1, 64)
+
+
+@pytest.mark.parametrize("d", [1, 7, 47, 172, 256])
+def test_colsum_any_width(cuda, d):
+    from sgformer_amd import ops
+    torch.manual_seed(d)
+    x = torch.randn(5003, d)
+    got = ops.K.colsum(x.to(cuda))
+    assert _rel(got, x.double().sum(0)) <= 1e-6
+    assert float(ops.K.colsum(torch.zeros(0, d, device=cuda)).abs().max()) == 0.0

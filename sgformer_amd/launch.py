@@ -1,0 +1,80 @@
+"""Run one of the reference's trainers UNCHANGED on top of this package.
+
+    python -m sgformer_amd.launch /path/to/SGFormer/large/main.py --dataset ogbn-arxiv --method sgformer ...
+    python -m sgformer_amd.launch /path/to/SGFormer/large/main-batch.py ...
+    python -m sgformer_amd.launch /path/to/SGFormer/100M/nb-sample.py ...
+
+Why a launcher: the reference has no plugin interface; its model is whatever the name `ours`
+resolves to (`from ours import *`, large/parse.py:2, 100M/parse.py:1).  CPython puts the trainer's
+own directory first on sys.path, so PYTHONPATH cannot displace large/ours.py — but `import` looks
+in sys.modules before sys.path.  This launcher registers the drop-in module as sys.modules['ours']
+and then executes the trainer file byte-for-byte with runpy.
+
+The variant (which constructor signature the trainer's parse.py expects) is taken from the
+trainer's directory name — `large` -> sgformer_amd.ours, `100M` -> sgformer_amd.ours_100m — or
+from --sgf-variant.  `--sgf-dtype bf16` switches every SGFormer the trainer builds to bf16
+activation storage (fp32 master weights / accumulation); the default is the reference's fp32.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import runpy
+import sys
+
+VARIANTS = {"large": "sgformer_amd.ours", "100M": "sgformer_amd.ours_100m",
+            "100m": "sgformer_amd.ours_100m"}
+
+
+def install(variant: str = "large", dtype: str | None = None):
+    """Register the drop-in as sys.modules['ours']; returns the module."""
+    if variant not in VARIANTS:
+        raise SystemExit(f"sgformer_amd.launch: unknown variant {variant!r} (choose from {sorted(set(VARIANTS))})")
+    mod = importlib.import_module(VARIANTS[variant])
+    if dtype in ("bf16", "bfloat16"):
+        import torch
+        importlib.import_module("sgformer_amd.ours").DEFAULT_COMPUTE_DTYPE = torch.bfloat16
+    elif dtype not in (None, "f32", "fp32", "float32"):
+        raise SystemExit(f"sgformer_amd.launch: unknown --sgf-dtype {dtype!r}")
+    sys.modules["ours"] = mod
+    return mod
+
+
+def _pop_option(argv, name):
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            v = argv[i + 1]
+            del argv[i:i + 2]
+            return v
+        if a.startswith(name + "="):
+            del argv[i]
+            return a.split("=", 1)[1]
+    return None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    variant = _pop_option(argv, "--sgf-variant")
+    dtype = _pop_option(argv, "--sgf-dtype")
+    if not argv or argv[0] in ("-h", "--help"):
+        raise SystemExit(__doc__)
+    trainer = os.path.abspath(argv[0])
+    if not os.path.isfile(trainer):
+        raise SystemExit(f"sgformer_amd.launch: trainer script not found: {trainer}")
+    tdir = os.path.dirname(trainer)
+    if variant is None:
+        variant = os.path.basename(tdir)
+        if variant not in VARIANTS:
+            raise SystemExit(f"sgformer_amd.launch: cannot infer the variant from directory {variant!r}; "
+                             f"pass --sgf-variant large|100M")
+    install(variant, dtype)
+    # what `python trainer.py args...` would have set up
+    sys.argv = [trainer] + argv[1:]
+    if tdir in sys.path:
+        sys.path.remove(tdir)
+    sys.path.insert(0, tdir)
+    runpy.run_path(trainer, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

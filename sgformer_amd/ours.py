@@ -33,6 +33,11 @@ __all__ = ["GraphConvLayer", "GraphConv", "TransConvLayer", "TransConv", "SGForm
 # Set by sgformer_amd.dist.shard_model(); None = single GPU.
 _NO_SHARD = None
 
+# Activation dtype of SGFormer instances built without an explicit `compute_dtype`.  None = the
+# dtype of the input (the reference's fp32 numerics); sgformer_amd.launch --sgf-dtype bf16 sets
+# torch.bfloat16 so that an unchanged trainer gets the bf16 mode of BASELINE.json config 3.
+DEFAULT_COMPUTE_DTYPE = None
+
 
 def _lin(x, lin: nn.Linear):
     """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
@@ -250,16 +255,18 @@ class TransConv(nn.Module):
     variant's (x + res)/2; a float is the 100M / medium variant's alpha*x + (1-alpha)*res."""
 
     def __init__(self, in_channels, hidden_channels, num_layers=2, num_heads=1, dropout=0.5,
-                 use_bn=True, use_residual=True, use_weight=True, use_act=True, alpha=None):
+                 use_bn=True, use_residual=True, use_weight=True, use_act=True, alpha=None,
+                 layer_cls=None):
         super().__init__()
+        layer_cls = layer_cls or TransConvLayer
         self.convs = nn.ModuleList()
         self.fcs = nn.ModuleList()
         self.fcs.append(nn.Linear(in_channels, hidden_channels))
         self.bns = nn.ModuleList()
         self.bns.append(nn.LayerNorm(hidden_channels))
         for _ in range(num_layers):
-            self.convs.append(TransConvLayer(hidden_channels, hidden_channels, num_heads=num_heads,
-                                             use_weight=use_weight))
+            self.convs.append(layer_cls(hidden_channels, hidden_channels, num_heads=num_heads,
+                                        use_weight=use_weight))
             self.bns.append(nn.LayerNorm(hidden_channels))
         self.dropout = dropout
         self.activation = F.relu
@@ -329,15 +336,17 @@ class SGFormer(nn.Module):
                  trans_use_residual=True, trans_use_weight=True, trans_use_act=True,
                  gnn_num_layers=1, gnn_dropout=0.5, gnn_use_weight=True, gnn_use_init=False,
                  gnn_use_bn=True, gnn_use_residual=True, gnn_use_act=True,
-                 use_graph=True, graph_weight=0.8, aggregate='add', alpha=None, compute_dtype=None):
+                 use_graph=True, graph_weight=0.8, aggregate='add', alpha=None, compute_dtype='default',
+                 trans_cls=None):
         super().__init__()
         # None: activations in the dtype of the input / parameters (fp32 = the reference's numerics).
         # torch.bfloat16: bf16 activation storage, fp32 master weights and fp32 accumulation in every
         # kernel and GEMM (BASELINE.json config 3); logits are returned in fp32 either way.
-        self.compute_dtype = compute_dtype
-        self.trans_conv = TransConv(in_channels, hidden_channels, trans_num_layers, trans_num_heads,
-                                    trans_dropout, trans_use_bn, trans_use_residual,
-                                    trans_use_weight, trans_use_act, alpha=alpha)
+        self.compute_dtype = DEFAULT_COMPUTE_DTYPE if isinstance(compute_dtype, str) else compute_dtype
+        self.trans_conv = (trans_cls or TransConv)(
+            in_channels, hidden_channels, num_layers=trans_num_layers, num_heads=trans_num_heads,
+            dropout=trans_dropout, use_bn=trans_use_bn, use_residual=trans_use_residual,
+            use_weight=trans_use_weight, use_act=trans_use_act, alpha=alpha)
         self.graph_conv = GraphConv(in_channels, hidden_channels, gnn_num_layers, gnn_dropout,
                                     gnn_use_bn, gnn_use_residual, gnn_use_weight, gnn_use_init,
                                     gnn_use_act)
@@ -354,7 +363,27 @@ class SGFormer(nn.Module):
         self.params2 = list(self.graph_conv.parameters()) if self.graph_conv is not None else []
         self.params2.extend(list(self.fc.parameters()))
 
+    def _forward_on_gpu_from_host(self, x, edge_index):
+        """Host tensors + host parameters, no autograd: the reference's CPU evaluation
+        (`evaluate_large`, large/eval.py:36-65, moves the model and the whole graph to the CPU and
+        large/main-batch.py:157 calls it every eval_step).  There is no CPU implementation here, so
+        the same HIP path is run on copies staged to the current GPU and the logits are returned
+        on the host — the trainer stays unchanged and nothing is computed on the CPU."""
+        if torch.is_grad_enabled():
+            raise RuntimeError("sgformer_amd: CPU tensors with autograd enabled — training runs on "
+                               "MI355X only; move the model and inputs to the GPU")
+        if not torch.cuda.is_available():
+            ops._require_cuda(x)  # raises the standard no-CPU-path error
+        dev = torch.device("cuda", torch.cuda.current_device())
+        state = {k: v.to(dev) for k, v in list(self.named_parameters()) + list(self.named_buffers())}
+        out = torch.func.functional_call(self, state, (x.to(dev), edge_index.to(dev)))
+        for k, v in self.named_buffers():  # train-mode BatchNorm under no_grad still tracks stats
+            v.copy_(state[k])
+        return out.to(x.device)
+
     def forward(self, x, edge_index):
+        if not x.is_cuda and ops.K.name == "hip" and not next(self.parameters()).is_cuda:
+            return self._forward_on_gpu_from_host(x, edge_index)
         ops._require_cuda(x, edge_index)
         out_dtype = x.dtype
         if self.compute_dtype is not None and x.dtype != self.compute_dtype:

@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ogbn-products", choices=sorted(synth.SHAPES))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="activation storage (BASELINE.json config 3 is bf16; f32 = the reference numerics)")
     ap.add_argument("--nodes", type=int, default=0, help="override N (debug only; marks the line)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

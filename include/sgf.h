@@ -146,6 +146,24 @@ int sgf_attn_bwd_apply(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        void* dv, int64_t lddv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for
+ * every nn.Linear on the path under loss.backward() (large/main.py:142): the projections
+ * large/ours.py:123-126, the GraphConvLayer weight :36-40, the stems :77,:198 and the head :275:
+ *     dW = dY^T X   ([N, m]^T [N, k] -> [m, k]),    db = sum_n dY[n, :]
+ * i.e. a d x d <- [N x d]^T [N x d] contraction over ALL nodes: the same streaming skeleton as
+ * sgf_attn_fwd_reduce (K^T V), on the bf16 matrix cores for SGF_BF16 and the exact-fp32 MFMA for
+ * SGF_F32, fp32 accumulation, deterministic two-stage reduction.  hipBLASLt's kernels for this
+ * shape ran at 0.7 TB/s (3.6 ms per call at ogbn-products scale, profiles/); this one is HBM-bound.
+ *     c[i, j] = sum_n a[n, i] * b[n, j]       c: fp32 [m, k] row-major, leading dim ldc
+ *     colsum_a[i] = sum_n a[n, i]             fp32 [m], optional (NULL to skip)
+ * m, k multiples of 4 (any size: tiled in 256 x 256 blocks).  Node-sharded runs all-reduce c.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_gram_workspace_bytes(int64_t n, int32_t m, int32_t k);
+int sgf_gram(const void* a, int64_t lda, int32_t m, const void* b, int64_t ldb, int32_t k,
+             int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum_a, void* workspace,
+             size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * T5 — TransConv glue.   Replaces large/ours.py:198-202 and :210-216 (medium/ours.py:150-156,
  * 100M/ours.py:262-268):   y = [relu]( LayerNorm( a * x + b * res ) )   row-wise
  * (large: a = b = 1/2; medium / 100M: a = alpha, b = 1 - alpha; input stem: a = 1, res = NULL).

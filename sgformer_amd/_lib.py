@@ -38,6 +38,9 @@ SIGNATURES = {
     "sgf_attn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                                      _P, c_int64, c_double, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                      _P, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "sgf_gram_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "sgf_gram": (c_int32, [_P, c_int64, c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P,
+                           _P, c_size_t, _P]),
     "sgf_ln_fwd": (c_int32, [_P, c_int64, _P, c_int64, c_float, c_float, _P, _P, c_int32, c_float,
                              c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     "sgf_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),

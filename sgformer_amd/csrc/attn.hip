@@ -44,6 +44,7 @@ constexpr int kMaxBlocks = kNumCU;                 // persistent: one block per 
 
 constexpr int kModeFwd = 0;  // reduce: A=K, B=V          apply: out
 constexpr int kModeBwd = 1;  // reduce: A=Q, B=dnum
+constexpr int kModeGram = 2; // reduce: C = A^T B plus column sums of A (sgf_gram); no third stream
 constexpr int kApplyFwd = 0, kApplyDQ = 1, kApplyDK = 2, kApplyDV = 3;
 
 static inline int padded_dim(int d) { return d <= 64 ? 64 : (d <= 128 ? 128 : 256); }
@@ -56,6 +57,7 @@ struct ReduceArgs {
   int64_t lda, ldb, ldq;
   int64_t n;
   int32_t d, heads, b_heads;  // b_heads: 1 -> operand b is shared across heads (use_weight=False)
+  int32_t db;                 // valid columns of operand b (= d except for sgf_gram)
   float gscale;               // bwd: 1/H
   float* partial;             // [gridDim.x * heads][kPartialStride]
 };
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
   const int srow = tid / F4;
   const int col = (tid % F4) * 4;
   const bool col_ok = col < p.d;
+  const bool colb_ok = col < p.db;
 
   const T* pa = static_cast<const T*>(p.a) + static_cast<int64_t>(head) * p.d + col;
   const T* pb = static_cast<const T*>(p.b) + (p.b_heads == 1 ? 0 : static_cast<int64_t>(head) * p.d) + col;
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
     const int64_t row = tile * R + srow;
     const bool ok = col_ok && row < p.n;
     ra = ok ? load4<T>(pa + row * p.lda) : zero4();
-    rb = ok ? load4<T>(pb + row * p.ldb) : zero4();
-    rq = ok ? load4<T>(pq + row * p.ldq) : zero4();
+    rb = (colb_ok && row < p.n) ? load4<T>(pb + row * p.ldb) : zero4();
+    if (MODE != kModeGram) rq = ok ? load4<T>(pq + row * p.ldq) : zero4();
     if (MODE == kModeBwd) rden = (row < p.n) ? p.den[row * p.heads + head] : 1.f;
   };
   auto commit = [&](int buf) {
@@ -126,6 +129,8 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
       colsum.x += ra.x; colsum.y += ra.y; colsum.z += ra.z; colsum.w += ra.w;
       ssq_a += dot4(ra, ra);
       ssq_q += dot4(rq, rq);
+    } else if (MODE == kModeGram) {
+      colsum.x += ra.x; colsum.y += ra.y; colsum.z += ra.z; colsum.w += ra.w;
     } else {
       // rb = g, rq = o:  dnum = (g/H)/den ; dden = -((g/H).o)/den
       const float gdo = group_sum<F4>(dot4(rb, rq));
@@ -241,6 +246,30 @@ __global__ void k_attn_finalize(const float* __restrict__ partial, int nblk, int
     } else if (which == 0) {
       out[idx] = 0.f;
     }
+  }
+}
+
+// sgf_gram: C[mb x kb] block (row stride ldc) and column sums of A from the per-block partials,
+// summed in a fixed order.
+__global__ void k_gram_finalize(const float* __restrict__ partial, int nblk, int mb, int kb, int DP,
+                                int RG, float* __restrict__ c, int64_t ldc,
+                                float* __restrict__ colsum) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t nmat = static_cast<int64_t>(mb) * kb;
+  if (idx < nmat) {
+    const int m = static_cast<int>(idx / kb);
+    const int dd = static_cast<int>(idx % kb);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      const float* part = partial + static_cast<int64_t>(b) * kPartialStride;
+      for (int g = 0; g < RG; ++g) s += part[(g * DP + m) * DP + dd];
+    }
+    c[static_cast<int64_t>(m) * ldc + dd] = s;
+  } else if (idx < nmat + mb && colsum != nullptr) {
+    const int j = static_cast<int>(idx - nmat);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * kPartialStride + kTileElems + j];
+    colsum[j] = s;
   }
 }
 
@@ -476,17 +505,448 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 storage: the same two skeletons on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16,
+// 16x the rate of the exact-fp32 MFMA), fp32 accumulation.  A product of two bf16 values is exact
+// in fp32, so against the fp32-MFMA kernels above only the summation order differs.
+//
+//   A operand: lane l holds A[i = l & 31][k = 8 (l >> 5) + 0..7]   (8 bf16 = 4 VGPRs)
+//   B operand: lane l holds B[k = 8 (l >> 5) + 0..7][j = l & 31]
+//
+// k_reduce_bf16 contracts over ROWS (C = A^T B), so both operands need 8 consecutive rows of one
+// column per lane.  Tiles are therefore staged TRANSPOSED in LDS, T[col][row]: a thread loads a
+// 4-row x 4-column patch (four 8-byte coalesced loads per stream), transposes it in registers and
+// writes four 8-byte column segments; an MFMA fragment is then one ds_read_b128.  The 16-byte
+// chunk index is XOR-swizzled with (col >> 1) & 7, which makes the fragment reads conflict-free
+// (bank = (addr/4) % 64 for b128: the 16 lanes of a service group hit 16 distinct 16-byte slots).
+// Any permutation of the rows inside a tile is harmless as long as A and B share it.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
+}
+
+constexpr int kBfThreads = 512;  // 8 waves = 2 per SIMD: a 256-VGPR budget per wave
+
+template <int DP, int MODE>
+__global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
+  constexpr int LPQ = DP / 4;             // lanes per patch row (64 / 32 / 16)
+  constexpr int QPW = 64 / LPQ;           // 4-row patches per wave per pass
+  constexpr int NPASS = 2;                // staging passes per tile
+  constexpr int R = 8 * QPW * 4 * NPASS;  // rows per tile (64 / 128 / 256)
+  constexpr int BN = DP >= 256 ? 128 : 64;  // a wave owns a 64 x BN block of the DP x DP result
+  constexpr int TN = BN / 32;
+  constexpr int NBM = DP / 64, NBN = DP / BN;
+  constexpr int RG = 8 / (NBM * NBN);     // row groups (1 / 4 / 8)
+  constexpr int KSTEPS = R / 16;          // MFMA k-steps (16 rows) per tile
+  constexpr int SPG = KSTEPS / RG;        // k-steps per row group per tile
+  constexpr int CSB = R * 2;              // bytes per LDS column
+  constexpr int OPB = DP * CSB;           // bytes per operand tile (32 KiB)
+  static_assert(SPG >= 1 && KSTEPS % RG == 0, "tile / row-group mismatch");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * OPB];  // [buf][A|B] = 128 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int head = blockIdx.y;
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  const int blk = wave % (NBM * NBN);
+  const int grp = wave / (NBM * NBN);
+  const int wm = blk / NBN;
+  const int wd = blk % NBN;
+
+  // staging map: in pass t this thread owns rows 4q..4q+3 (q = q0 + t * 8 * QPW), columns c0..c0+3
+  const int q0 = wave * QPW + lane / LPQ;
+  const int c0 = (lane % LPQ) * 4;
+  const bool a_ok = c0 < p.d;
+  const bool b_ok = c0 < p.db;
+
+  const uint16_t* pa = static_cast<const uint16_t*>(p.a) + static_cast<int64_t>(head) * p.d + c0;
+  const uint16_t* pb = static_cast<const uint16_t*>(p.b) +
+                       (p.b_heads == 1 ? 0 : static_cast<int64_t>(head) * p.d) + c0;
+  const uint16_t* pq = static_cast<const uint16_t*>(p.q) + static_cast<int64_t>(head) * p.d + c0;
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 colsum = zero4();
+  float ssq_a = 0.f, ssq_q = 0.f;
+
+  const int64_t ntiles = (p.n + R - 1) / R;
+  // Only ONE staging pass is in flight at a time (24 VGPRs of loads): a tile iteration is NPASS
+  // half-steps, each = issue the loads of pass t of the next tile, run the MFMAs of half of the
+  // current tile's k-steps, then transpose / commit pass t into the other LDS buffer.
+  uint2 ra[4], rb[4], rq[4];
+  float rden[4];
+
+  auto issue = [&](int64_t tile, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = tile * R + 4 * (q0 + t * 8 * QPW) + i;
+      const bool rok = row < p.n;
+      ra[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pa + row * p.lda) : make_uint2(0u, 0u);
+      rb[i] = (rok && b_ok) ? *reinterpret_cast<const uint2*>(pb + row * p.ldb) : make_uint2(0u, 0u);
+      if (MODE != kModeGram)
+        rq[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pq + row * p.ldq) : make_uint2(0u, 0u);
+      if (MODE == kModeBwd) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
+    }
+  };
+  // column j of a 4x4 patch as 8 bytes: rows 0..3
+  auto column = [](const uint2 (&r)[4], int j) -> uint2 {
+    uint32_t x0, x1, x2, x3;
+    if (j < 2) { x0 = r[0].x; x1 = r[1].x; x2 = r[2].x; x3 = r[3].x; }
+    else       { x0 = r[0].y; x1 = r[1].y; x2 = r[2].y; x3 = r[3].y; }
+    if (j & 1) return make_uint2((x0 >> 16) | (x1 & 0xffff0000u), (x2 >> 16) | (x3 & 0xffff0000u));
+    return make_uint2((x0 & 0xffffu) | (x1 << 16), (x2 & 0xffffu) | (x3 << 16));
+  };
+  auto commit = [&](int buf, int t) {
+    unsigned char* ta = lds + buf * 2 * OPB;
+    unsigned char* tb = ta + OPB;
+    if (MODE == kModeFwd) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint2 a = ra[i], qq = rq[i];
+        const float a0 = bf_lo(a.x), a1 = bf_hi(a.x), a2 = bf_lo(a.y), a3 = bf_hi(a.y);
+        const float q0f = bf_lo(qq.x), q1 = bf_hi(qq.x), q2 = bf_lo(qq.y), q3 = bf_hi(qq.y);
+        colsum.x += a0; colsum.y += a1; colsum.z += a2; colsum.w += a3;
+        ssq_a += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        ssq_q += q0f * q0f + q1 * q1 + q2 * q2 + q3 * q3;
+      }
+    } else if (MODE == kModeGram) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
+        colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
+      }
+    } else {
+      // rb = g, rq = o: dnum = (g/H)/den (re-rounded to bf16 for the MFMA); dden = -((g/H).o)/den
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint2 g = rb[i], o = rq[i];
+        const float g0 = bf_lo(g.x), g1 = bf_hi(g.x), g2 = bf_lo(g.y), g3 = bf_hi(g.y);
+        const float gdo = group_sum<LPQ>(g0 * bf_lo(o.x) + g1 * bf_hi(o.x) + g2 * bf_lo(o.y) +
+                                         g3 * bf_hi(o.y));
+        const float inv = p.gscale / rden[i];
+        const float dden = -gdo * inv;
+        rb[i] = make_uint2(pack_bf16(g0 * inv, g1 * inv), pack_bf16(g2 * inv, g3 * inv));
+        colsum.x += bf_lo(ra[i].x) * dden; colsum.y += bf_hi(ra[i].x) * dden;
+        colsum.z += bf_lo(ra[i].y) * dden; colsum.w += bf_hi(ra[i].y) * dden;
+      }
+    }
+    const int q = q0 + t * 8 * QPW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c0 + j;
+      const int off = col * CSB + (((q >> 1) ^ ((col >> 1) & 7)) << 4) + ((q & 1) << 3);
+      *reinterpret_cast<uint2*>(ta + off) = column(ra, j);
+      *reinterpret_cast<uint2*>(tb + off) = column(rb, j);
+    }
+  };
+
+  static_assert(SPG % NPASS == 0, "k-steps must split evenly over the staging passes");
+  int64_t tile = blockIdx.x;
+  int buf = 0;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int t = 0; t < NPASS; ++t) {
+      issue(tile, t);
+      commit(0, t);
+    }
+  }
+  __syncthreads();
+  const int ca0 = 64 * wm + i31, ca1 = ca0 + 32;
+  const int cb0 = BN * wd + i31;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    const unsigned char* ta = lds + buf * 2 * OPB;
+    const unsigned char* tb = ta + OPB;
+#pragma unroll
+    for (int t = 0; t < NPASS; ++t) {
+      if (has_next) issue(next, t);
+#pragma unroll 1
+      for (int s = t * (SPG / NPASS); s < (t + 1) * (SPG / NPASS); ++s) {
+        const int chunk = 2 * (grp + RG * s) + hi;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ta + ca0 * CSB + ((chunk ^ ((ca0 >> 1) & 7)) << 4));
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ta + ca1 * CSB + ((chunk ^ ((ca1 >> 1) & 7)) << 4));
+        bf16x8 bfr[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int cb = cb0 + 32 * tn;
+          bfr[tn] = *reinterpret_cast<const bf16x8*>(tb + cb * CSB + ((chunk ^ ((cb >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[tn], acc[0][tn], 0, 0, 0);
+          acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[tn], acc[1][tn], 0, 0, 0);
+        }
+      }
+      if (has_next) commit(buf ^ 1, t);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- this block's partial, same layout as k_attn_reduce: [grp][m][dd] | colsum[DP] | ssq ----
+  float* part = p.partial + (static_cast<int64_t>(head) * gridDim.x + blockIdx.x) * kPartialStride;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 64 * wm + 32 * tm + mfma32_row(r, lane);
+        const int dd = BN * wd + 32 * tn + i31;
+        part[(grp * DP + m) * DP + dd] = acc[tm][tn][r];
+      }
+  // column sums: threads with equal c0 differ in patch row -> reduce over the 8*QPW slots via LDS
+  __syncthreads();
+  float* fl = reinterpret_cast<float*>(lds);
+  constexpr int SLOTS = 8 * QPW;
+  *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsum;
+  const float wa = group_sum<64>(ssq_a);
+  const float wq = group_sum<64>(ssq_q);
+  if (lane == 0) {
+    fl[SLOTS * DP + wave] = wa;
+    fl[SLOTS * DP + 8 + wave] = wq;
+  }
+  __syncthreads();
+  if (tid < DP) {
+    float s = 0.f;
+    for (int r = 0; r < SLOTS; ++r) s += fl[r * DP + tid];
+    part[kTileElems + tid] = s;
+  }
+  if (tid == 0) {
+    float sa = 0.f, sq = 0.f;
+    for (int w = 0; w < 8; ++w) {
+      sa += fl[SLOTS * DP + w];
+      sq += fl[SLOTS * DP + 8 + w];
+    }
+    part[kTileElems + DP] = sa;
+    part[kTileElems + DP + 1] = sq;
+  }
+}
+
+// k_apply_bf16: out[n x d] = ar[n] (A[n x d] B[d x d]) + br[n] cvec + gr[n] E   on bf16 MFMA.
+// 8 waves = NS 32-column strips x RGW row groups; a wave keeps its [DP x 32] strip of B (rounded
+// to bf16) in DP/4 registers for the whole kernel and applies it to two 32-row sub-blocks per
+// tile.  A tiles are staged row-major (stride DP + 8 bf16: conflict-free ds_read_b128 fragments);
+// the accumulators go through an fp32 LDS tile so that E is loaded and `out` stored row-wise,
+// 8 bytes per lane, fully coalesced.
+template <int DP, int MODE>
+__global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
+  constexpr int NS = DP / 32;             // strips (8 / 4 / 2)
+  constexpr int RGW = 8 / NS;             // row groups of waves (1 / 2 / 4)
+  constexpr int RT = 64 * RGW;            // rows per tile (64 / 128 / 256)
+  constexpr int F4 = DP / 4;              // lanes per row in the staging / epilogue map
+  constexpr int RPP = kBfThreads / F4;    // rows per staging pass (8 / 16 / 32)
+  constexpr int NP = RT / RPP;            // staging passes (8)
+  constexpr int LDA = DP + 8;             // bf16 elements per LDS row of A
+  constexpr int LDC = DP + 4;             // floats per LDS row of C
+  constexpr int KS = DP / 16;             // k-steps
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RT * LDA * 2 + RT * LDC * 4 + 2 * 3 * RT * 4];
+  uint16_t* const ldsA = reinterpret_cast<uint16_t*>(smem);                       // [buf][RT][LDA]
+  float* const ldsC = reinterpret_cast<float*>(smem + 2 * RT * LDA * 2);          // [RT][LDC]
+  float* const ldsR = ldsC + RT * LDC;                                            // [buf][3][RT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  const int ws = wave % NS;
+  const int wr = wave / NS;
+  const int d = p.d;
+
+  const float ssq_q = p.stats[p.stats_len - 2];
+  const float ssq_k = p.stats[p.stats_len - 1];
+  const float c = 1.0f / (sqrtf(ssq_q) * sqrtf(ssq_k));
+  float gconst = 0.f;
+  if (MODE == kApplyDQ) gconst = -(c * p.sdot[0]) / ssq_q;
+  if (MODE == kApplyDK) gconst = -(c * p.sdot[0]) / ssq_k;
+
+  // resident strip of B: breg[s][t] = B[16 s + 8 hi + t][32 ws + i31]
+  bf16x8 breg[KS];
+  {
+    const int j = 32 * ws + i31;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = 16 * s + 8 * hi + t;
+        float v = 0.f;
+        if (k < d && j < d) v = p.trans_b ? p.bmat[static_cast<int64_t>(j) * d + k]
+                                           : p.bmat[static_cast<int64_t>(k) * d + j];
+        breg[s][t] = static_cast<short>(f32_to_bf16(v));
+      }
+  }
+
+  const int scol = (tid % F4) * 4;
+  const int srow0 = tid / F4;
+  const bool scol_ok = scol < d;
+  float4 zc = zero4();
+  if (MODE != kApplyDV && scol_ok) zc = *reinterpret_cast<const float4*>(p.cvec + scol);
+
+  const uint16_t* pa = static_cast<const uint16_t*>(p.a) + scol;
+  const uint16_t* pa2 = static_cast<const uint16_t*>(p.a2) + scol;
+  const uint16_t* pe = static_cast<const uint16_t*>(p.e) + scol;
+  uint16_t* po = static_cast<uint16_t*>(p.out) + scol;
+
+  uint2 ra[NP], ra2[NP];
+  float rden[NP];
+  const int64_t ntiles = (p.n + RT - 1) / RT;
+
+  auto issue = [&](int64_t tile) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t row = tile * RT + srow0 + i * RPP;
+      const bool ok = scol_ok && row < p.n;
+      ra[i] = ok ? *reinterpret_cast<const uint2*>(pa + row * p.lda) : make_uint2(0u, 0u);
+      if (MODE == kApplyDQ) ra2[i] = ok ? *reinterpret_cast<const uint2*>(pa2 + row * p.lda2) : make_uint2(0u, 0u);
+      if (MODE == kApplyDQ || MODE == kApplyDV) rden[i] = (row < p.n) ? p.den[row * p.heads] : 1.f;
+    }
+  };
+  auto commit = [&](int buf, int64_t tile) {
+    float* rs = ldsR + buf * 3 * RT;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int lrow = srow0 + i * RPP;
+      const int64_t row = tile * RT + lrow;
+      uint2 w = ra[i];
+      float ar = c, br = 0.f, gr = gconst;
+      if (MODE == kApplyFwd) {
+        const float qz = group_sum<F4>(bf_lo(w.x) * zc.x + bf_hi(w.x) * zc.y + bf_lo(w.y) * zc.z +
+                                       bf_hi(w.y) * zc.w);
+        const float den = c * qz + p.ntot;
+        ar = c / den;
+        gr = p.ntot / den;
+        if (scol == 0 && row < p.n) p.den[row * p.heads] = den;
+      } else if (MODE == kApplyDQ) {
+        const float g0 = bf_lo(w.x), g1 = bf_hi(w.x), g2 = bf_lo(w.y), g3 = bf_hi(w.y);
+        const float gdo = group_sum<F4>(g0 * bf_lo(ra2[i].x) + g1 * bf_hi(ra2[i].x) +
+                                        g2 * bf_lo(ra2[i].y) + g3 * bf_hi(ra2[i].y));
+        const float inv = p.gscale / rden[i];
+        w = make_uint2(pack_bf16(g0 * inv, g1 * inv), pack_bf16(g2 * inv, g3 * inv));
+        br = c * (-gdo * inv);
+      } else if (MODE == kApplyDK) {
+        br = c;
+      } else {
+        gr = p.ntot * p.gscale / rden[i];
+      }
+      *reinterpret_cast<uint2*>(&ldsA[(buf * RT + lrow) * LDA + scol]) = w;
+      if (scol == 0) {
+        rs[lrow] = ar;
+        rs[RT + lrow] = br;
+        rs[2 * RT + lrow] = gr;
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  int buf = 0;
+  if (tile < ntiles) {
+    issue(tile);
+    commit(0, tile);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    if (has_next) issue(next);
+    {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      const uint16_t* A0 = ldsA + (buf * RT + 64 * wr + i31) * LDA + 8 * hi;
+      const uint16_t* A1 = A0 + 32 * LDA;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(A0 + 16 * s);
+        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(A1 + 16 * s);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, breg[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, breg[s], acc1, 0, 0, 0);
+      }
+      float* C0 = ldsC + (64 * wr + 4 * hi) * LDC + 32 * ws + i31;
+      float* C1 = C0 + 32 * LDC;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        C0[((r & 3) + 8 * (r >> 2)) * LDC] = acc0[r];
+        C1[((r & 3) + 8 * (r >> 2)) * LDC] = acc1[r];
+      }
+    }
+    __syncthreads();
+    {
+      const float* rs = ldsR + buf * 3 * RT;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int lrow = srow0 + i * RPP;
+        const int64_t row = tile * RT + lrow;
+        if (scol_ok && row < p.n) {
+          const float4 e = load4<uint16_t>(pe + row * p.lde);
+          const float4 c0 = *reinterpret_cast<const float4*>(&ldsC[lrow * LDC + scol]);
+          const float ar = rs[lrow], gr = rs[2 * RT + lrow];
+          float4 v = make_float4(ar * c0.x + gr * e.x, ar * c0.y + gr * e.y, ar * c0.z + gr * e.z,
+                                 ar * c0.w + gr * e.w);
+          if (MODE == kApplyDQ || MODE == kApplyDK) {
+            const float br = rs[RT + lrow];
+            v.x += br * zc.x; v.y += br * zc.y; v.z += br * zc.z; v.w += br * zc.w;
+          }
+          if (p.accumulate) {
+            const float4 o = load4<uint16_t>(po + row * p.ldo);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          store4<uint16_t>(po + row * p.ldo, v);
+        }
+      }
+    }
+    if (has_next) commit(buf ^ 1, next);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-inline int reduce_rows_per_tile(int DP) { return kRedThreads / (DP / 4); }
+template <typename T>
+inline int reduce_rows_per_tile(int DP) {
+  // fp32 storage: k_attn_reduce, 1024 / (DP/4) rows;  bf16 storage: k_reduce_bf16, 16384 / DP rows
+  return sizeof(T) == 4 ? kRedThreads / (DP / 4) : 16384 / DP;
+}
+
+template <typename T>
+inline int reduce_row_groups(int DP) {
+  // row groups whose partial results the finalize kernels add up (must match the kernels' RG)
+  if (sizeof(T) == 4) return 16 / ((DP / 64) * (DP / 64));       // k_attn_reduce: 16 waves, 64x64 blocks
+  return DP >= 256 ? 1 : (DP == 128 ? 2 : 8);                    // k_reduce_bf16: 8 waves, 64xBN blocks
+}
 
 template <typename T, int MODE>
 int launch_reduce(const ReduceArgs& args, int DP, int nblk, hipStream_t st) {
-  const dim3 grid(nblk, args.heads), block(kRedThreads);
-  switch (DP) {
-    case 64: hipLaunchKernelGGL((k_attn_reduce<T, 64, MODE>), grid, block, 0, st, args); break;
-    case 128: hipLaunchKernelGGL((k_attn_reduce<T, 128, MODE>), grid, block, 0, st, args); break;
-    default: hipLaunchKernelGGL((k_attn_reduce<T, 256, MODE>), grid, block, 0, st, args); break;
+  const dim3 grid(nblk, args.heads), block(sizeof(T) == 2 ? kBfThreads : kRedThreads);
+  if (sizeof(T) == 2) {
+    switch (DP) {
+      case 64: hipLaunchKernelGGL((k_reduce_bf16<64, MODE>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_reduce_bf16<128, MODE>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_reduce_bf16<256, MODE>), grid, block, 0, st, args); break;
+    }
+  } else {
+    switch (DP) {
+      case 64: hipLaunchKernelGGL((k_attn_reduce<float, 64, MODE>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_attn_reduce<float, 128, MODE>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_attn_reduce<float, 256, MODE>), grid, block, 0, st, args); break;
+    }
   }
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -494,14 +954,23 @@ int launch_reduce(const ReduceArgs& args, int DP, int nblk, hipStream_t st) {
 
 template <typename T, int MODE>
 int launch_apply(const ApplyArgs& args, int DP, hipStream_t st) {
-  const int RT = 32 * (8 / (DP / 32));
+  // rows per tile: k_attn_apply 32 * (8 / (DP/32));  k_apply_bf16 64 * (8 / (DP/32))
+  const int RT = (sizeof(T) == 4 ? 32 : 64) * (8 / (DP / 32));
   int64_t ntiles = (args.n + RT - 1) / RT;
   const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
-  const dim3 grid(nblk), block(kApplyThreads);
-  switch (DP) {
-    case 64: hipLaunchKernelGGL((k_attn_apply<T, 64, MODE>), grid, block, 0, st, args); break;
-    case 128: hipLaunchKernelGGL((k_attn_apply<T, 128, MODE>), grid, block, 0, st, args); break;
-    default: hipLaunchKernelGGL((k_attn_apply<T, 256, MODE>), grid, block, 0, st, args); break;
+  const dim3 grid(nblk), block(sizeof(T) == 2 ? kBfThreads : kApplyThreads);
+  if (sizeof(T) == 2) {
+    switch (DP) {
+      case 64: hipLaunchKernelGGL((k_apply_bf16<64, MODE>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_apply_bf16<128, MODE>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_apply_bf16<256, MODE>), grid, block, 0, st, args); break;
+    }
+  } else {
+    switch (DP) {
+      case 64: hipLaunchKernelGGL((k_attn_apply<float, 64, MODE>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_attn_apply<float, 128, MODE>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_attn_apply<float, 256, MODE>), grid, block, 0, st, args); break;
+    }
   }
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -527,6 +996,68 @@ bool aligned4(const void* p, int64_t ld) {
 
 using namespace sgf;
 
+namespace {
+template <typename T>
+int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k, int64_t n, float* c,
+           int64_t ldc, float* colsum_a, void* ws, hipStream_t st) {
+  SGF_REQUIRE(aligned4<T>(a, lda) && aligned4<T>(b, ldb), SGF_E_INVALID,
+              "sgf_gram: a / b must be 4-element aligned with ld %% 4 == 0");
+  for (int mi = 0; mi < m; mi += 256) {
+    const int mb = m - mi < 256 ? m - mi : 256;
+    for (int ki = 0; ki < k; ki += 256) {
+      const int kb = k - ki < 256 ? k - ki : 256;
+      const int DP = padded_dim(mb > kb ? mb : kb);
+      const int R = reduce_rows_per_tile<T>(DP);
+      const int64_t ntiles = (n + R - 1) / R;
+      const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+      ReduceArgs r{};
+      r.a = static_cast<const T*>(a) + mi; r.lda = lda;
+      r.b = static_cast<const T*>(b) + ki; r.ldb = ldb;
+      r.q = nullptr; r.ldq = 0; r.den = nullptr;
+      r.n = n; r.d = mb; r.db = kb; r.heads = 1; r.b_heads = 1; r.gscale = 1.f;
+      r.partial = static_cast<float*>(ws);
+      int rc = launch_reduce<T, kModeGram>(r, DP, nblk, st);
+      if (rc != SGF_OK) return rc;
+      const int RG = reduce_row_groups<T>(DP);
+      const int64_t len = static_cast<int64_t>(mb) * kb + mb;
+      float* cs = (colsum_a != nullptr && ki == 0) ? colsum_a + mi : nullptr;
+      hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0,
+                         st, r.partial, nblk, mb, kb, DP, RG, c + static_cast<int64_t>(mi) * ldc + ki,
+                         ldc, cs);
+      SGF_LAUNCH_CHECK();
+    }
+  }
+  return SGF_OK;
+}
+}  // namespace
+
+extern "C" size_t sgf_gram_workspace_bytes(int64_t n, int32_t m, int32_t k) {
+  (void)n; (void)m; (void)k;
+  return static_cast<size_t>(kMaxBlocks) * kPartialStride * sizeof(float);
+}
+
+extern "C" int sgf_gram(const void* a, int64_t lda, int32_t m, const void* b, int64_t ldb, int32_t k,
+                        int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum_a,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(n >= 0 && m >= 1 && k >= 1, SGF_E_INVALID, "sgf_gram: bad sizes n=%lld m=%d k=%d",
+              static_cast<long long>(n), m, k);
+  SGF_REQUIRE(m % 4 == 0 && k % 4 == 0, SGF_E_UNSUPPORTED,
+              "sgf_gram: m and k must be multiples of 4 (m=%d k=%d)", m, k);
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "sgf_gram: unknown dtype %d", dtype);
+  SGF_REQUIRE(c && ldc >= k, SGF_E_INVALID, "sgf_gram: null c or ldc < k");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemset2DAsync(c, ldc * sizeof(float), 0, k * sizeof(float), m, st));
+    if (colsum_a) SGF_CHECK_HIP(hipMemsetAsync(colsum_a, 0, m * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(a && b, SGF_E_INVALID, "sgf_gram: null operand");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE,
+              "sgf_gram: workspace too small");
+  if (dtype == SGF_F32) return gram_t<float>(a, lda, m, b, ldb, k, n, c, ldc, colsum_a, workspace, st);
+  return gram_t<uint16_t>(a, lda, m, b, ldb, k, n, c, ldc, colsum_a, workspace, st);
+}
+
 extern "C" int64_t sgf_attn_stats_len(int32_t heads, int32_t d) {
   return static_cast<int64_t>(heads) * d * d + static_cast<int64_t>(heads) * d + 2;
 }
@@ -547,7 +1078,7 @@ int fwd_reduce_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(k, ldk) && aligned4<T>(v, ldv), SGF_E_INVALID,
               "sgf_attn_fwd_reduce: q/k/v must be 4-element aligned with ld %% 4 == 0");
   const int DP = padded_dim(d);
-  const int R = reduce_rows_per_tile(DP);
+  const int R = reduce_rows_per_tile<T>(DP);
   const int64_t ntiles = (n + R - 1) / R;
   const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
   const int64_t len = sgf_attn_stats_len(heads, d);
@@ -560,11 +1091,11 @@ int fwd_reduce_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
   a.b = v; a.ldb = ldv;
   a.q = q; a.ldq = ldq;
   a.den = nullptr;
-  a.n = n; a.d = d; a.heads = heads; a.b_heads = v_heads; a.gscale = 1.f;
+  a.n = n; a.d = d; a.db = d; a.heads = heads; a.b_heads = v_heads; a.gscale = 1.f;
   a.partial = static_cast<float*>(ws);
   int rc = launch_reduce<T, kModeFwd>(a, DP, nblk, st);
   if (rc != SGF_OK) return rc;
-  const int RG = 16 / ((DP / 64) * (DP / 64));
+  const int RG = reduce_row_groups<T>(DP);
   const int fb = static_cast<int>((len + 255) / 256);
   hipLaunchKernelGGL(k_attn_finalize, dim3(fb), dim3(256), 0, st, a.partial, nblk, heads, d, DP, RG,
                      kModeFwd, stats);
@@ -612,7 +1143,7 @@ int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const v
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(g, ldg) && aligned4<T>(o, ldo), SGF_E_INVALID,
               "sgf_attn_bwd_reduce: q/g/o must be 4-element aligned with ld %% 4 == 0");
   const int DP = padded_dim(d);
-  const int R = reduce_rows_per_tile(DP);
+  const int R = reduce_rows_per_tile<T>(DP);
   const int64_t ntiles = (n + R - 1) / R;
   const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
   const int64_t len = sgf_attn_bstats_len(heads, d);
@@ -625,11 +1156,11 @@ int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const v
   a.b = g; a.ldb = ldg;     // g is [n, d]: shared by all heads
   a.q = o; a.ldq = ldo;     // o is [n, H, d] (or out when H == 1)
   a.den = den;
-  a.n = n; a.d = d; a.heads = heads; a.b_heads = 1; a.gscale = 1.f / heads;
+  a.n = n; a.d = d; a.db = d; a.heads = heads; a.b_heads = 1; a.gscale = 1.f / heads;
   a.partial = static_cast<float*>(ws);
   int rc = launch_reduce<T, kModeBwd>(a, DP, nblk, st);
   if (rc != SGF_OK) return rc;
-  const int RG = 16 / ((DP / 64) * (DP / 64));
+  const int RG = reduce_row_groups<T>(DP);
   const int fb = static_cast<int>((len + 1 + 255) / 256);
   hipLaunchKernelGGL(k_attn_finalize, dim3(fb), dim3(256), 0, st, a.partial, nblk, heads, d, DP, RG,
                      kModeBwd, bstats);

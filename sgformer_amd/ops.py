@@ -183,6 +183,22 @@ class HipKernels:
                       _code(q), _ptr(stats), _ptr(bstats), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk),
                       _ptr(dv), _ld(dv), _stream(dev))
 
+    # ---- T4: dW = a^T b, db = colsum(a) ----
+    @staticmethod
+    def gram(a, b, out=None, want_colsum=True):
+        """out[m, k] (fp32, may be a column-sliced view) = a[n, m]^T b[n, k]; colsum(a) fp32 [m]."""
+        n, m = a.shape
+        k = b.shape[1]
+        dev = a.device
+        if out is None:
+            out = torch.empty((m, k), dtype=_F32, device=dev)
+        cs = torch.empty(m, dtype=_F32, device=dev) if want_colsum else None
+        ws = _workspace(dev, "attn", _lib.load().sgf_gram_workspace_bytes(n, m, k))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gram", _ptr(a), _ld(a), m, _ptr(b), _ld(b), k, n, _code(a), _ptr(out),
+                      out.stride(0), _ptr(cs), _ptr(ws), ws.numel(), _stream(dev))
+        return out, cs
+
     # ---- T5 ----
     @staticmethod
     def ln_fwd(x, res, a: float, b: float, gamma, beta, relu: bool, eps: float):
@@ -573,29 +589,81 @@ def axpby(x1, x2, a, b):
 
 
 # ------------------------------------------------------------------------------------------------
-# output layer  x W^T + b  (large/ours.py:275).  The GEMMs stay on hipBLASLt; only the bias
-# gradient is ours: ATen's column reduction of a [N, C] tensor with C = 47 took 18.6 ms per step at
-# ogbn-products scale (profiles/r01_products_f32_kernel_stats.md), k_colsum_any takes < 0.5 ms.
+# T4: the Linear layers  y = x W^T + b  (large/ours.py:123-126, :36-40, :77, :198, :275).
+# Forward and dX stay on hipBLASLt (plain library GEMMs); the weight / bias gradients
+#     dW = dY^T X   (a d x d <- [N x d]^T [N x d] reduction over all nodes),   db = colsum(dY)
+# run on sgf_gram: hipBLASLt's kernels for that shape ran at 0.7 TB/s (3.6 ms per call at
+# ogbn-products scale, profiles/r01_products_bf16_kernel_stats.md) and ATen's column reduction for
+# the bias gradient at 18.6 ms for C = 47.  Master weights may be fp32 while activations are bf16.
 # ------------------------------------------------------------------------------------------------
-class _OutLinear(torch.autograd.Function):
+class _Linear(torch.autograd.Function):
+    """y = sum_i x_i W_i^T + b with W = [W_1 | W_2 | ...] split along its input dimension
+    (one operand for nn.Linear; two for GraphConvLayer's W [A x | x0], large/ours.py:36-38,
+    without materialising the concatenation)."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
-        K.check(x)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+    def forward(ctx, w, b, *xs):
+        K.check(*xs)
+        dt = xs[0].dtype
+        wc = w if w.dtype == dt else w.to(dt)
+        bc = None if b is None else (b if b.dtype == dt else b.to(dt))
+        widths = [x.shape[1] for x in xs]
+        if sum(widths) != w.shape[1]:
+            raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
+        if len(xs) == 1:
+            y = torch.nn.functional.linear(xs[0], wc, bc)
+        else:
+            y, off = bc, 0
+            for x, k in zip(xs, widths):
+                wt = wc[:, off:off + k].t()
+                y = x @ wt if y is None else torch.addmm(y, x, wt)
+                off += k
+        ctx.save_for_backward(wc, *xs)
+        ctx.meta = (w.dtype, None if b is None else b.dtype, widths)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        wc, *xs = ctx.saved_tensors
+        wdtype, bdtype, widths = ctx.meta
         g = g.contiguous()
-        dx = g @ w if ctx.needs_input_grad[0] else None
-        dw = g.t() @ x if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(g).to(w.dtype) if g.shape[1] <= 256 else g.sum(0)
-        return dx, dw, db
+        need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and bdtype is not None
+        dxs, off = [], 0
+        for i, k in enumerate(widths):
+            dxs.append(g @ wc[:, off:off + k] if ctx.needs_input_grad[2 + i] else None)
+            off += k
+        dw = db = None
+        if need_w or need_b:
+            # sgf_gram wants widths that are multiples of 4 elements: zero-pad the odd ones (e.g. the
+            # C = 47 logits gradient: one extra [N, 48] pass) and slice the result
+            m = g.shape[1]
+            gp = _rows(g if m % 4 == 0 else torch.nn.functional.pad(g, (0, 4 - m % 4)))
+            dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
+            off = 0
+            for i, (x, k) in enumerate(zip(xs, widths)):
+                if k % 4 == 0:
+                    _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
+                else:
+                    xp = _rows(torch.nn.functional.pad(x, (0, 4 - k % 4)))
+                    blk, cs = K.gram(gp, xp, want_colsum=(i == 0 and need_b))
+                    dw[:, off:off + k] = blk[:, :k]
+                if i == 0:
+                    db = cs
+                off += k
+            dw = dw[:m].to(wdtype) if need_w else None
+            db = db[:m].to(bdtype) if need_b else None
+        return (dw, db, *dxs)
+
+
+def linear(x, w, b):
+    """nn.Linear forward on hipBLASLt, weight / bias gradients on sgf_gram."""
+    return _Linear.apply(w, b, x)
+
+
+def linear_cat(xs, w, b):
+    """[x_1 | x_2 | ...] W^T + b without the concatenation (GraphConvLayer with use_init)."""
+    return _Linear.apply(w, b, *xs)
 
 
 def out_linear(x, w, b):
-    return _OutLinear.apply(x, w, b)
+    return _Linear.apply(w, b, x)

@@ -41,12 +41,9 @@ DEFAULT_COMPUTE_DTYPE = None
 
 def _lin(x, lin: nn.Linear):
     """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
-    with bf16 activations (`SGFormer.compute_dtype`); a no-op cast otherwise.  hipBLASLt GEMM."""
-    w = lin.weight if lin.weight.dtype == x.dtype else lin.weight.to(x.dtype)
-    b = lin.bias
-    if b is not None and b.dtype != x.dtype:
-        b = b.to(x.dtype)
-    return F.linear(x, w, b)
+    with bf16 activations (`SGFormer.compute_dtype`).  Forward / dX on hipBLASLt, dW / db on
+    sgf_gram (ops.linear)."""
+    return ops.linear(x, lin.weight, lin.bias)
 
 
 def _drop(x, p, training):
@@ -114,10 +111,8 @@ class GraphConvLayer(nn.Module):
             graph = ops.graph_cache.get(edge_index, x.shape[0])
         y = ops.spmm(graph, x, shard)
         if self.use_init:
-            d = y.shape[1]
-            w, b = self.W.weight.to(y.dtype), self.W.bias.to(y.dtype)
             # W [y | x0] + b without materialising the concatenation
-            y = torch.addmm(torch.addmm(b, y, w[:, :d].t()), x0, w[:, d:].t())
+            y = ops.linear_cat((y, x0), self.W.weight, self.W.bias)
         elif self.use_weight:
             y = _lin(y, self.W)
         return y
@@ -224,11 +219,10 @@ class TransConvLayer(nn.Module):
         """[Q | K (| V)] in ONE buffer: a single [d -> 2Hd or 3Hd] GEMM when query is source."""
         ws = [self.Wq.weight, self.Wk.weight] + ([self.Wv.weight] if self.use_weight else [])
         bs = [self.Wq.bias, self.Wk.bias] + ([self.Wv.bias] if self.use_weight else [])
-        dt = query_input.dtype
         if query_input is source_input:
-            return F.linear(query_input, torch.cat(ws, 0).to(dt), torch.cat(bs, 0).to(dt))
-        q = F.linear(query_input, ws[0].to(dt), bs[0].to(dt))
-        kv = F.linear(source_input, torch.cat(ws[1:], 0).to(dt), torch.cat(bs[1:], 0).to(dt))
+            return ops.linear(query_input, torch.cat(ws, 0), torch.cat(bs, 0))
+        q = ops.linear(query_input, ws[0], bs[0])
+        kv = ops.linear(source_input, torch.cat(ws[1:], 0), torch.cat(bs[1:], 0))
         return torch.cat([q, kv], 1)
 
     def forward(self, query_input, source_input, output_attn=False):
@@ -369,11 +363,11 @@ class SGFormer(nn.Module):
         large/main-batch.py:157 calls it every eval_step).  There is no CPU implementation here, so
         the same HIP path is run on copies staged to the current GPU and the logits are returned
         on the host — the trainer stays unchanged and nothing is computed on the CPU."""
-        if torch.is_grad_enabled():
-            raise RuntimeError("sgformer_amd: CPU tensors with autograd enabled — training runs on "
-                               "MI355X only; move the model and inputs to the GPU")
         if not torch.cuda.is_available():
             ops._require_cuda(x)  # raises the standard no-CPU-path error
+        if torch.is_grad_enabled():
+            raise RuntimeError("sgformer_amd: CPU tensors with autograd enabled — there is no CPU fallback "
+                               "and training runs on MI355X only; move the model and inputs to the GPU")
         dev = torch.device("cuda", torch.cuda.current_device())
         state = {k: v.to(dev) for k, v in list(self.named_parameters()) + list(self.named_buffers())}
         out = torch.func.functional_call(self, state, (x.to(dev), edge_index.to(dev)))
@@ -398,8 +392,7 @@ class SGFormer(nn.Module):
                 x = torch.cat((x1, x2), dim=1)
         else:
             x = x1
-        w, b = self.fc.weight.to(x.dtype), self.fc.bias.to(x.dtype)
-        return ops.out_linear(x, w, b).to(out_dtype)
+        return ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
 
     def get_attentions(self, x):
         return self.trans_conv.get_attentions(x)

@@ -43,6 +43,16 @@ class CpuKernels:
         rows = torch.repeat_interleave(torch.arange(n_rows), counts)
         return y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
 
+    # ---- T4 ----
+    @staticmethod
+    def gram(a, b, out=None, want_colsum=True):
+        c = a.float().t() @ b.float()
+        if out is None:
+            out = c
+        else:
+            out.copy_(c)
+        return out, (a.float().sum(0) if want_colsum else None)
+
     # ---- T3 ----
     @staticmethod
     def _unpack(stats, heads, d):

@@ -191,6 +191,105 @@ def test_attention_bf16(cuda):
     assert _rel(out.float(), ref) <= 8e-3      # bf16 output rounding (2^-8) on fp32 arithmetic
 
 
+BF16_CASES = [(50, 1, 64, False), (777, 1, 64, False), (1000, 1, 128, False), (3000, 1, 256, False),
+              (4099, 1, 256, False), (333, 2, 64, True), (515, 1, 100, False), (20000, 1, 256, False)]
+
+
+@pytest.mark.parametrize("n,h,d,shared_v", BF16_CASES)
+def test_attention_bf16_raw_stats(cuda, n, h, d, shared_v):
+    """bf16 storage runs on the bf16 matrix cores (k_reduce_bf16): products of bf16 values are exact
+    in fp32 and accumulation is fp32, so against fp64 on the SAME bf16-rounded inputs the partials
+    must agree to fp32 accumulation accuracy — this also pins the transposed-LDS fragment layout
+    (asymmetric Q / K / V: a row/column swap cannot pass)."""
+    from sgformer_amd import ops
+    q, k, v = (t.bfloat16() for t in _qkv(n, h, d, shared_v))
+    ref = O.attention_raw_stats(q.double(), k.double(), v.double())
+    got = ops.attention_stats(q.to(cuda), k.to(cuda), v.to(cuda))
+    nm = h * d * d
+    assert _rel(got[:nm], ref[:nm]) <= 5e-6
+    assert _rel(got[nm:nm + h * d], ref[nm:nm + h * d]) <= 5e-6
+    assert abs(float(got[-2]) / float(ref[-2]) - 1) <= 5e-6
+    assert abs(float(got[-1]) / float(ref[-1]) - 1) <= 5e-6
+
+
+@pytest.mark.parametrize("n,h,d,shared_v", BF16_CASES)
+def test_attention_bf16_forward_backward(cuda, n, h, d, shared_v):
+    """bf16 activations, small n_total so that the all-pair term is O(1): outputs and gradients are
+    rounded to bf16 once (2^-9 relative per element) and the d x d matrices enter the apply MFMAs
+    rounded to bf16, so the bound is a few 2^-8 in Frobenius norm — a transposed or mis-tiled
+    operand would be off by O(1)."""
+    q, k, v = (t.bfloat16() for t in _qkv(n, h, d, shared_v, seed=1))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = O.attention(qd, kd, vd, n_total=4.0)
+    w = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).bfloat16()
+    (ref * w.double()).sum().backward()
+    out, qkv, vx = _run_attention(cuda, q, k, v, 4.0)
+    assert out.dtype == torch.bfloat16
+    assert _rel(out.float(), ref.detach()) <= 6e-3
+    (out.float() * w.float().to(cuda)).sum().backward()
+    hd = h * d
+    gq, gk = qkv.grad[:, :hd].reshape(n, h, d), qkv.grad[:, hd:2 * hd].reshape(n, h, d)
+    gv = qkv.grad[:, 2 * hd:].reshape(n, h, d) if vx is None else vx.grad.reshape(n, 1, d)
+    assert _rel(gv.float(), vd.grad) <= 1e-2
+    assert _rel(gq.float(), qd.grad) <= 1.5e-2
+    assert _rel(gk.float(), kd.grad) <= 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------------
+# T4 weight / bias gradients: sgf_gram
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,m,k", [(5000, 256, 256), (3000, 768, 256), (1000, 256, 100), (777, 64, 64),
+                                   (50, 128, 36), (2049, 256, 512), (300, 4, 8), (0, 64, 32)])
+def test_gram(cuda, dtype, n, m, k):
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + m + k)
+    a = (torch.randn(n, m, generator=g) * 0.5 + 0.3).to(dtype)
+    b = (torch.randn(n, k, generator=g) * 1.5 - 0.2).to(dtype)
+    c, cs = ops.K.gram(a.to(cuda), b.to(cuda))
+    ref = a.double().t() @ b.double()
+    assert c.dtype == torch.float32 and c.shape == (m, k)
+    if n == 0:
+        assert torch.count_nonzero(c) == 0 and torch.count_nonzero(cs) == 0
+        return
+    assert _rel(c, ref) <= 5e-6                      # fp32 accumulation of exact (bf16) / fp32 products
+    assert _rel(cs, a.double().sum(0)) <= 5e-6
+    # column-sliced output view (how ops.linear_cat fills dW = [dW_1 | dW_2])
+    big = torch.full((m, k + 12), 7.0, device=cuda)
+    ops.K.gram(a.to(cuda), b.to(cuda), out=big[:, 4:4 + k], want_colsum=False)
+    assert _rel(big[:, 4:4 + k], ref) <= 5e-6
+    assert bool((big[:, :4] == 7.0).all()) and bool((big[:, 4 + k:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("widths,out_dim", [((256,), 256), ((256, 256), 256), ((100,), 256), ((64,), 47)])
+def test_linear_gradients(cuda, dtype, widths, out_dim):
+    """ops.linear / linear_cat (hipBLASLt forward + dX, sgf_gram dW / db) against autograd of the
+    plain fp64 expression; fp32 master weights, activations in `dtype`."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n = 1500
+    xs = [torch.randn(n, w, generator=g).to(dtype) for w in widths]
+    w = torch.randn(out_dim, sum(widths), generator=g) * 0.1
+    b = torch.randn(out_dim, generator=g)
+    gy = torch.randn(n, out_dim, generator=g).to(dtype)
+    xd = [x.double().requires_grad_(True) for x in xs]
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.cat(xd, 1) @ wd.t() + bd
+    ref.backward(gy.double())
+    xg = [x.to(cuda).requires_grad_(True) for x in xs]
+    wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    y = ops.linear_cat(tuple(xg), wg, bg)
+    y.backward(gy.to(cuda))
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert _rel(y.float(), ref.detach()) <= tol
+    assert wg.grad.dtype == torch.float32 and bg.grad.dtype == torch.float32
+    assert _rel(wg.grad, wd.grad) <= (1e-5 if dtype == torch.float32 else 1e-5)  # exact products, fp32 acc
+    assert _rel(bg.grad, bd.grad) <= 1e-5
+    for a, r in zip(xg, xd):
+        assert _rel(a.grad.float(), r.grad) <= tol
+
+
 def test_attention_n0(cuda):
     from sgformer_amd import ops
     out = ops.attention(torch.zeros(0, 3 * 64, device=cuda), None, 1, 64)

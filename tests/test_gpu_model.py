@@ -197,3 +197,26 @@ def test_bf16_activation_mode(cuda):
     for k in ["fc.weight", "graph_conv.convs.2.W.weight", "graph_conv.fcs.0.weight"]:
         g, gr = dict(m.named_parameters())[k].grad.double().cpu(), p64[k].grad
         assert float((g - gr).norm() / gr.norm()) <= 8e-2, k
+
+
+def test_host_tensors_are_evaluated_on_the_gpu(cuda):
+    """large/eval.py:36-65 (`evaluate_large`) moves the model and the graph to the CPU and calls
+    model(x, edge_index) under no_grad: the drop-in stages copies to the GPU, runs the HIP path and
+    returns host logits (no CPU implementation exists); with autograd enabled it refuses."""
+    cfg = CONFIGS["products"]
+    n, f, d, c = 900, 24, 64, 7
+    torch.manual_seed(1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 6.0, seed=2)
+    m, _ = _build(cfg, f, d, c, cuda)
+    m.eval()
+    with torch.no_grad():
+        ref = m(x.to(cuda), ei.to(cuda)).cpu()
+        m.to("cpu")
+        out = m(x, ei)
+    assert out.device.type == "cpu" and torch.equal(out, ref)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, ei)
+    m.to(cuda)
+    with torch.no_grad():
+        assert torch.equal(m(x.to(cuda), ei.to(cuda)).cpu(), ref)

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
 // column per lane.  Tiles are therefore staged TRANSPOSED in LDS, T[col][row]: a thread loads a
 // 4-row x 4-column patch (four 8-byte coalesced loads per stream), transposes it in registers and
 // writes four 8-byte column segments; an MFMA fragment is then one ds_read_b128.  The 16-byte
-// chunk index is XOR-swizzled with (col >> 1) & 7, which makes the fragment reads conflict-free
+// chunk index is XOR-swizzled per column (swz), which makes the fragment reads conflict-free
 // (bank = (addr/4) % 64 for b128: the 16 lanes of a service group hit 16 distinct 16-byte slots).
 // Any permutation of the rows inside a tile is harmless as long as A and B share it.
 // ------------------------------------------------------------------------------------------------
@@ -531,16 +531,32 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 
 constexpr int kBfThreads = 512;  // 8 waves = 2 per SIMD: a 256-VGPR budget per wave
 
-template <int DP, int MODE>
-__global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
-  constexpr int LPQ = DP / 4;             // lanes per patch row (64 / 32 / 16)
-  constexpr int QPW = 64 / LPQ;           // 4-row patches per wave per pass
-  constexpr int NPASS = 2;                // staging passes per tile
-  constexpr int R = 8 * QPW * 4 * NPASS;  // rows per tile (64 / 128 / 256)
-  constexpr int BN = DP >= 256 ? 128 : 64;  // a wave owns a 64 x BN block of the DP x DP result
+// XOR swizzle of the 16-byte chunk index inside an LDS column of the transposed tiles.  With a
+// 128-byte column (DP = 256) the ds_read_b128 fragment reads are conflict-free (the 16 lanes of a
+// service group land on 16 distinct 16-byte slots of the 256-byte bank row) and the ds_write_b64
+// patch stores are 2-way, the minimum for 16 lanes on 8 slots.
+__device__ __forceinline__ int swz(int col) { return ((col >> 2) ^ ((col & 2) << 1)) & 7; }
+
+// NW waves per block.  NW = 16 (4 per SIMD, 128 VGPRs): 64x64 wave blocks, one staging pass per
+// tile, 64-96 KiB of loads in flight per CU.  NW = 8 (2 per SIMD, 256 VGPRs): 64x128 wave blocks
+// (fewer LDS fragment reads per MFMA), two half-tile staging passes.
+template <int NW, int DP>
+struct ReduceGeom {
+  static constexpr int LPQ = DP / 4;             // lanes per patch row (64 / 32 / 16)
+  static constexpr int QPW = 64 / LPQ;           // 4-row patches per wave per pass
+  static constexpr int NPASS = NW == 16 ? 1 : 2; // staging passes per tile
+  static constexpr int R = NW * QPW * 4 * NPASS; // rows per tile (64 / 128 / 256)
+  static constexpr int BN = (NW == 8 && DP >= 256) ? 128 : 64;  // a wave owns a 64 x BN result block
+  static constexpr int NBM = DP / 64, NBN = DP / BN;
+  static constexpr int RG = NW / (NBM * NBN);    // row groups
+};
+
+template <int DP, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
+  using G = ReduceGeom<NW, DP>;
+  constexpr int LPQ = G::LPQ, QPW = G::QPW, NPASS = G::NPASS, R = G::R, BN = G::BN;
   constexpr int TN = BN / 32;
-  constexpr int NBM = DP / 64, NBN = DP / BN;
-  constexpr int RG = 8 / (NBM * NBN);     // row groups (1 / 4 / 8)
+  constexpr int NBM = G::NBM, NBN = G::NBN, RG = G::RG;
   constexpr int KSTEPS = R / 16;          // MFMA k-steps (16 rows) per tile
   constexpr int SPG = KSTEPS / RG;        // k-steps per row group per tile
   constexpr int CSB = R * 2;              // bytes per LDS column
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
   const int wm = blk / NBN;
   const int wd = blk % NBN;
 
-  // staging map: in pass t this thread owns rows 4q..4q+3 (q = q0 + t * 8 * QPW), columns c0..c0+3
+  // staging map: in pass t this thread owns rows 4q..4q+3 (q = q0 + t * NW * QPW), columns c0..c0+3
   const int q0 = wave * QPW + lane / LPQ;
   const int c0 = (lane % LPQ) * 4;
   const bool a_ok = c0 < p.d;
@@ -592,7 +608,7 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
   auto issue = [&](int64_t tile, int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t row = tile * R + 4 * (q0 + t * 8 * QPW) + i;
+      const int64_t row = tile * R + 4 * (q0 + t * NW * QPW) + i;
       const bool rok = row < p.n;
       ra[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pa + row * p.lda) : make_uint2(0u, 0u);
       rb[i] = (rok && b_ok) ? *reinterpret_cast<const uint2*>(pb + row * p.ldb) : make_uint2(0u, 0u);
@@ -643,11 +659,11 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
         colsum.z += bf_lo(ra[i].y) * dden; colsum.w += bf_hi(ra[i].y) * dden;
       }
     }
-    const int q = q0 + t * 8 * QPW;
+    const int q = q0 + t * NW * QPW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = c0 + j;
-      const int off = col * CSB + (((q >> 1) ^ ((col >> 1) & 7)) << 4) + ((q & 1) << 3);
+      const int off = col * CSB + (((q >> 1) ^ swz(col)) << 4) + ((q & 1) << 3);
       *reinterpret_cast<uint2*>(ta + off) = column(ra, j);
       *reinterpret_cast<uint2*>(tb + off) = column(rb, j);
     }
@@ -677,13 +693,13 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
 #pragma unroll 1
       for (int s = t * (SPG / NPASS); s < (t + 1) * (SPG / NPASS); ++s) {
         const int chunk = 2 * (grp + RG * s) + hi;
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ta + ca0 * CSB + ((chunk ^ ((ca0 >> 1) & 7)) << 4));
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ta + ca1 * CSB + ((chunk ^ ((ca1 >> 1) & 7)) << 4));
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ta + ca0 * CSB + ((chunk ^ swz(ca0)) << 4));
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ta + ca1 * CSB + ((chunk ^ swz(ca1)) << 4));
         bf16x8 bfr[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const int cb = cb0 + 32 * tn;
-          bfr[tn] = *reinterpret_cast<const bf16x8*>(tb + cb * CSB + ((chunk ^ ((cb >> 1) & 7)) << 4));
+          bfr[tn] = *reinterpret_cast<const bf16x8*>(tb + cb * CSB + ((chunk ^ swz(cb)) << 4));
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -712,13 +728,13 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
   // column sums: threads with equal c0 differ in patch row -> reduce over the 8*QPW slots via LDS
   __syncthreads();
   float* fl = reinterpret_cast<float*>(lds);
-  constexpr int SLOTS = 8 * QPW;
+  constexpr int SLOTS = NW * QPW;
   *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsum;
   const float wa = group_sum<64>(ssq_a);
   const float wq = group_sum<64>(ssq_q);
   if (lane == 0) {
     fl[SLOTS * DP + wave] = wa;
-    fl[SLOTS * DP + 8 + wave] = wq;
+    fl[SLOTS * DP + NW + wave] = wq;
   }
   __syncthreads();
   if (tid < DP) {
@@ -728,9 +744,9 @@ __global__ __launch_bounds__(kBfThreads) void k_reduce_bf16(ReduceArgs p) {
   }
   if (tid == 0) {
     float sa = 0.f, sq = 0.f;
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < NW; ++w) {
       sa += fl[SLOTS * DP + w];
-      sq += fl[SLOTS * DP + 8 + w];
+      sq += fl[SLOTS * DP + NW + w];
     }
     part[kTileElems + DP] = sa;
     part[kTileElems + DP + 1] = sq;
@@ -864,6 +880,13 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
     const int64_t next = tile + gridDim.x;
     const bool has_next = next < ntiles;
     if (has_next) issue(next);
+    // E rows of THIS tile: issued before the MFMA phase, consumed after it (latency hidden)
+    uint2 re[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t row = tile * RT + srow0 + i * RPP;
+      re[i] = (scol_ok && row < p.n) ? *reinterpret_cast<const uint2*>(pe + row * p.lde) : make_uint2(0u, 0u);
+    }
     {
       f32x16 acc0, acc1;
 #pragma unroll
@@ -893,7 +916,7 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
         const int lrow = srow0 + i * RPP;
         const int64_t row = tile * RT + lrow;
         if (scol_ok && row < p.n) {
-          const float4 e = load4<uint16_t>(pe + row * p.lde);
+          const float4 e = make_float4(bf_lo(re[i].x), bf_hi(re[i].x), bf_lo(re[i].y), bf_hi(re[i].y));
           const float4 c0 = *reinterpret_cast<const float4*>(&ldsC[lrow * LDC + scol]);
           const float ar = rs[lrow], gr = rs[2 * RT + lrow];
           float4 v = make_float4(ar * c0.x + gr * e.x, ar * c0.y + gr * e.y, ar * c0.z + gr * e.z,
@@ -919,27 +942,34 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// NW of k_reduce_bf16 per mode: the two-stream Gram mode fits 16 waves x 128 VGPRs without spilling
+// (twice the loads in flight); the three-stream attention modes need the 8-wave / 256-VGPR shape.
+constexpr int bf_reduce_waves(int mode) { return mode == kModeGram ? 16 : 8; }
+
+template <typename T, int MODE>
 inline int reduce_rows_per_tile(int DP) {
-  // fp32 storage: k_attn_reduce, 1024 / (DP/4) rows;  bf16 storage: k_reduce_bf16, 16384 / DP rows
-  return sizeof(T) == 4 ? kRedThreads / (DP / 4) : 16384 / DP;
+  // fp32 storage: k_attn_reduce, 1024 / (DP/4) rows;  bf16 storage: ReduceGeom::R
+  if (sizeof(T) == 4) return kRedThreads / (DP / 4);
+  constexpr int NW = bf_reduce_waves(MODE);
+  return DP == 64 ? ReduceGeom<NW, 64>::R : (DP == 128 ? ReduceGeom<NW, 128>::R : ReduceGeom<NW, 256>::R);
 }
 
-template <typename T>
+template <typename T, int MODE>
 inline int reduce_row_groups(int DP) {
   // row groups whose partial results the finalize kernels add up (must match the kernels' RG)
   if (sizeof(T) == 4) return 16 / ((DP / 64) * (DP / 64));       // k_attn_reduce: 16 waves, 64x64 blocks
-  return DP >= 256 ? 1 : (DP == 128 ? 2 : 8);                    // k_reduce_bf16: 8 waves, 64xBN blocks
+  constexpr int NW = bf_reduce_waves(MODE);
+  return DP == 64 ? ReduceGeom<NW, 64>::RG : (DP == 128 ? ReduceGeom<NW, 128>::RG : ReduceGeom<NW, 256>::RG);
 }
 
 template <typename T, int MODE>
 int launch_reduce(const ReduceArgs& args, int DP, int nblk, hipStream_t st) {
-  const dim3 grid(nblk, args.heads), block(sizeof(T) == 2 ? kBfThreads : kRedThreads);
+  const dim3 grid(nblk, args.heads), block(sizeof(T) == 2 ? bf_reduce_waves(MODE) * 64 : kRedThreads);
   if (sizeof(T) == 2) {
     switch (DP) {
-      case 64: hipLaunchKernelGGL((k_reduce_bf16<64, MODE>), grid, block, 0, st, args); break;
-      case 128: hipLaunchKernelGGL((k_reduce_bf16<128, MODE>), grid, block, 0, st, args); break;
-      default: hipLaunchKernelGGL((k_reduce_bf16<256, MODE>), grid, block, 0, st, args); break;
+      case 64: hipLaunchKernelGGL((k_reduce_bf16<64, MODE, bf_reduce_waves(MODE)>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_reduce_bf16<128, MODE, bf_reduce_waves(MODE)>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_reduce_bf16<256, MODE, bf_reduce_waves(MODE)>), grid, block, 0, st, args); break;
     }
   } else {
     switch (DP) {
@@ -1007,7 +1037,7 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
     for (int ki = 0; ki < k; ki += 256) {
       const int kb = k - ki < 256 ? k - ki : 256;
       const int DP = padded_dim(mb > kb ? mb : kb);
-      const int R = reduce_rows_per_tile<T>(DP);
+      const int R = reduce_rows_per_tile<T, kModeGram>(DP);
       const int64_t ntiles = (n + R - 1) / R;
       const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
       ReduceArgs r{};
@@ -1018,7 +1048,7 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
       r.partial = static_cast<float*>(ws);
       int rc = launch_reduce<T, kModeGram>(r, DP, nblk, st);
       if (rc != SGF_OK) return rc;
-      const int RG = reduce_row_groups<T>(DP);
+      const int RG = reduce_row_groups<T, kModeGram>(DP);
       const int64_t len = static_cast<int64_t>(mb) * kb + mb;
       float* cs = (colsum_a != nullptr && ki == 0) ? colsum_a + mi : nullptr;
       hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0,
@@ -1078,7 +1108,7 @@ int fwd_reduce_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(k, ldk) && aligned4<T>(v, ldv), SGF_E_INVALID,
               "sgf_attn_fwd_reduce: q/k/v must be 4-element aligned with ld %% 4 == 0");
   const int DP = padded_dim(d);
-  const int R = reduce_rows_per_tile<T>(DP);
+  const int R = reduce_rows_per_tile<T, kModeFwd>(DP);
   const int64_t ntiles = (n + R - 1) / R;
   const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
   const int64_t len = sgf_attn_stats_len(heads, d);
@@ -1095,7 +1125,7 @@ int fwd_reduce_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
   a.partial = static_cast<float*>(ws);
   int rc = launch_reduce<T, kModeFwd>(a, DP, nblk, st);
   if (rc != SGF_OK) return rc;
-  const int RG = reduce_row_groups<T>(DP);
+  const int RG = reduce_row_groups<T, kModeFwd>(DP);
   const int fb = static_cast<int>((len + 255) / 256);
   hipLaunchKernelGGL(k_attn_finalize, dim3(fb), dim3(256), 0, st, a.partial, nblk, heads, d, DP, RG,
                      kModeFwd, stats);
@@ -1143,7 +1173,7 @@ int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const v
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(g, ldg) && aligned4<T>(o, ldo), SGF_E_INVALID,
               "sgf_attn_bwd_reduce: q/g/o must be 4-element aligned with ld %% 4 == 0");
   const int DP = padded_dim(d);
-  const int R = reduce_rows_per_tile<T>(DP);
+  const int R = reduce_rows_per_tile<T, kModeBwd>(DP);
   const int64_t ntiles = (n + R - 1) / R;
   const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
   const int64_t len = sgf_attn_bstats_len(heads, d);
@@ -1160,7 +1190,7 @@ int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const v
   a.partial = static_cast<float*>(ws);
   int rc = launch_reduce<T, kModeBwd>(a, DP, nblk, st);
   if (rc != SGF_OK) return rc;
-  const int RG = reduce_row_groups<T>(DP);
+  const int RG = reduce_row_groups<T, kModeBwd>(DP);
   const int fb = static_cast<int>((len + 1 + 255) / 256);
   hipLaunchKernelGGL(k_attn_finalize, dim3(fb), dim3(256), 0, st, a.partial, nblk, heads, d, DP, RG,
                      kModeBwd, bstats);

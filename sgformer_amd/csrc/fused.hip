@@ -269,7 +269,18 @@ __global__ __launch_bounds__(kThreads) void k_colreduce(F f, int64_t n, int d,
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_blk;
     int64_t r1 = r0 + rows_per_blk;
     if (r1 > n) r1 = n;
-    for (int64_t row = r0 + sr; row < r1; row += rpp) {
+    int64_t row = r0 + sr;
+    for (; row + 3 * static_cast<int64_t>(rpp) < r1; row += 4 * static_cast<int64_t>(rpp)) {
+      float4 a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f(row + u * static_cast<int64_t>(rpp), col, a0[u], a1[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {   // same order as the scalar loop: bitwise the same sums
+        s0.x += a0[u].x; s0.y += a0[u].y; s0.z += a0[u].z; s0.w += a0[u].w;
+        s1.x += a1[u].x; s1.y += a1[u].y; s1.z += a1[u].z; s1.w += a1[u].w;
+      }
+    }
+    for (; row < r1; row += rpp) {
       float4 v0, v1;
       f(row, col, v0, v1);
       s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
@@ -336,30 +347,52 @@ struct BnBwdStatsF {
 // ------------------------------------------------------------------------------------------------
 // elementwise: BN apply / BN backward apply / axpby.  One float4 per thread per step.
 // ------------------------------------------------------------------------------------------------
+// Thread map of the BatchNorm element-wise kernels: a thread keeps ONE 4-column chunk for the whole
+// kernel (its mean / rstd / gamma / beta / stats coefficients live in registers) and walks down the
+// rows, kRowUnroll independent row loads in flight per thread.  f4 = d/4 chunks per row, rpp =
+// 256 / f4 row slots per block pass; threads beyond rpp * f4 idle (only when 256 % f4 != 0).
+constexpr int kRowUnroll = 4;
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const T* __restrict__ x, int64_t ldx,
                                                        BnParams p, const T* __restrict__ res,
                                                        int64_t ldr, int relu, int64_t n, int d,
                                                        T* __restrict__ y, int64_t ldy) {
   const int f4 = d / 4;
-  const int64_t total = n * f4;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int64_t row = i / f4;
-    const int col = static_cast<int>(i % f4) * 4;
-    float4 mu, rs, ga, be;
-    bn_coeffs(p, col, mu, rs, ga, be);
-    const float4 xv = load4<T>(x + row * ldx + col);
-    float4 o = make_float4((xv.x - mu.x) * rs.x * ga.x + be.x, (xv.y - mu.y) * rs.y * ga.y + be.y,
-                           (xv.z - mu.z) * rs.z * ga.z + be.z, (xv.w - mu.w) * rs.w * ga.w + be.w);
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+  const int rpp = kThreads / f4;
+  const int sr = threadIdx.x / f4;
+  if (sr >= rpp) return;
+  const int col = (threadIdx.x % f4) * 4;
+  float4 mu, rs, ga, be;
+  bn_coeffs(p, col, mu, rs, ga, be);
+  // y = x * sc + sh  with sc = rstd*gamma, sh = beta - mean*sc  would round differently from the
+  // reference's (x - mean) * rstd * gamma + beta; keep the reference order of operations.
+  const int64_t step = static_cast<int64_t>(gridDim.x) * rpp;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * rpp + sr; row0 < n; row0 += step * kRowUnroll) {
+    float4 xv[kRowUnroll], rv[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * step;
+      if (row < n) {
+        xv[u] = load4<T>(x + row * ldx + col);
+        if (res != nullptr) rv[u] = load4<T>(res + row * ldr + col);
+      }
     }
-    if (res != nullptr) {
-      const float4 r = load4<T>(res + row * ldr + col);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * step;
+      if (row < n) {
+        float4 o = make_float4((xv[u].x - mu.x) * rs.x * ga.x + be.x, (xv[u].y - mu.y) * rs.y * ga.y + be.y,
+                               (xv[u].z - mu.z) * rs.z * ga.z + be.z, (xv[u].w - mu.w) * rs.w * ga.w + be.w);
+        if (relu) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        if (res != nullptr) {
+          o.x += rv[u].x; o.y += rv[u].y; o.z += rv[u].z; o.w += rv[u].w;
+        }
+        store4<T>(y + row * ldy + col, o);
+      }
     }
-    store4<T>(y + row * ldy + col, o);
   }
 }
 
@@ -369,33 +402,51 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
     int relu, const float* __restrict__ stats, float inv_n, int training, int64_t n, int d,
     T* __restrict__ dx, int64_t lddx) {
   const int f4 = d / 4;
-  const int64_t total = n * f4;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int64_t row = i / f4;
-    const int col = static_cast<int>(i % f4) * 4;
-    float4 mu, rs, ga, be;
-    bn_coeffs(p, col, mu, rs, ga, be);
-    const float4 xv = load4<T>(x + row * ldx + col);
-    float4 g = load4<T>(dy + row * lddy + col);
-    const float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z,
-                                  (xv.w - mu.w) * rs.w);
-    if (relu) {
-      g.x = (xh.x * ga.x + be.x) > 0.f ? g.x : 0.f;
-      g.y = (xh.y * ga.y + be.y) > 0.f ? g.y : 0.f;
-      g.z = (xh.z * ga.z + be.z) > 0.f ? g.z : 0.f;
-      g.w = (xh.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+  const int rpp = kThreads / f4;
+  const int sr = threadIdx.x / f4;
+  if (sr >= rpp) return;
+  const int col = (threadIdx.x % f4) * 4;
+  float4 mu, rs, ga, be;
+  bn_coeffs(p, col, mu, rs, ga, be);
+  float4 s0 = zero4(), s1 = zero4();
+  if (training) {
+    s0 = ld4f(stats + col);
+    s1 = ld4f(stats + d + col);
+  }
+  const int64_t step = static_cast<int64_t>(gridDim.x) * rpp;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * rpp + sr; row0 < n; row0 += step * kRowUnroll) {
+    float4 xv[kRowUnroll], gv[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * step;
+      if (row < n) {
+        xv[u] = load4<T>(x + row * ldx + col);
+        gv[u] = load4<T>(dy + row * lddy + col);
+      }
     }
-    if (training) {
-      const float4 s0 = ld4f(stats + col);
-      const float4 s1 = ld4f(stats + d + col);
-      g.x -= s0.x * inv_n + xh.x * s1.x * inv_n;
-      g.y -= s0.y * inv_n + xh.y * s1.y * inv_n;
-      g.z -= s0.z * inv_n + xh.z * s1.z * inv_n;
-      g.w -= s0.w * inv_n + xh.w * s1.w * inv_n;
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * step;
+      if (row < n) {
+        float4 g = gv[u];
+        const float4 xh = make_float4((xv[u].x - mu.x) * rs.x, (xv[u].y - mu.y) * rs.y,
+                                      (xv[u].z - mu.z) * rs.z, (xv[u].w - mu.w) * rs.w);
+        if (relu) {
+          g.x = (xh.x * ga.x + be.x) > 0.f ? g.x : 0.f;
+          g.y = (xh.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+          g.z = (xh.z * ga.z + be.z) > 0.f ? g.z : 0.f;
+          g.w = (xh.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+        }
+        if (training) {
+          g.x -= s0.x * inv_n + xh.x * s1.x * inv_n;
+          g.y -= s0.y * inv_n + xh.y * s1.y * inv_n;
+          g.z -= s0.z * inv_n + xh.z * s1.z * inv_n;
+          g.w -= s0.w * inv_n + xh.w * s1.w * inv_n;
+        }
+        store4<T>(dx + row * lddx + col,
+                  make_float4(ga.x * rs.x * g.x, ga.y * rs.y * g.y, ga.z * rs.z * g.z, ga.w * rs.w * g.w));
+      }
     }
-    store4<T>(dx + row * lddx + col,
-              make_float4(ga.x * rs.x * g.x, ga.y * rs.y * g.y, ga.z * rs.z * g.z, ga.w * rs.w * g.w));
   }
 }
 
@@ -419,6 +470,17 @@ __global__ __launch_bounds__(kThreads) void k_axpby(const T* __restrict__ x1, in
 
 inline int ew_grid(int64_t total_vec) {
   int64_t b = (total_vec + kThreads - 1) / kThreads;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+// blocks for the column-fixed row-walk kernels: enough to fill the chip (8 blocks / CU), never more
+// than one unrolled pass of rows per block
+inline int rowwalk_grid(int64_t n, int d) {
+  const int rpp = kThreads / (d / 4);
+  int64_t b = (n + static_cast<int64_t>(rpp) * kRowUnroll - 1) / (static_cast<int64_t>(rpp) * kRowUnroll);
   const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
@@ -621,7 +683,7 @@ extern "C" int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const
               "sgf_bn_apply: leading dims must be multiples of 4");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BnParams p{mean, rstd, gamma, beta};
-  const dim3 grid(ew_grid(n * (d / 4)));
+  const dim3 grid(rowwalk_grid(n, d));
   if (dtype == SGF_F32)
     hipLaunchKernelGGL((k_bn_apply<float>), grid, dim3(kThreads), 0, st,
                        static_cast<const float*>(x), ldx, p, static_cast<const float*>(res), ldr,
@@ -675,7 +737,7 @@ extern "C" int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int
               "sgf_bn_bwd_apply: leading dims must be multiples of 4");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BnParams p{mean, rstd, gamma, beta};
-  const dim3 grid(ew_grid(n * (d / 4)));
+  const dim3 grid(rowwalk_grid(n, d));
   if (dtype == SGF_F32)
     hipLaunchKernelGGL((k_bn_bwd_apply<float>), grid, dim3(kThreads), 0, st,
                        static_cast<const float*>(dy), lddy, static_cast<const float*>(x), ldx, p,

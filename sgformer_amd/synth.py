@@ -53,6 +53,28 @@ def synthetic_graph(n: int, avg_deg: float, seed: int = 123, directed: bool = Fa
     return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
 
 
+def synthetic_graph_local(n: int, avg_deg: float, locality: float = 0.9, window: int = 4096,
+                          seed: int = 123, device="cpu") -> torch.Tensor:
+    """Same sizes and prologue as `synthetic_graph`, but a fraction `locality` of the undirected
+    pairs joins nodes whose ids differ by ~N(0, window): the banded / community structure a real
+    co-purchase or social graph has after any locality-preserving node ordering (the uniform
+    generator is the zero-locality worst case: it is an expander, no ordering can help it)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    m = int(n * avg_deg / 2)
+    src = torch.randint(0, n, (m,), generator=g).to(device)
+    far = torch.randint(0, n, (m,), generator=g).to(device)
+    off = (torch.randn(m, generator=g) * float(window)).round().long().to(device)
+    is_local = (torch.rand(m, generator=g) < locality).to(device)
+    dst = torch.where(is_local, (src + off).clamp_(0, n - 1), far)
+    del far, off, is_local
+    src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
 def synthetic_task(n: int, f: int, c: int, seed: int = 123, device="cpu", dtype=torch.float32):
     """randn features, uniform labels, first half of a seeded permutation as the training split
     (rand_train_test_idx, large/data_utils.py:13-37, with train_prop = 0.5)."""

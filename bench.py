@@ -42,6 +42,12 @@ from sgformer_amd.ours import SGFormer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 
+# HBM bytes per k_spmm_wave launch from the rocprofv3 PMC passes committed under profiles/
+# (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 per the gfx950 correction of
+# MI355X_MICROARCH.md §HBM, which reproduces the gather bytes of this graph to 0.3 %).  PMC counters
+# cannot be collected from inside this process, so the figure is keyed on the exact workload.
+PMC_SPMM_TRAFFIC = {("ogbn-products", "bf16"): (67.1e9 + 1.25e9, "profiles/r01_spmm_pmc.md")}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -271,6 +277,8 @@ def main():
         loss_val = float(lt)
 
     roof = timer.summary()
+    if roof is not None and world == 1 and not args.nodes and (args.workload, args.dtype) in PMC_SPMM_TRAFFIC:
+        roof["traffic"], roof["traffic_source"] = PMC_SPMM_TRAFFIC[(args.workload, args.dtype)]
     if rank == 0 and world == 1 and roof is not None and not args.no_locality_probe and not args.nodes:
         del model, opt, x, y, loss
         ops.graph_cache.clear()

@@ -146,6 +146,41 @@ int sgf_attn_bwd_apply(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        void* dv, int64_t lddv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * T3 + T4 fused — attention straight from the un-projected layer input (H = 1, query == source:
+ * every recipe of the reference).  Replaces large/ours.py:123-157 as a whole: the projections
+ * Q = h Wq^T + bq, K = h Wk^T + bk, V = h Wv^T + bv are never materialised.  Because the attention
+ * only needs K^T V, sum K, ||Q||, ||K|| and Q applied to d x d matrices, everything global follows
+ * from the Gram matrix G = h^T h and s = sum_n h_n (sgf_gram(h, h) with its column sums):
+ *     S0 = Wk G Wv^T + (Wk s) bv^T + bk (Wv s)^T + N bk bv^T        z0 = Wk s + N bk
+ *     ||Q||^2 = tr(Wq G Wq^T) + 2 bq.(Wq s) + N |bq|^2   (same for K)    c = 1 / (||Q|| ||K||)
+ *     num = h M + m,  M = c Wq^T S0 + Ntot Wv^T,  m = c bq S0 + Ntot bv
+ *     den = h.w + beta,  w = c Wq^T z0,  beta = c bq.z0 + Ntot            out = num / den
+ * The d x d algebra (M, m, w, beta and its backward) is a handful of tiny fp32 GEMMs done by the
+ * caller (sgformer_amd/ops.py, on device, autograd); the library streams the [N, d] operands:
+ *     sgf_attn_h_fwd        : out = (h M + m) / (h.w + beta), den saved            (reads h once)
+ *     sgf_attn_h_bwd_reduce : hstats = [ dM = sum h^T dnum | dw = sum h dden | dm = sum dnum |
+ *                             dbeta = sum dden ],  dnum = g/den, dden = -(g.out)/den
+ *     sgf_attn_h_bwd_apply  : dh = dnum M^T + dden w + h D + ds   with D = dG + dG^T, ds from the
+ *                             caller's backward through the d x d algebra
+ * HBM traffic per layer: 3 [N,d] passes forward, 9 backward — against ~31 for the materialised
+ * Q/K/V form (projection GEMM + its dX / dW, two reduce and four apply passes).  Node-sharded runs
+ * all-reduce [G | s] and hstats (d^2 + d and d^2 + 2d + 1 floats).
+ * M, D: fp32 [d, d] row-major (M[k][j]: input feature k -> output feature j); m, w, ds: fp32 [d];
+ * beta: fp32 [1]; all DEVICE pointers.  d % 4 == 0, d <= 256.
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgf_attn_h_bstats_len(int32_t d);
+int sgf_attn_h_fwd(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* M,
+                   const float* m, const float* w, const float* beta, void* out, int64_t ldo,
+                   float* den, void* stream);
+int sgf_attn_h_bwd_reduce(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o,
+                          int64_t ldo, const float* den, int64_t n, int32_t d, int32_t dtype,
+                          float* hstats, void* workspace, size_t workspace_bytes, void* stream);
+int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o,
+                         int64_t ldo, const float* den, int64_t n, int32_t d, int32_t dtype,
+                         const float* M, const float* w, const float* D, const float* ds, void* dh,
+                         int64_t lddh, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for
  * every nn.Linear on the path under loss.backward() (large/main.py:142): the projections
  * large/ours.py:123-126, the GraphConvLayer weight :36-40, the stems :77,:198 and the head :275:

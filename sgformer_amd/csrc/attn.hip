@@ -39,13 +39,19 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int kRedThreads = 1024;
 constexpr int kTileElems = 65536;                  // RG * DP * DP, identical for every DP
-constexpr int kPartialStride = kTileElems + 264;   // + [DP colsum | ssq_a | ssq_q], padded
+constexpr int kVecB = kTileElems + 264;            // second column-sum vector (kModeBwdH) + 1 scalar
+constexpr int kPartialStride = kTileElems + 528;   // + [DP colsum | ssq_a | ssq_q | pad][DP colsum_b | s | pad]
 constexpr int kMaxBlocks = kNumCU;                 // persistent: one block per CU
 
 constexpr int kModeFwd = 0;  // reduce: A=K, B=V          apply: out
 constexpr int kModeBwd = 1;  // reduce: A=Q, B=dnum
 constexpr int kModeGram = 2; // reduce: C = A^T B plus column sums of A (sgf_gram); no third stream
+constexpr int kModeBwdH = 3; // reduce: A=h, B=dnum; vecA = sum h*dden, vecB = sum dnum, scalar = sum dden
 constexpr int kApplyFwd = 0, kApplyDQ = 1, kApplyDK = 2, kApplyDV = 3;
+// attention from the un-projected input (sgf_attn_h_*): no E operand, no global scalars
+constexpr int kApplyHFwd = 4;   // out = (h M + m) / (h.w + beta)
+constexpr int kApplyHBwd1 = 5;  // dh  = dnum M^T + dden w
+constexpr int kApplyHBwd2 = 6;  // dh += h D + ds
 
 static inline int padded_dim(int d) { return d <= 64 ? 64 : (d <= 128 ? 128 : 256); }
 
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float4 colsum = zero4();  // fwd: sum K        bwd: sum Q * dden
-  float ssq_a = 0.f;        // fwd: sum K^2
+  float4 colsumb = zero4(); // bwdH: sum dnum
+  float ssq_a = 0.f;        // fwd: sum K^2      bwdH: sum dden
   float ssq_q = 0.f;        // fwd: sum Q^2
 
   const int64_t ntiles = (p.n + R - 1) / R;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
     ra = ok ? load4<T>(pa + row * p.lda) : zero4();
     rb = (colb_ok && row < p.n) ? load4<T>(pb + row * p.ldb) : zero4();
     if (MODE != kModeGram) rq = ok ? load4<T>(pq + row * p.ldq) : zero4();
-    if (MODE == kModeBwd) rden = (row < p.n) ? p.den[row * p.heads + head] : 1.f;
+    if (MODE == kModeBwd || MODE == kModeBwdH) rden = (row < p.n) ? p.den[row * p.heads + head] : 1.f;
   };
   auto commit = [&](int buf) {
     float4 wa = ra, wb = rb;
@@ -139,6 +146,10 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
       wb = make_float4(rb.x * inv, rb.y * inv, rb.z * inv, rb.w * inv);
       colsum.x += ra.x * dden; colsum.y += ra.y * dden;
       colsum.z += ra.z * dden; colsum.w += ra.w * dden;
+      if (MODE == kModeBwdH) {
+        colsumb.x += wb.x; colsumb.y += wb.y; colsumb.z += wb.z; colsumb.w += wb.w;
+        if (col == 0) ssq_a += dden;   // one lane per row
+      }
     }
     *reinterpret_cast<float4*>(&ldsA[(buf * R + srow) * DP + col]) = wa;
     *reinterpret_cast<float4*>(&ldsB[(buf * R + srow) * DP + col]) = wb;
@@ -207,6 +218,16 @@ __global__ __launch_bounds__(kRedThreads) void k_attn_reduce(ReduceArgs p) {
     part[kTileElems + DP] = sa;
     part[kTileElems + DP + 1] = sq;
   }
+  if (MODE == kModeBwdH) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&lds[srow * DP + col]) = colsumb;
+    __syncthreads();
+    if (tid < DP) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += lds[r * DP + tid];
+      part[kVecB + tid] = s;
+    }
+  }
 }
 
 // out layout: [ M (heads*d*d) | vec (heads*d) | extra0 | extra1 ]; extras written iff n_extra > 0
@@ -273,6 +294,29 @@ __global__ void k_gram_finalize(const float* __restrict__ partial, int nblk, int
   }
 }
 
+// sgf_attn_h_bwd_reduce: hstats = [ dM (d*d) | dw (d) | dm (d) | dbeta ] from the per-block partials.
+__global__ void k_hbwd_finalize(const float* __restrict__ partial, int nblk, int d, int DP, int RG,
+                                float* __restrict__ out) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t nmat = static_cast<int64_t>(d) * d;
+  if (idx < nmat) {
+    const int m = static_cast<int>(idx / d);
+    const int dd = static_cast<int>(idx % d);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      const float* part = partial + static_cast<int64_t>(b) * kPartialStride;
+      for (int g = 0; g < RG; ++g) s += part[(g * DP + m) * DP + dd];
+    }
+    out[idx] = s;
+  } else if (idx < nmat + 2 * d + 1) {
+    const int j = static_cast<int>(idx - nmat);
+    const int off = j < d ? kTileElems + j : (j < 2 * d ? kVecB + (j - d) : kTileElems + DP);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * kPartialStride + off];
+    out[idx] = s;
+  }
+}
+
 // sdot = <S0,dS0> + <z0,dz0> over all heads: one block, fixed-order tree -> deterministic.
 __global__ __launch_bounds__(1024) void k_attn_sdot(const float* __restrict__ stats,
                                                     float* __restrict__ bstats, int64_t len) {
@@ -312,7 +356,9 @@ struct ApplyArgs {
   void* out;
   int64_t lda, lda2, lde, ldo;
   const float* bmat;   // [d, d] row-major (S0 or dS0 of this head)
-  const float* cvec;   // FWD/DQ: z0   DK: dz0   DV: unused
+  const float* cvec;   // FWD/DQ: z0   DK: dz0   DV: unused   H modes: epilogue vector (m / w / ds)
+  const float* dvec;   // HFwd: w (den = h.w + beta)
+  const float* beta;   // HFwd: device scalar
   float* den;          // [n, heads] (+head): written by FWD, read by DQ / DV
   const float* stats;  // fwd stats (for ssq_q, ssq_k)
   const float* sdot;   // DQ / DK: pointer to <S0,dS0>+<z0,dz0>
@@ -355,12 +401,15 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
   const int d = p.d;
 
   // global scalars (device-side: no host sync anywhere on the path)
-  const float ssq_q = p.stats[p.stats_len - 2];
-  const float ssq_k = p.stats[p.stats_len - 1];
-  const float c = 1.0f / (sqrtf(ssq_q) * sqrtf(ssq_k));
-  float gconst = 0.f;
-  if (MODE == kApplyDQ) gconst = -(c * p.sdot[0]) / ssq_q;
-  if (MODE == kApplyDK) gconst = -(c * p.sdot[0]) / ssq_k;
+  float c = 1.f, gconst = 0.f, hbeta = 0.f;
+  if (MODE <= kApplyDV) {
+    const float ssq_q = p.stats[p.stats_len - 2];
+    const float ssq_k = p.stats[p.stats_len - 1];
+    c = 1.0f / (sqrtf(ssq_q) * sqrtf(ssq_k));
+    if (MODE == kApplyDQ) gconst = -(c * p.sdot[0]) / ssq_q;
+    if (MODE == kApplyDK) gconst = -(c * p.sdot[0]) / ssq_k;
+  }
+  if (MODE == kApplyHFwd) hbeta = p.beta[0];
 
   // resident piece of the d x d matrix: breg[4s+t] = B[8(s + kh*KSH) + 4hi + t][32ws + i31]
   float breg[DP / 4];
@@ -384,6 +433,8 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
   const bool scol_ok = scol < d;
   float4 zc = zero4();  // FWD: z0 chunk (den = c Q.z0 + N);  DQ: z0, DK: dz0 chunk (epilogue)
   if (MODE != kApplyDV && scol_ok) zc = *reinterpret_cast<const float4*>(p.cvec + scol);
+  float4 zd = zero4();  // HFwd: w chunk (den = h.w + beta)
+  if (MODE == kApplyHFwd && scol_ok) zd = *reinterpret_cast<const float4*>(p.dvec + scol);
 
   const T* pa = static_cast<const T*>(p.a) + scol;
   const T* pa2 = static_cast<const T*>(p.a2) + scol;
@@ -401,8 +452,8 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
       const int64_t row = tile * RT + srow0 + i * RPP;
       const bool ok = scol_ok && row < p.n;
       ra[i] = ok ? load4<T>(pa + row * p.lda) : zero4();
-      if (MODE == kApplyDQ) ra2[i] = ok ? load4<T>(pa2 + row * p.lda2) : zero4();
-      if (MODE == kApplyDQ || MODE == kApplyDV)
+      if (MODE == kApplyDQ || MODE == kApplyHBwd1) ra2[i] = ok ? load4<T>(pa2 + row * p.lda2) : zero4();
+      if (MODE == kApplyDQ || MODE == kApplyDV || MODE == kApplyHBwd1)
         rden[i] = (row < p.n) ? p.den[row * p.heads] : 1.f;
     }
   };
@@ -427,8 +478,25 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
         br = c * (-gdo * inv);
       } else if (MODE == kApplyDK) {
         br = c;
-      } else {  // DV
+      } else if (MODE == kApplyDV) {
         gr = p.ntot * p.gscale / rden[i];
+      } else if (MODE == kApplyHFwd) {
+        const float den = group_sum<F4>(dot4(ra[i], zd)) + hbeta;
+        ar = 1.0f / den;
+        br = ar;
+        gr = 0.f;
+        if (scol == 0 && row < p.n) p.den[row * p.heads] = den;
+      } else if (MODE == kApplyHBwd1) {
+        const float gdo = group_sum<F4>(dot4(ra[i], ra2[i]));
+        const float inv = 1.0f / rden[i];
+        w = make_float4(ra[i].x * inv, ra[i].y * inv, ra[i].z * inv, ra[i].w * inv);
+        ar = 1.f;
+        br = -gdo * inv;
+        gr = 0.f;
+      } else {  // HBwd2
+        ar = 1.f;
+        br = 1.f;
+        gr = 0.f;
       }
       *reinterpret_cast<float4*>(&ldsA[(buf * RT + lrow) * LD + scol]) = w;
       if (scol == 0) {
@@ -479,13 +547,13 @@ __global__ __launch_bounds__(kApplyThreads) void k_attn_apply(ApplyArgs p) {
         const int lrow = srow0 + i * RPP;
         const int64_t row = tile * RT + lrow;
         if (scol_ok && row < p.n) {
-          const float4 e = load4<T>(pe + row * p.lde);
+          const float4 e = MODE <= kApplyDV ? load4<T>(pe + row * p.lde) : zero4();
           const float4 c0 = *reinterpret_cast<const float4*>(&ldsC[lrow * LD + scol]);
           const float4 c1 = *reinterpret_cast<const float4*>(&ldsC[(RT + lrow) * LD + scol]);
           const float ar = rs[lrow], gr = rs[2 * RT + lrow];
           float4 v = make_float4(ar * (c0.x + c1.x) + gr * e.x, ar * (c0.y + c1.y) + gr * e.y,
                                  ar * (c0.z + c1.z) + gr * e.z, ar * (c0.w + c1.w) + gr * e.w);
-          if (MODE == kApplyDQ || MODE == kApplyDK) {
+          if (MODE == kApplyDQ || MODE == kApplyDK || MODE >= kApplyHFwd) {
             const float br = rs[RT + lrow];
             v.x += br * zc.x; v.y += br * zc.y; v.z += br * zc.z; v.w += br * zc.w;
           }
@@ -595,8 +663,8 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 colsum = zero4();
-  float ssq_a = 0.f, ssq_q = 0.f;
+  float4 colsum = zero4(), colsumb = zero4();   // colsumb: bwdH only (sum dnum)
+  float ssq_a = 0.f, ssq_q = 0.f;               // bwdH: ssq_a = sum dden
 
   const int64_t ntiles = (p.n + R - 1) / R;
   // Only ONE staging pass is in flight at a time (24 VGPRs of loads): a tile iteration is NPASS
@@ -614,7 +682,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       rb[i] = (rok && b_ok) ? *reinterpret_cast<const uint2*>(pb + row * p.ldb) : make_uint2(0u, 0u);
       if (MODE != kModeGram)
         rq[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pq + row * p.ldq) : make_uint2(0u, 0u);
-      if (MODE == kModeBwd) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
+      if (MODE == kModeBwd || MODE == kModeBwdH) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
     }
   };
   // column j of a 4x4 patch as 8 bytes: rows 0..3
@@ -657,6 +725,10 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
         rb[i] = make_uint2(pack_bf16(g0 * inv, g1 * inv), pack_bf16(g2 * inv, g3 * inv));
         colsum.x += bf_lo(ra[i].x) * dden; colsum.y += bf_hi(ra[i].x) * dden;
         colsum.z += bf_lo(ra[i].y) * dden; colsum.w += bf_hi(ra[i].y) * dden;
+        if (MODE == kModeBwdH) {   // sums of the un-rounded dnum and of dden (one lane per row)
+          colsumb.x += g0 * inv; colsumb.y += g1 * inv; colsumb.z += g2 * inv; colsumb.w += g3 * inv;
+          if (c0 == 0) ssq_a += dden;
+        }
       }
     }
     const int q = q0 + t * NW * QPW;
@@ -751,6 +823,16 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
     part[kTileElems + DP] = sa;
     part[kTileElems + DP + 1] = sq;
   }
+  if (MODE == kModeBwdH) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsumb;
+    __syncthreads();
+    if (tid < DP) {
+      float s = 0.f;
+      for (int r = 0; r < SLOTS; ++r) s += fl[r * DP + tid];
+      part[kVecB + tid] = s;
+    }
+  }
 }
 
 // k_apply_bf16: out[n x d] = ar[n] (A[n x d] B[d x d]) + br[n] cvec + gr[n] E   on bf16 MFMA.
@@ -785,12 +867,15 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
   const int wr = wave / NS;
   const int d = p.d;
 
-  const float ssq_q = p.stats[p.stats_len - 2];
-  const float ssq_k = p.stats[p.stats_len - 1];
-  const float c = 1.0f / (sqrtf(ssq_q) * sqrtf(ssq_k));
-  float gconst = 0.f;
-  if (MODE == kApplyDQ) gconst = -(c * p.sdot[0]) / ssq_q;
-  if (MODE == kApplyDK) gconst = -(c * p.sdot[0]) / ssq_k;
+  float c = 1.f, gconst = 0.f, hbeta = 0.f;
+  if (MODE <= kApplyDV) {
+    const float ssq_q = p.stats[p.stats_len - 2];
+    const float ssq_k = p.stats[p.stats_len - 1];
+    c = 1.0f / (sqrtf(ssq_q) * sqrtf(ssq_k));
+    if (MODE == kApplyDQ) gconst = -(c * p.sdot[0]) / ssq_q;
+    if (MODE == kApplyDK) gconst = -(c * p.sdot[0]) / ssq_k;
+  }
+  if (MODE == kApplyHFwd) hbeta = p.beta[0];
 
   // resident strip of B: breg[s][t] = B[16 s + 8 hi + t][32 ws + i31]
   bf16x8 breg[KS];
@@ -813,6 +898,8 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
   const bool scol_ok = scol < d;
   float4 zc = zero4();
   if (MODE != kApplyDV && scol_ok) zc = *reinterpret_cast<const float4*>(p.cvec + scol);
+  float4 zd = zero4();  // HFwd: w chunk (den = h.w + beta)
+  if (MODE == kApplyHFwd && scol_ok) zd = *reinterpret_cast<const float4*>(p.dvec + scol);
 
   const uint16_t* pa = static_cast<const uint16_t*>(p.a) + scol;
   const uint16_t* pa2 = static_cast<const uint16_t*>(p.a2) + scol;
@@ -829,8 +916,10 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
       const int64_t row = tile * RT + srow0 + i * RPP;
       const bool ok = scol_ok && row < p.n;
       ra[i] = ok ? *reinterpret_cast<const uint2*>(pa + row * p.lda) : make_uint2(0u, 0u);
-      if (MODE == kApplyDQ) ra2[i] = ok ? *reinterpret_cast<const uint2*>(pa2 + row * p.lda2) : make_uint2(0u, 0u);
-      if (MODE == kApplyDQ || MODE == kApplyDV) rden[i] = (row < p.n) ? p.den[row * p.heads] : 1.f;
+      if (MODE == kApplyDQ || MODE == kApplyHBwd1)
+        ra2[i] = ok ? *reinterpret_cast<const uint2*>(pa2 + row * p.lda2) : make_uint2(0u, 0u);
+      if (MODE == kApplyDQ || MODE == kApplyDV || MODE == kApplyHBwd1)
+        rden[i] = (row < p.n) ? p.den[row * p.heads] : 1.f;
     }
   };
   auto commit = [&](int buf, int64_t tile) {
@@ -857,8 +946,29 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
         br = c * (-gdo * inv);
       } else if (MODE == kApplyDK) {
         br = c;
-      } else {
+      } else if (MODE == kApplyDV) {
         gr = p.ntot * p.gscale / rden[i];
+      } else if (MODE == kApplyHFwd) {
+        const float hw = group_sum<F4>(bf_lo(w.x) * zd.x + bf_hi(w.x) * zd.y + bf_lo(w.y) * zd.z +
+                                       bf_hi(w.y) * zd.w);
+        const float den = hw + hbeta;
+        ar = 1.0f / den;
+        br = ar;
+        gr = 0.f;
+        if (scol == 0 && row < p.n) p.den[row * p.heads] = den;
+      } else if (MODE == kApplyHBwd1) {
+        const float g0 = bf_lo(w.x), g1 = bf_hi(w.x), g2 = bf_lo(w.y), g3 = bf_hi(w.y);
+        const float gdo = group_sum<F4>(g0 * bf_lo(ra2[i].x) + g1 * bf_hi(ra2[i].x) +
+                                        g2 * bf_lo(ra2[i].y) + g3 * bf_hi(ra2[i].y));
+        const float inv = 1.0f / rden[i];
+        w = make_uint2(pack_bf16(g0 * inv, g1 * inv), pack_bf16(g2 * inv, g3 * inv));
+        ar = 1.f;
+        br = -gdo * inv;
+        gr = 0.f;
+      } else {  // HBwd2
+        ar = 1.f;
+        br = 1.f;
+        gr = 0.f;
       }
       *reinterpret_cast<uint2*>(&ldsA[(buf * RT + lrow) * LDA + scol]) = w;
       if (scol == 0) {
@@ -885,7 +995,8 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int64_t row = tile * RT + srow0 + i * RPP;
-      re[i] = (scol_ok && row < p.n) ? *reinterpret_cast<const uint2*>(pe + row * p.lde) : make_uint2(0u, 0u);
+      re[i] = (MODE <= kApplyDV && scol_ok && row < p.n) ? *reinterpret_cast<const uint2*>(pe + row * p.lde)
+                                                          : make_uint2(0u, 0u);
     }
     {
       f32x16 acc0, acc1;
@@ -921,7 +1032,7 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
           const float ar = rs[lrow], gr = rs[2 * RT + lrow];
           float4 v = make_float4(ar * c0.x + gr * e.x, ar * c0.y + gr * e.y, ar * c0.z + gr * e.z,
                                  ar * c0.w + gr * e.w);
-          if (MODE == kApplyDQ || MODE == kApplyDK) {
+          if (MODE == kApplyDQ || MODE == kApplyDK || MODE >= kApplyHFwd) {
             const float br = rs[RT + lrow];
             v.x += br * zc.x; v.y += br * zc.y; v.z += br * zc.z; v.w += br * zc.w;
           }
@@ -944,7 +1055,7 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
 // ------------------------------------------------------------------------------------------------
 // NW of k_reduce_bf16 per mode: the two-stream Gram mode fits 16 waves x 128 VGPRs without spilling
 // (twice the loads in flight); the three-stream attention modes need the 8-wave / 256-VGPR shape.
-constexpr int bf_reduce_waves(int mode) { return mode == kModeGram ? 16 : 8; }
+constexpr int bf_reduce_waves(int mode) { return mode == kModeGram ? 16 : 8; }  // BwdH: 8
 
 template <typename T, int MODE>
 inline int reduce_rows_per_tile(int DP) {
@@ -1086,6 +1197,122 @@ extern "C" int sgf_gram(const void* a, int64_t lda, int32_t m, const void* b, in
               "sgf_gram: workspace too small");
   if (dtype == SGF_F32) return gram_t<float>(a, lda, m, b, ldb, k, n, c, ldc, colsum_a, workspace, st);
   return gram_t<uint16_t>(a, lda, m, b, ldb, k, n, c, ldc, colsum_a, workspace, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention from the un-projected input (H = 1): see include/sgf.h
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t sgf_attn_h_bstats_len(int32_t d) { return static_cast<int64_t>(d) * d + 2 * d + 1; }
+
+namespace {
+template <typename T>
+int h_fwd_t(const void* h, int64_t ldh, int64_t n, int d, const float* M, const float* m, const float* w,
+            const float* beta, void* out, int64_t ldo, float* den, hipStream_t st) {
+  SGF_REQUIRE(aligned4<T>(h, ldh) && aligned4<T>(out, ldo), SGF_E_INVALID, "sgf_attn_h_fwd: alignment");
+  ApplyArgs a{};
+  a.a = h; a.lda = ldh;
+  a.out = out; a.ldo = ldo;
+  a.bmat = M; a.trans_b = 0; a.cvec = m; a.dvec = w; a.beta = beta;
+  a.den = den; a.n = n; a.d = d; a.heads = 1; a.gscale = 1.f; a.accumulate = 0;
+  return launch_apply<T, kApplyHFwd>(a, padded_dim(d), st);
+}
+
+template <typename T>
+int h_bwd_reduce_t(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo,
+                   const float* den, int64_t n, int d, float* hstats, void* ws, hipStream_t st) {
+  SGF_REQUIRE(aligned4<T>(h, ldh) && aligned4<T>(g, ldg) && aligned4<T>(o, ldo), SGF_E_INVALID,
+              "sgf_attn_h_bwd_reduce: h/g/o must be 4-element aligned with ld %% 4 == 0");
+  const int DP = padded_dim(d);
+  const int R = reduce_rows_per_tile<T, kModeBwdH>(DP);
+  const int64_t ntiles = (n + R - 1) / R;
+  const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+  ReduceArgs a{};
+  a.a = h; a.lda = ldh;
+  a.b = g; a.ldb = ldg;
+  a.q = o; a.ldq = ldo;
+  a.den = den;
+  a.n = n; a.d = d; a.db = d; a.heads = 1; a.b_heads = 1; a.gscale = 1.f;
+  a.partial = static_cast<float*>(ws);
+  int rc = launch_reduce<T, kModeBwdH>(a, DP, nblk, st);
+  if (rc != SGF_OK) return rc;
+  const int RG = reduce_row_groups<T, kModeBwdH>(DP);
+  const int64_t len = sgf_attn_h_bstats_len(d);
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, st,
+                     a.partial, nblk, d, DP, RG, hstats);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+template <typename T>
+int h_bwd_apply_t(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo,
+                  const float* den, int64_t n, int d, const float* M, const float* w, const float* D,
+                  const float* ds, void* dh, int64_t lddh, hipStream_t st) {
+  SGF_REQUIRE(aligned4<T>(h, ldh) && aligned4<T>(g, ldg) && aligned4<T>(o, ldo) && aligned4<T>(dh, lddh),
+              SGF_E_INVALID, "sgf_attn_h_bwd_apply: operands must be 4-element aligned");
+  const int DP = padded_dim(d);
+  ApplyArgs a{};
+  a.n = n; a.d = d; a.heads = 1; a.gscale = 1.f;
+  a.den = const_cast<float*>(den);
+  a.out = dh; a.ldo = lddh;
+  // dh = dnum M^T + dden w
+  a.a = g; a.lda = ldg;
+  a.a2 = o; a.lda2 = ldo;
+  a.bmat = M; a.trans_b = 1; a.cvec = w; a.accumulate = 0;
+  int rc = launch_apply<T, kApplyHBwd1>(a, DP, st);
+  if (rc != SGF_OK) return rc;
+  // dh += h D + ds
+  a.a = h; a.lda = ldh;
+  a.a2 = nullptr; a.lda2 = 0;
+  a.bmat = D; a.trans_b = 0; a.cvec = ds; a.accumulate = 1;
+  return launch_apply<T, kApplyHBwd2>(a, DP, st);
+}
+}  // namespace
+
+extern "C" int sgf_attn_h_fwd(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype,
+                              const float* M, const float* m, const float* w, const float* beta,
+                              void* out, int64_t ldo, float* den, void* stream) {
+  int rc = check_common("sgf_attn_h_fwd", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(h && M && m && w && beta && out && den, SGF_E_INVALID, "sgf_attn_h_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32) return h_fwd_t<float>(h, ldh, n, d, M, m, w, beta, out, ldo, den, st);
+  return h_fwd_t<uint16_t>(h, ldh, n, d, M, m, w, beta, out, ldo, den, st);
+}
+
+extern "C" int sgf_attn_h_bwd_reduce(const void* h, int64_t ldh, const void* g, int64_t ldg,
+                                     const void* o, int64_t ldo, const float* den, int64_t n,
+                                     int32_t d, int32_t dtype, float* hstats, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = check_common("sgf_attn_h_bwd_reduce", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(hstats, SGF_E_INVALID, "sgf_attn_h_bwd_reduce: null hstats");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(hstats, 0, sgf_attn_h_bstats_len(d) * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(h && g && o && den, SGF_E_INVALID, "sgf_attn_h_bwd_reduce: null pointer");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_attn_workspace_bytes(n, 1, d), SGF_E_WORKSPACE,
+              "sgf_attn_h_bwd_reduce: workspace too small");
+  if (dtype == SGF_F32)
+    return h_bwd_reduce_t<float>(h, ldh, g, ldg, o, ldo, den, n, d, hstats, workspace, st);
+  return h_bwd_reduce_t<uint16_t>(h, ldh, g, ldg, o, ldo, den, n, d, hstats, workspace, st);
+}
+
+extern "C" int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, int64_t ldg,
+                                    const void* o, int64_t ldo, const float* den, int64_t n, int32_t d,
+                                    int32_t dtype, const float* M, const float* w, const float* D,
+                                    const float* ds, void* dh, int64_t lddh, void* stream) {
+  int rc = check_common("sgf_attn_h_bwd_apply", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(h && g && o && den && M && w && D && ds && dh, SGF_E_INVALID,
+              "sgf_attn_h_bwd_apply: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32)
+    return h_bwd_apply_t<float>(h, ldh, g, ldg, o, ldo, den, n, d, M, w, D, ds, dh, lddh, st);
+  return h_bwd_apply_t<uint16_t>(h, ldh, g, ldg, o, ldo, den, n, d, M, w, D, ds, dh, lddh, st);
 }
 
 extern "C" int64_t sgf_attn_stats_len(int32_t heads, int32_t d) {

@@ -183,6 +183,41 @@ class HipKernels:
                       _code(q), _ptr(stats), _ptr(bstats), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk),
                       _ptr(dv), _ld(dv), _stream(dev))
 
+    # ---- T3+T4 fused: attention from the un-projected input (H = 1) ----
+    @staticmethod
+    def attn_h_fwd(h, M, m, w, beta):
+        n, d = h.shape
+        dev = h.device
+        out = torch.empty((n, d), dtype=h.dtype, device=dev)
+        den = torch.empty((n, 1), dtype=_F32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_fwd", _ptr(h), _ld(h), n, d, _code(h), _ptr(M), _ptr(m), _ptr(w),
+                      _ptr(beta), _ptr(out), out.stride(0), _ptr(den), _stream(dev))
+        return out, den
+
+    @staticmethod
+    def attn_h_bwd_reduce(h, g, o, den):
+        n, d = h.shape
+        dev = h.device
+        lib = _lib.load()
+        hstats = torch.empty(lib.sgf_attn_h_bstats_len(d), dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, 1, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_bwd_reduce", _ptr(h), _ld(h), _ptr(g), _ld(g), _ptr(o), _ld(o),
+                      _ptr(den), n, d, _code(h), _ptr(hstats), _ptr(ws), ws.numel(), _stream(dev))
+        return hstats
+
+    @staticmethod
+    def attn_h_bwd_apply(h, g, o, den, M, w, D, ds):
+        n, d = h.shape
+        dev = h.device
+        dh = torch.empty((n, d), dtype=h.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_bwd_apply", _ptr(h), _ld(h), _ptr(g), _ld(g), _ptr(o), _ld(o),
+                      _ptr(den), n, d, _code(h), _ptr(M), _ptr(w), _ptr(D), _ptr(ds), _ptr(dh),
+                      dh.stride(0), _stream(dev))
+        return dh
+
     # ---- T4: dW = a^T b, db = colsum(a) ----
     @staticmethod
     def gram(a, b, out=None, want_colsum=True):
@@ -468,6 +503,87 @@ def attention(qkv: torch.Tensor, v_ext: Optional[torch.Tensor], heads: int, d: i
     """mean_h (qn S + N V)/(qn z + N) from fused projections; see _Attention.  `n_total` overrides
     the N of large/ours.py:133 (default: the number of rows, or the global count when sharded)."""
     return _Attention.apply(qkv, v_ext, heads, d, shard, n_total)
+
+
+# ------------------------------------------------------------------------------------------------
+# T3 + T4 fused: attention straight from the un-projected input (H = 1, query == source)
+# ------------------------------------------------------------------------------------------------
+def _attn_h_small(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv):
+    """The d x d algebra of include/sgf.h (sgf_attn_h_*): fp32, tiny, differentiable torch ops.
+    G = h^T h, s = sum_n h_n over ALL rows (n_rows of them); weights [d, d_in], biases [d]."""
+    wk_s, wv_s, wq_s = wk @ s, wv @ s, wq @ s
+    s0 = wk @ G @ wv.t() + torch.outer(wk_s, bv) + torch.outer(bk, wv_s) + n_rows * torch.outer(bk, bv)
+    z0 = wk_s + n_rows * bk
+    ssq_q = ((wq @ G) * wq).sum() + 2.0 * torch.dot(bq, wq_s) + n_rows * torch.dot(bq, bq)
+    ssq_k = ((wk @ G) * wk).sum() + 2.0 * torch.dot(bk, wk_s) + n_rows * torch.dot(bk, bk)
+    c = 1.0 / (torch.sqrt(ssq_q) * torch.sqrt(ssq_k))
+    M = c * (wq.t() @ s0) + n_total * wv.t()
+    m = c * (bq @ s0) + n_total * bv
+    w = c * (wq.t() @ z0)
+    beta = (c * torch.dot(bq, z0) + n_total).reshape(1)
+    return M.contiguous(), m.contiguous(), w.contiguous(), beta.contiguous()
+
+
+class _AttentionFromInput(torch.autograd.Function):
+    """out = full_attention_conv(h Wq^T + bq, h Wk^T + bk, h Wv^T + bv) for ONE head, without ever
+    materialising Q / K / V (include/sgf.h, "attention straight from the un-projected layer
+    input").  wv / bv None = V is h itself (use_weight=False, large/ours.py:128)."""
+
+    @staticmethod
+    def forward(ctx, h, wq, bq, wk, bk, wv, bv, shard, n_override):
+        K.check(h)
+        h = _rows(h)
+        n, d = h.shape
+        f32 = [t.detach().float() for t in (wq, bq, wk, bk)]
+        if wv is None:
+            f32 += [torch.eye(d, dtype=_F32, device=h.device), torch.zeros(d, dtype=_F32, device=h.device)]
+        else:
+            f32 += [wv.detach().float(), bv.detach().float()]
+        G, s = K.gram(h, h)                       # [d, d], [d]: the only global reduction of the forward
+        n_rows = float(n)
+        if shard is not None:
+            gs = torch.cat([G.reshape(-1), s])
+            shard.all_reduce(gs)
+            G, s = gs[:d * d].reshape(d, d), gs[d * d:]
+            n_rows = float(shard.n_global)
+        n_total = n_rows if n_override is None else float(n_override)
+        M, m, w, beta = _attn_h_small(G, s, n_rows, n_total, *f32)
+        out, den = K.attn_h_fwd(h, M, m, w, beta)
+        ctx.save_for_backward(h, out, den, G, s, M, w, *f32)
+        ctx.meta = (n_rows, n_total, shard, wv is None,
+                    [None if t is None else t.dtype for t in (wq, bq, wk, bk, wv, bv)])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, out, den, G, s, M, w, *f32 = ctx.saved_tensors
+        n_rows, n_total, shard, v_is_h, dtypes = ctx.meta
+        d = h.shape[1]
+        g = _rows(g.contiguous())
+        hstats = K.attn_h_bwd_reduce(h, g, out, den)      # [dM | dw | dm | dbeta]
+        if shard is not None:
+            shard.all_reduce(hstats)
+        dM, dw_, dm = hstats[:d * d].reshape(d, d), hstats[d * d:d * d + d], hstats[d * d + d:d * d + 2 * d]
+        dbeta = hstats[d * d + 2 * d:]
+        # backward through the d x d algebra: re-run it under autograd on leaf copies (microseconds)
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) for t in (G, s, *f32)]
+            outs = _attn_h_small(leaves[0], leaves[1], n_rows, n_total, *leaves[2:])
+            grads = torch.autograd.grad(outs, leaves, grad_outputs=(dM, dm, dw_, dbeta), allow_unused=True)
+        dG, ds = grads[0], grads[1]
+        D = (dG + dG.t()).contiguous()
+        dh = K.attn_h_bwd_apply(h, g, out, den, M, w, D, ds.contiguous())
+        pg = list(grads[2:])
+        if shard is not None:   # parameter grads are summed over ranks again by ShardContext.sync_grads
+            pg = [None if t is None else shard.unsum(t) for t in pg]
+        if v_is_h:
+            pg[4] = pg[5] = None
+        pg = [None if (t is None or dt is None) else t.to(dt) for t, dt in zip(pg, dtypes)]
+        return (dh, *pg, None, None)
+
+
+def attention_from_input(h, wq, bq, wk, bk, wv=None, bv=None, shard=None, n_total=None):
+    return _AttentionFromInput.apply(h, wq, bq, wk, bk, wv, bv, shard, n_total)
 
 
 def attention_stats(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):

@@ -228,6 +228,14 @@ class TransConvLayer(nn.Module):
     def forward(self, query_input, source_input, output_attn=False):
         ops._require_cuda(query_input, source_input)
         h, d = self.num_heads, self.out_channels
+        if (h == 1 and query_input is source_input and not output_attn and query_input.shape[1] == d
+                and d % 4 == 0 and d <= 256):
+            # every recipe of the reference: one head, query == source.  Q / K / V are never
+            # materialised (ops.attention_from_input; include/sgf.h "attention straight from the
+            # un-projected layer input").
+            wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
+            return ops.attention_from_input(query_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
+                                            self.Wk.bias, wv, bv, self._shard)
         qkv = self._project(query_input, source_input)
         v_ext = None
         if not self.use_weight:

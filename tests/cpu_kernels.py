@@ -43,6 +43,27 @@ class CpuKernels:
         rows = torch.repeat_interleave(torch.arange(n_rows), counts)
         return y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
 
+    # ---- T3+T4 fused ----
+    @staticmethod
+    def attn_h_fwd(h, M, m, w, beta):
+        hf = h.float()
+        den = (hf @ w + beta).unsqueeze(1)
+        return ((hf @ M + m) / den).to(h.dtype), den.contiguous()
+
+    @staticmethod
+    def attn_h_bwd_reduce(h, g, o, den):
+        hf, gf, of = h.float(), g.float(), o.float()
+        dnum = gf / den
+        dden = -(gf * of).sum(1, keepdim=True) / den
+        return torch.cat([(hf.t() @ dnum).reshape(-1), (hf * dden).sum(0), dnum.sum(0), dden.sum().reshape(1)])
+
+    @staticmethod
+    def attn_h_bwd_apply(h, g, o, den, M, w, D, ds):
+        hf, gf, of = h.float(), g.float(), o.float()
+        dnum = gf / den
+        dden = -(gf * of).sum(1, keepdim=True) / den
+        return (dnum @ M.t() + dden * w + hf @ D + ds).to(h.dtype)
+
     # ---- T4 ----
     @staticmethod
     def gram(a, b, out=None, want_colsum=True):

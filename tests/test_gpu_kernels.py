@@ -236,6 +236,56 @@ def test_attention_bf16_forward_backward(cuda, n, h, d, shared_v):
 
 
 # ------------------------------------------------------------------------------------------------
+# T3 + T4 fused: attention from the un-projected input (sgf_attn_h_*; H = 1)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,d,use_wv,small_n", [(50, 64, True, True), (777, 64, True, False), (1000, 128, True, True),
+                                                (3000, 256, True, True), (4099, 256, True, False),
+                                                (515, 100, True, True), (2000, 256, False, True),
+                                                (20000, 256, True, True)])
+def test_attention_from_input(cuda, dtype, n, d, use_wv, small_n):
+    """out = attention(h Wq^T + bq, h Wk^T + bk, h Wv^T + bv) without materialising Q / K / V, against
+    the fp64 oracle applied to explicitly projected Q / K / V; gradients w.r.t. the input AND every
+    projection parameter (relative: dWq / dWk are ~1/N of dWv).  small n_total makes
+    the all-pair term O(1) so a kernel that ignored it would fail by orders of magnitude."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    h = (torch.relu(torch.randn(n, d, generator=g)) * 0.8 + 0.05).to(dtype)     # what the layer sees: >= 0
+    ws = [torch.randn(d, d, generator=g) / d ** 0.5 for _ in range(3)]
+    bs = [torch.randn(d, generator=g) * 0.1 for _ in range(3)]
+    n_total = 4.0 if small_n else None
+    wgt = torch.randn(n, d, generator=g).to(dtype)
+
+    hd = h.double().requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    bd = [b.double().requires_grad_(True) for b in bs]
+    q = (hd @ wd[0].t() + bd[0]).unsqueeze(1)
+    k = (hd @ wd[1].t() + bd[1]).unsqueeze(1)
+    v = (hd @ wd[2].t() + bd[2]).unsqueeze(1) if use_wv else hd.unsqueeze(1)
+    ref = O.attention(q, k, v, n_total=n_total)
+    (ref * wgt.double()).sum().backward()
+
+    hg = h.to(cuda).requires_grad_(True)
+    wg = [w.to(cuda).requires_grad_(True) for w in ws]
+    bg = [b.to(cuda).requires_grad_(True) for b in bs]
+    out = ops.attention_from_input(hg, wg[0], bg[0], wg[1], bg[1], wg[2] if use_wv else None,
+                                   bg[2] if use_wv else None, None, n_total)
+    assert out.dtype == dtype
+    (out.float() * wgt.float().to(cuda)).sum().backward()
+    f32 = dtype == torch.float32
+    assert _rel(out.float(), ref.detach()) <= (2e-6 if f32 else 6e-3)
+    assert _rel(hg.grad.float(), hd.grad) <= (2e-4 if f32 else 1.5e-2)
+    names = ["q", "k", "v"] if use_wv else ["q", "k"]
+    for i, nm in enumerate(names):
+        tol = (2e-4 if f32 else 2e-2)
+        assert wg[i].grad.dtype == torch.float32
+        assert _rel(wg[i].grad, wd[i].grad) <= tol, nm
+        assert _rel(bg[i].grad, bd[i].grad) <= tol, nm
+    if not use_wv:
+        assert wg[2].grad is None and bg[2].grad is None
+
+
+# ------------------------------------------------------------------------------------------------
 # T4 weight / bias gradients: sgf_gram
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

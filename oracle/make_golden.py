@@ -2,7 +2,7 @@
 
     python oracle/make_golden.py
 
-Imports /root/reference/{large,100M}/ours.py unchanged through oracle/ref_shim.py, runs one
+Imports /root/reference/{large,100M,medium}/ours.py (and medium/models.py) unchanged through oracle/ref_shim.py, runs one
 training-mode forward + loss + backward and one eval-mode forward in float64 (the reference's own
 arithmetic, `torch.set_default_dtype(float64)` because large/ours.py:141 creates `all_ones` in the
 default dtype), and records
@@ -137,6 +137,68 @@ def run_case(name, variant, n, f, d, c, avg_deg, directed, kw):
     return out
 
 
+MEDIUM_CASES = {
+    # medium/run.sh:2-7 (Cora recipe): 1 attention layer, GCN backbone with num_layers 4, gw 0.8, alpha 0.5
+    "cora_medium": dict(n=180, f=24, d=16, c=7, avg_deg=4.0, gcn_layers=4,
+                        cfg=dict(num_layers=1, num_heads=1, alpha=0.5, use_bn=True, use_residual=True,
+                                 use_weight=True, use_graph=True, graph_weight=0.8, aggregate="add")),
+}
+
+
+class _Data:
+    """The `data` object medium/ours.py:134-136 and medium/models.py:50-52 read."""
+
+    def __init__(self, x, ei):
+        self.graph = {"node_feat": x, "edge_index": ei, "num_nodes": x.shape[0]}
+
+
+def run_medium_case(name, n, f, d, c, avg_deg, gcn_layers, cfg):
+    ref = ref_shim.load_reference("medium")
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(4321)
+        gnn = ref.models.GCN(f, d, d, num_layers=gcn_layers, dropout=0.0, use_bn=True)
+        model = ref.SGFormer(f, d, c, dropout=0.0, gnn=gnn, **cfg).double()
+        with torch.no_grad():
+            for k_, v_ in model.state_dict().items():
+                if k_.endswith("running_mean"):
+                    v_.normal_(0, 0.1)
+                elif k_.endswith("running_var"):
+                    v_.uniform_(0.8, 1.3)
+                elif k_.endswith("bias"):
+                    v_.normal_(0.0, 0.1)          # GCNConv biases start at zero: make them count
+        x = torch.randn(n, f)
+        ei = synthetic_graph(n, avg_deg, seed=11)[:, :-n]   # medium/main.py:94 symmetrises, adds no self-loops
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: n // 2]
+        sd0 = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+        data = _Data(x, ei)
+        model.train()
+        logits = model(data)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(logits, dim=1)[idx], y[idx])
+        loss.backward()
+        grads = {k_: p.grad.detach().clone() for k_, p in model.named_parameters() if p.grad is not None}
+        sd1 = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            logits_eval = model(data)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out = {"x": x.numpy(), "edge_index": ei.numpy(), "y": y.numpy(), "train_idx": idx.numpy(),
+           "logits_train": logits.detach().numpy(), "loss": np.array(float(loss)),
+           "logits_eval": logits_eval.numpy()}
+    for k_, v_ in sd0.items():
+        out["param/" + k_] = v_.numpy()
+    for k_, v_ in sd1.items():
+        if "running" in k_:
+            out["after/" + k_] = v_.numpy()
+    for k_, g in grads.items():
+        out["grad/" + k_] = g.numpy()
+    out["meta"] = np.array(json.dumps(dict(name=name, variant="medium", n=n, f=f, d=d, c=c, avg_deg=avg_deg,
+                                           gcn_layers=gcn_layers, cfg=cfg)))
+    return out
+
+
 def main():
     if not ref_shim.reference_available():
         raise SystemExit("reference not mounted: golden vectors can only be generated in the build container")
@@ -144,6 +206,11 @@ def main():
     os.makedirs(dst, exist_ok=True)
     for name, spec in CASES.items():
         out = run_case(name, *spec)
+        path = os.path.join(dst, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")
+    for name, spec in MEDIUM_CASES.items():
+        out = run_medium_case(name, **spec)
         path = os.path.join(dst, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")

@@ -53,6 +53,69 @@ def _degree(index, num_nodes=None, dtype=None):
     return out.scatter_add_(0, index, torch.ones((index.numel(),), dtype=out.dtype, device=index.device))
 
 
+def _gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False, add_self_loops=True,
+              dtype=None):
+    """torch_geometric 1.7.2 nn/conv/gcn_conv.py gcn_norm for a LongTensor edge_index (SURVEY.md
+    App. D vii): add_remaining_self_loops(fill 1 / 2), deg = scatter_add(w, col),
+    norm = deg^-1/2[row] * w * deg^-1/2[col] with inf -> 0."""
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    if edge_weight is None:
+        edge_weight = torch.ones((edge_index.size(1),), dtype=dtype or torch.get_default_dtype(),
+                                 device=edge_index.device)
+    if add_self_loops:
+        fill = 2.0 if improved else 1.0
+        row, col = edge_index[0], edge_index[1]
+        mask = row != col
+        loop_w = torch.full((n,), fill, dtype=edge_weight.dtype, device=edge_index.device)
+        loop_w[row[~mask]] = edge_weight[~mask]            # an existing self-loop keeps its weight
+        loops = torch.arange(n, dtype=edge_index.dtype, device=edge_index.device)
+        edge_index = torch.cat([edge_index[:, mask], torch.stack([loops, loops])], dim=1)
+        edge_weight = torch.cat([edge_weight[mask], loop_w])
+    row, col = edge_index[0], edge_index[1]
+    deg = torch.zeros(n, dtype=edge_weight.dtype, device=edge_index.device).scatter_add_(0, col, edge_weight)
+    dis = deg.pow(-0.5)
+    dis.masked_fill_(dis == float("inf"), 0)
+    return edge_index, dis[row] * edge_weight * dis[col]
+
+
+class _MessagePassing(torch.nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+
+class _GCNConv(_MessagePassing):
+    """torch_geometric 1.7.2 GCNConv (defaults: improved=False, add_self_loops=True, normalize=True,
+    bias=True): out = A_norm (x @ weight) + bias, weight [in, out] glorot, bias zeros."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, add_self_loops=True,
+                 normalize=True, bias=True, **kwargs):
+        super().__init__()
+        assert normalize and add_self_loops and not improved and bias
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = torch.nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = (6.0 / (self.weight.size(-2) + self.weight.size(-1))) ** 0.5
+        self.weight.data.uniform_(-a, a)
+        self.bias.data.fill_(0)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        ei, w = _gcn_norm(edge_index, edge_weight, x.size(0), dtype=x.dtype)
+        x = x @ self.weight
+        out = torch.zeros_like(x).index_add(0, ei[1], w.to(x.dtype).unsqueeze(1) * x[ei[0]])
+        return out + self.bias
+
+
+def _placeholder(name):
+    class _P(torch.nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"stand-in: torch_geometric.nn.{name} is not on the sgformer path")
+    _P.__name__ = name
+    return _P
+
+
 def install_stand_ins():
     if "torch_sparse" not in sys.modules:
         ts = types.ModuleType("torch_sparse")
@@ -65,15 +128,49 @@ def install_stand_ins():
         tg.utils = tgu
         sys.modules["torch_geometric"] = tg
         sys.modules["torch_geometric.utils"] = tgu
+    if "torch_geometric.nn" not in sys.modules:   # medium/models.py:6-7 imports these at module level
+        tg = sys.modules["torch_geometric"]
+        tgn = types.ModuleType("torch_geometric.nn")
+        tgn.GCNConv, tgn.MessagePassing = _GCNConv, _MessagePassing
+        for nm in ("SGConv", "GATConv", "JumpingKnowledge", "APPNP"):
+            setattr(tgn, nm, _placeholder(nm))
+        tgc = types.ModuleType("torch_geometric.nn.conv")
+        tgg = types.ModuleType("torch_geometric.nn.conv.gcn_conv")
+        tgg.gcn_norm = _gcn_norm
+        tgc.gcn_conv = tgg
+        tgn.conv = tgc
+        if not hasattr(tg, "nn"):
+            tg.nn = tgn
+        sys.modules.setdefault("torch_geometric.nn", tgn)
+        sys.modules.setdefault("torch_geometric.nn.conv", tgc)
+        sys.modules.setdefault("torch_geometric.nn.conv.gcn_conv", tgg)
+
+
+def _exec(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def load_reference(variant: str = "large"):
-    """Return the reference's `ours` module for variant 'large' or '100M', executed unchanged."""
+    """Return the reference's `ours` module for variant 'large', '100M' or 'medium', executed
+    unchanged.  medium/ours.py:9 does `from models import GCN`: medium/models.py is executed unchanged
+    too (over the GCNConv stand-in) and registered as `models` for the duration of the import."""
     if not reference_available():
         raise FileNotFoundError(f"reference not found under {REFERENCE_ROOT}")
     install_stand_ins()
     path = os.path.join(REFERENCE_ROOT, variant, "ours.py")
-    spec = importlib.util.spec_from_file_location(f"_sgf_reference_{variant}_ours", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
+    if variant != "medium":
+        return _exec(path, f"_sgf_reference_{variant}_ours")
+    saved = sys.modules.get("models")
+    sys.modules["models"] = _exec(os.path.join(REFERENCE_ROOT, "medium", "models.py"), "_sgf_reference_medium_models")
+    try:
+        mod = _exec(path, "_sgf_reference_medium_ours")
+        mod.models = sys.modules["models"]
+        return mod
+    finally:
+        if saved is None:
+            del sys.modules["models"]
+        else:
+            sys.modules["models"] = saved

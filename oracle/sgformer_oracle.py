@@ -257,6 +257,70 @@ def sgformer_forward(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: d
     return _linear(p, "fc", xx)                                    # :275
 
 
+# ------------------------------------------------------------------------------------------------
+# medium variant (BASELINE.json config 1, Cora): medium/ours.py + its injected `gnn` = models.GCN,
+# a stack of PyG GCNConv layers (medium/models.py:14-63; third-party torch_geometric 1.7.2 GCNConv)
+# ------------------------------------------------------------------------------------------------
+def gcn_norm_edges(edge_index: Tensor, n: int):
+    """torch_geometric 1.7.2 gcn_norm on an unweighted graph: add_remaining_self_loops == drop the
+    existing self-loops and append one per node (fill 1).  Returns the edge_index GCNConv propagates
+    over; its weights deg^-1/2[row] * deg^-1/2[col] (deg = in-degree) are the same symmetric
+    normalisation as large/ours.py:28-31, so csr_build / gcn_propagate apply to it unchanged
+    (value differences vs PyG's deg.pow(-0.5) are last-bit only)."""
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    return torch.cat([edge_index[:, keep], torch.stack([loops, loops])], dim=1)
+
+
+def medium_gcn(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, training: bool, use_bn: bool = True,
+               bn_stats: Optional[dict] = None, pre: str = "gnn.") -> Tensor:
+    """models.GCN.forward with dropout inactive (medium/models.py:49-63): conv -> BN -> relu for all
+    but the last GCNConv; GCNConv = A_norm (x @ weight) + bias (weight [in, out])."""
+    ei = gcn_norm_edges(edge_index, x.shape[0])
+    row, col = ei[0], ei[1]
+    # gcn_norm in x's dtype: deg = scatter_add(1, col); deg^-1/2 (inf -> 0); norm = dis[row] * 1 * dis[col]
+    deg = torch.zeros(x.shape[0], dtype=x.dtype).index_add_(0, col, torch.ones(col.numel(), dtype=x.dtype))
+    dis = deg.pow(-0.5)
+    dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+    norm = (dis[row] * dis[col]).unsqueeze(1)
+    n_conv = len([k for k in p if k.startswith(pre + "convs.") and k.endswith(".weight")])
+    for i in range(n_conv):
+        xw = x @ p[f"{pre}convs.{i}.weight"]
+        x = torch.zeros_like(xw).index_add(0, col, norm * xw[row]) + p[f"{pre}convs.{i}.bias"]
+        if i < n_conv - 1:
+            if use_bn:
+                x = _batch_norm(p, f"{pre}bns.{i}", x, training, bn_stats)
+            x = torch.relu(x)
+    return x
+
+
+MEDIUM_DEFAULT_CFG = dict(num_layers=2, num_heads=1, alpha=0.5, use_bn=True, use_residual=True,
+                          use_weight=True, use_graph=True, graph_weight=0.8, aggregate="add",
+                          gnn_use_bn=True)
+
+
+def medium_forward(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict, training: bool = True,
+                   bn_stats: Optional[dict] = None) -> Tensor:
+    """medium/ours.py SGFormer.forward(data) (:202-213) with gnn = models.GCN.  The TransConv is the
+    100M flavour (alpha residual) and NEVER applies the post-layer activation: SGFormer passes its
+    arguments positionally and drops use_act (medium/ours.py:183)."""
+    c = dict(MEDIUM_DEFAULT_CFG)
+    c.update(cfg)
+    tc = dict(DEFAULT_CFG, trans_num_layers=c["num_layers"], trans_num_heads=c["num_heads"],
+              trans_use_bn=c["use_bn"], trans_use_residual=c["use_residual"],
+              trans_use_weight=c["use_weight"], trans_use_act=False, alpha=c["alpha"])
+    x1 = trans_conv(p, x, tc)
+    if c["use_graph"]:
+        x2 = medium_gcn(p, x, edge_index, training, c["gnn_use_bn"], bn_stats)
+        if c["aggregate"] == "add":
+            xx = c["graph_weight"] * x2 + (1 - c["graph_weight"]) * x1
+        else:
+            xx = torch.cat((x1, x2), dim=1)
+    else:
+        xx = x1
+    return _linear(p, "fc", xx)
+
+
 def nll_loss(logits: Tensor, y: Tensor, idx: Tensor) -> Tensor:
     """large/main.py:139-141: log_softmax + NLLLoss on the training rows."""
     lp = torch.log_softmax(logits, dim=1)

@@ -11,8 +11,9 @@ in sys.modules before sys.path.  This launcher registers the drop-in module as s
 and then executes the trainer file byte-for-byte with runpy.
 
 The variant (which constructor signature the trainer's parse.py expects) is taken from the
-trainer's directory name — `large` -> sgformer_amd.ours, `100M` -> sgformer_amd.ours_100m — or
-from --sgf-variant.  `--sgf-dtype bf16` switches every SGFormer the trainer builds to bf16
+trainer's directory name — `large` -> sgformer_amd.ours, `100M` -> sgformer_amd.ours_100m,
+`medium` -> sgformer_amd.ours_medium (which also swaps `models.GCN`, the injected GNN branch, for
+the libsgf one) — or from --sgf-variant.  `--sgf-dtype bf16` switches every SGFormer the trainer builds to bf16
 activation storage (fp32 master weights / accumulation); the default is the reference's fp32.
 """
 from __future__ import annotations
@@ -23,7 +24,7 @@ import runpy
 import sys
 
 VARIANTS = {"large": "sgformer_amd.ours", "100M": "sgformer_amd.ours_100m",
-            "100m": "sgformer_amd.ours_100m"}
+            "100m": "sgformer_amd.ours_100m", "medium": "sgformer_amd.ours_medium"}
 
 
 def install(variant: str = "large", dtype: str | None = None):
@@ -38,6 +39,17 @@ def install(variant: str = "large", dtype: str | None = None):
         raise SystemExit(f"sgformer_amd.launch: unknown --sgf-dtype {dtype!r}")
     sys.modules["ours"] = mod
     return mod
+
+
+def patch_medium_gcn():
+    """medium/parse.py:99 builds the GNN branch from the reference's own `models.GCN` (PyG GCNConv).
+    Import the trainer's `models` module (it must be importable: the trainer directory is on
+    sys.path by now) and point its `GCN` at the libsgf one, so `from models import *` in parse.py
+    picks it up — same class name, constructor and state_dict keys."""
+    import importlib as _il
+    models = _il.import_module("models")
+    models.GCN = _il.import_module("sgformer_amd.ours_medium").GCN
+    return models
 
 
 def _pop_option(argv, name):
@@ -66,13 +78,15 @@ def main(argv=None):
         variant = os.path.basename(tdir)
         if variant not in VARIANTS:
             raise SystemExit(f"sgformer_amd.launch: cannot infer the variant from directory {variant!r}; "
-                             f"pass --sgf-variant large|100M")
+                             f"pass --sgf-variant large|100M|medium")
     install(variant, dtype)
     # what `python trainer.py args...` would have set up
     sys.argv = [trainer] + argv[1:]
     if tdir in sys.path:
         sys.path.remove(tdir)
     sys.path.insert(0, tdir)
+    if variant == "medium":
+        patch_medium_gcn()
     runpy.run_path(trainer, run_name="__main__")
 
 

@@ -395,9 +395,9 @@ class _GraphCache:
         self.capacity = capacity
         self._d: "OrderedDict[tuple, CSRGraph]" = OrderedDict()
 
-    def get(self, edge_index: torch.Tensor, num_nodes: int, factory=None):
+    def get(self, edge_index: torch.Tensor, num_nodes: int, factory=None, tag=None):
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-               tuple(edge_index.stride()), str(edge_index.device), int(num_nodes))
+               tuple(edge_index.stride()), str(edge_index.device), int(num_nodes), tag)
         g = self._d.get(key)
         if g is not None:  # the entry pins its tensor, so an equal key means the same live memory
             self._d.move_to_end(key)

@@ -220,3 +220,51 @@ def test_host_tensors_are_evaluated_on_the_gpu(cuda):
     m.to(cuda)
     with torch.no_grad():
         assert torch.equal(m(x.to(cuda), ei.to(cuda)).cpu(), ref)
+
+
+class _Data:
+    def __init__(self, x, ei):
+        self.graph = {"node_feat": x, "edge_index": ei}
+
+
+@pytest.mark.parametrize("shape,gcn_layers,cfg", [
+    ((2708, 1433, 64, 7), 4, dict(num_layers=1, alpha=0.5, graph_weight=0.8)),        # Cora, medium/run.sh:2-7
+    ((900, 50, 128, 5), 2, dict(num_layers=2, num_heads=2, use_weight=False, aggregate="cat")),
+])
+def test_medium_variant_parity(cuda, shape, gcn_layers, cfg):
+    """BASELINE.json config 1: medium/ours.py SGFormer(data) with the GCN backbone (models.GCN over
+    GCNConv), Cora shape, fp32: logits within 1e-4 of the fp64 oracle, gradients relative."""
+    from sgformer_amd import ours_medium as M
+    n, f, d, c = shape
+    torch.manual_seed(7)
+    gnn = M.GCN(f, d, d, num_layers=gcn_layers, dropout=0.0)
+    m = M.SGFormer(f, d, c, dropout=0.0, gnn=gnn, **cfg)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith("bias"):
+                v.normal_(0, 0.1)
+    x = (torch.rand(n, f) < 0.02).float()                      # bag-of-words like Cora
+    x = x / x.sum(1, keepdim=True).clamp_min(1.0)
+    ei = O.synthetic_graph(n, 3.9, seed=6)[:, :-n]
+    y = torch.randint(0, c, (n,))
+    idx = torch.randperm(n)[:140]
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(cuda).train()
+    logits = m(_Data(x.to(cuda), ei.to(cuda)))
+    loss = O.nll_loss(logits, y.to(cuda), idx.to(cuda))
+    loss.backward()
+    p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    ref = O.medium_forward(p64, x.double(), ei, cfg, training=True)
+    O.nll_loss(ref, y, idx).backward()
+    assert float((logits.detach().double().cpu() - ref.detach()).abs().max()) <= 1e-4
+    for k, prm in m.named_parameters():
+        g = p64[k].grad
+        assert prm.grad is not None and g is not None, k
+        if float(g.norm()) > 1e-9:
+            rel = float((prm.grad.double().cpu() - g).norm() / g.norm())
+            assert rel <= 5e-4, (k, rel)
+    m.eval()
+    pe = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        le = m(_Data(x.to(cuda), ei.to(cuda)))
+    assert float((le.double().cpu() - O.medium_forward(pe, x.double(), ei, cfg, training=False)).abs().max()) <= 1e-4

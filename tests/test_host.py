@@ -206,3 +206,68 @@ def test_graph_cache_rules(cpu_table):
         ops.CSRGraph(torch.tensor([[0, 9], [1, 2]]), 4)
     with pytest.raises(ValueError):
         ops.CSRGraph(torch.zeros((2, 3), dtype=torch.int32), 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# medium variant (medium/ours.py + models.GCN) on the CPU kernel table
+# ------------------------------------------------------------------------------------------------
+class _Data:
+    def __init__(self, x, ei):
+        self.graph = {"node_feat": x, "edge_index": ei}
+
+
+@pytest.mark.parametrize("cfg,gcn_layers", [(dict(num_layers=1, alpha=0.5, graph_weight=0.8), 4),
+                                            (dict(num_layers=2, num_heads=2, use_weight=False, aggregate="cat"), 2)])
+def test_medium_module_matches_oracle(cpu_table, cfg, gcn_layers):
+    from sgformer_amd import ours_medium as M
+    n, f, d, c = 170, 21, 16, 5
+    torch.manual_seed(2)
+    gnn = M.GCN(f, d, d, num_layers=gcn_layers, dropout=0.0)
+    m = M.SGFormer(f, d, c, dropout=0.0, gnn=gnn, **cfg)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith("bias"):
+                v.normal_(0, 0.1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 5.0, seed=4)[:, :-n]
+    y = torch.randint(0, c, (n,))
+    idx = torch.arange(0, n, 2)
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert len(m.params1) + len(m.params2) == len(list(m.parameters()))
+    m.train()
+    logits = m(_Data(x, ei))
+    loss = O.nll_loss(logits, y, idx)
+    loss.backward()
+    p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    ref = O.medium_forward(p64, x.double(), ei, cfg, training=True)
+    O.nll_loss(ref, y, idx).backward()
+    assert float((logits.detach().double() - ref.detach()).abs().max()) <= 2e-5
+    for k, prm in m.named_parameters():
+        g = p64[k].grad
+        assert prm.grad is not None and g is not None, k
+        if float(g.norm()) > 1e-9:
+            assert _rel(prm.grad, g) <= 2e-4, k
+    m.eval()
+    pe = {k: v.detach().double() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        assert float((m(_Data(x, ei)).double() - O.medium_forward(pe, x.double(), ei, cfg, training=False)).abs().max()) <= 2e-5
+
+
+def test_medium_state_dict_matches_reference_keys():
+    """Same parameter names / shapes as medium/ours.py + models.GCN over PyG 1.7.2 GCNConv
+    (`gnn.convs.i.weight [in, out]`, `gnn.convs.i.bias`, `gnn.bns.i.*`): checkpoints interchange."""
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference not mounted")
+    from sgformer_amd import ours_medium as M
+    ref = ref_shim.load_reference("medium")
+    torch.manual_seed(0)
+    a = ref.SGFormer(30, 16, 4, num_layers=1, gnn=ref.models.GCN(30, 16, 16, num_layers=4))
+    torch.manual_seed(0)
+    b = M.SGFormer(30, 16, 4, num_layers=1, gnn=M.GCN(30, 16, 16, num_layers=4))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert sa[k].shape == sb[k].shape, k
+        assert torch.equal(sa[k], sb[k]), k          # same creation order -> same seeded init
+    b.load_state_dict(sa)

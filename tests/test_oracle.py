@@ -22,9 +22,44 @@ def _load(path):
     return z, meta
 
 
+def _medium_golden(z, meta):
+    """medium/ours.py + models.GCN fixture (BASELINE.json config 1 lineage)."""
+    cfg = meta["cfg"]
+    x, ei = torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"])
+    y, idx = torch.from_numpy(z["y"]), torch.from_numpy(z["train_idx"])
+    p = {k[6:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("param/")}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    stats = {}
+    logits = O.medium_forward(p, x, ei, cfg, training=True, bn_stats=stats)
+    assert np.abs(logits.detach().numpy() - z["logits_train"]).max() <= 1e-12
+    loss = O.nll_loss(logits, y, idx)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-12
+    loss.backward()
+    n_grad = 0
+    for k in z.files:
+        if k.startswith("grad/"):
+            g = p[k[5:]].grad
+            assert g is not None, k
+            assert np.abs(g.numpy() - z[k]).max() <= 1e-12 + 1e-9 * np.abs(z[k]).max(), k
+            n_grad += 1
+    assert n_grad >= 20
+    for key, (mu, var_unb) in stats.items():
+        assert np.abs((0.9 * p[key + ".running_mean"] + 0.1 * mu).numpy() - z["after/" + key + ".running_mean"]).max() <= 1e-12
+        assert np.abs((0.9 * p[key + ".running_var"] + 0.1 * var_unb).numpy() - z["after/" + key + ".running_var"]).max() <= 1e-12
+    pe = {k: v.detach() for k, v in p.items()}
+    for k in z.files:
+        if k.startswith("after/"):
+            pe[k[6:]] = torch.from_numpy(z[k])
+    assert np.abs(O.medium_forward(pe, x, ei, cfg, training=False).numpy() - z["logits_eval"]).max() <= 1e-12
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_matches_golden(path):
     z, meta = _load(path)
+    if meta["variant"] == "medium":
+        return _medium_golden(z, meta)
     cfg = meta["cfg"]
     x = torch.from_numpy(z["x"])
     ei = torch.from_numpy(z["edge_index"])
@@ -104,6 +139,41 @@ def test_oracle_matches_live_reference(cfg):
         m.eval()
         p = {k: v.detach().clone() for k, v in m.state_dict().items()}
         assert float((m(x, ei) - O.sgformer_forward(p, x, ei, cfg, training=False)).abs().max()) <= 1e-12
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not mounted")
+@pytest.mark.parametrize("cfg,gcn_layers", [(dict(num_layers=1, alpha=0.5, graph_weight=0.8), 4),
+                                            (dict(num_layers=2, num_heads=2, use_weight=False, aggregate="cat"), 2),
+                                            (dict(num_layers=1, use_bn=False, use_residual=False), 3)])
+def test_medium_oracle_matches_live_reference(cfg, gcn_layers):
+    """medium/ours.py and medium/models.py executed unchanged (GCNConv = the restatement in
+    oracle/ref_shim.py: torch_geometric is not installed, SURVEY.md App. D vii)."""
+    ref = ref_shim.load_reference("medium")
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(5)
+        n, f, d, c = 160, 22, 16, 6
+        gnn = ref.models.GCN(f, d, d, num_layers=gcn_layers, dropout=0.0)
+        m = ref.SGFormer(f, d, c, dropout=0.0, gnn=gnn, **cfg).double()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.endswith("bias"):
+                    v.normal_(0, 0.1)
+
+        class Data:
+            pass
+        data = Data()
+        x = torch.randn(n, f)
+        ei = O.synthetic_graph(n, 5.0, seed=9)[:, :-n]
+        data.graph = {"node_feat": x, "edge_index": ei}
+        for training in (True, False):
+            m.train(training)
+            p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            with torch.no_grad():
+                a = m(data)
+            assert float((a - O.medium_forward(p, x, ei, cfg, training=training)).abs().max()) <= 1e-12
     finally:
         torch.set_default_dtype(torch.float32)
 

@@ -258,6 +258,14 @@ int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
 int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
               int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
 
+/* y = sum_i xs[i] for 1 <= k <= 8 equally shaped [n, d] operands (fp32 accumulation in operand
+ * order).  Replaces the pairwise gradient accumulation autograd performs for a tensor with several
+ * consumers — GraphConv's x0 (large/ours.py:83-93) receives one gradient per layer from the
+ * [. | x0] Linear, one per layer from the residual and one from the first SpMM.
+ * xs / lds are HOST arrays of k device pointers / leading dimensions. */
+int sgf_sum_n(const void* const* xs_host, const int64_t* lds_host, int32_t k, int64_t n, int32_t d,
+              int32_t dtype, void* y, int64_t ldy, void* stream);
+
 /* Column sum out[j] = sum_n x[n,j] for ANY 1 <= d <= 256 (no multiple-of-4 requirement): the bias
  * gradient of the output layer, large/ours.py:275 under autograd, where d = number of classes
  * (47 for ogbn-products).  fp32 result, deterministic two-stage reduction. */

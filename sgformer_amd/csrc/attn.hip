@@ -841,11 +841,11 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
 // tile.  A tiles are staged row-major (stride DP + 8 bf16: conflict-free ds_read_b128 fragments);
 // the accumulators go through an fp32 LDS tile so that E is loaded and `out` stored row-wise,
 // 8 bytes per lane, fully coalesced.
-template <int DP, int MODE>
-__global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
+template <int DP, int MODE, int RB>
+__global__ __launch_bounds__(kBfThreads, RB == 1 ? 4 : 2) void k_apply_bf16(ApplyArgs p) {
   constexpr int NS = DP / 32;             // strips (8 / 4 / 2)
   constexpr int RGW = 8 / NS;             // row groups of waves (1 / 2 / 4)
-  constexpr int RT = 64 * RGW;            // rows per tile (64 / 128 / 256)
+  constexpr int RT = 32 * RB * RGW;       // rows per tile (RB = 2: 64 / 128 / 256)
   constexpr int F4 = DP / 4;              // lanes per row in the staging / epilogue map
   constexpr int RPP = kBfThreads / F4;    // rows per staging pass (8 / 16 / 32)
   constexpr int NP = RT / RPP;            // staging passes (8)
@@ -999,25 +999,25 @@ __global__ __launch_bounds__(kBfThreads) void k_apply_bf16(ApplyArgs p) {
                                                           : make_uint2(0u, 0u);
     }
     {
-      f32x16 acc0, acc1;
+      f32x16 acc[RB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      const uint16_t* A0 = ldsA + (buf * RT + 64 * wr + i31) * LDA + 8 * hi;
-      const uint16_t* A1 = A0 + 32 * LDA;
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      const uint16_t* A0 = ldsA + (buf * RT + 32 * RB * wr + i31) * LDA + 8 * hi;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(A0 + 16 * s);
-        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(A1 + 16 * s);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, breg[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, breg[s], acc1, 0, 0, 0);
-      }
-      float* C0 = ldsC + (64 * wr + 4 * hi) * LDC + 32 * ws + i31;
-      float* C1 = C0 + 32 * LDC;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        C0[((r & 3) + 8 * (r >> 2)) * LDC] = acc0[r];
-        C1[((r & 3) + 8 * (r >> 2)) * LDC] = acc1[r];
+        for (int b = 0; b < RB; ++b) {
+          const bf16x8 xa = *reinterpret_cast<const bf16x8*>(A0 + b * 32 * LDA + 16 * s);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, breg[s], acc[b], 0, 0, 0);
+        }
       }
+      float* C0 = ldsC + (32 * RB * wr + 4 * hi) * LDC + 32 * ws + i31;
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) C0[(b * 32 + (r & 3) + 8 * (r >> 2)) * LDC] = acc[b][r];
     }
     __syncthreads();
     {
@@ -1093,18 +1093,23 @@ int launch_reduce(const ReduceArgs& args, int DP, int nblk, hipStream_t st) {
   return SGF_OK;
 }
 
+// 32-row blocks per wave in k_apply_bf16: 1 -> ~68 KiB LDS, 128 VGPRs: TWO independent blocks per CU
+// whose MFMA / epilogue phases interleave; 2 -> one 135 KiB block per CU with twice the tile.
+constexpr int kApplyRB = 2;  // RB = 1 spills at DP = 256 (the resident B strip alone is 64 VGPRs of the 128)
+
 template <typename T, int MODE>
 int launch_apply(const ApplyArgs& args, int DP, hipStream_t st) {
-  // rows per tile: k_attn_apply 32 * (8 / (DP/32));  k_apply_bf16 64 * (8 / (DP/32))
-  const int RT = (sizeof(T) == 4 ? 32 : 64) * (8 / (DP / 32));
+  // rows per tile: k_attn_apply 32 * (8 / (DP/32));  k_apply_bf16 32 * kApplyRB * (8 / (DP/32))
+  const int RT = (sizeof(T) == 4 ? 32 : 32 * kApplyRB) * (8 / (DP / 32));
   int64_t ntiles = (args.n + RT - 1) / RT;
-  const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+  const int64_t maxblk = (sizeof(T) == 2 && kApplyRB == 1) ? 2 * kMaxBlocks : kMaxBlocks;
+  const int nblk = static_cast<int>(ntiles < maxblk ? ntiles : maxblk);
   const dim3 grid(nblk), block(sizeof(T) == 2 ? kBfThreads : kApplyThreads);
   if (sizeof(T) == 2) {
     switch (DP) {
-      case 64: hipLaunchKernelGGL((k_apply_bf16<64, MODE>), grid, block, 0, st, args); break;
-      case 128: hipLaunchKernelGGL((k_apply_bf16<128, MODE>), grid, block, 0, st, args); break;
-      default: hipLaunchKernelGGL((k_apply_bf16<256, MODE>), grid, block, 0, st, args); break;
+      case 64: hipLaunchKernelGGL((k_apply_bf16<64, MODE, kApplyRB>), grid, block, 0, st, args); break;
+      case 128: hipLaunchKernelGGL((k_apply_bf16<128, MODE, kApplyRB>), grid, block, 0, st, args); break;
+      default: hipLaunchKernelGGL((k_apply_bf16<256, MODE, kApplyRB>), grid, block, 0, st, args); break;
     }
   } else {
     switch (DP) {

@@ -322,6 +322,19 @@ class HipKernels:
                       _stream(dev))
         return out
 
+    @staticmethod
+    def sum_n(xs) -> torch.Tensor:
+        """sum of up to 8 equally shaped [n, d] tensors in one pass."""
+        xs = [_rows(x) for x in xs]
+        n, d = xs[0].shape
+        y = torch.empty((n, d), dtype=xs[0].dtype, device=xs[0].device)
+        k = len(xs)
+        ptrs = (ctypes.c_void_p * k)(*[x.data_ptr() for x in xs])
+        lds = (ctypes.c_int64 * k)(*[x.stride(0) for x in xs])
+        with torch.cuda.device(y.device):
+            _lib.call("sgf_sum_n", ptrs, lds, k, n, d, _code(y), _ptr(y), y.stride(0), _stream(y.device))
+        return y
+
     # ---- T7 ----
     @staticmethod
     def axpby(x1, a: float, x2, b: float) -> torch.Tensor:
@@ -697,6 +710,37 @@ def bn_act_res(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard=Non
 
 
 # ------------------------------------------------------------------------------------------------
+# fan-out hub: one tensor, k consumers, ONE fused gradient sum (instead of k-1 pairwise ATen adds)
+# ------------------------------------------------------------------------------------------------
+class _FanOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k: int):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if gs[0].shape[1] % 4 != 0 or len(gs) > 8:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        return K.sum_n(gs), None
+
+
+def fan_out(x: torch.Tensor, k: int):
+    """k aliases of x whose gradients are summed in one pass (K.sum_n) in the backward."""
+    if k <= 1 or not x.requires_grad:
+        return tuple(x for _ in range(max(k, 1)))
+    return _FanOut.apply(x, k)
+
+
+# ------------------------------------------------------------------------------------------------
 # T7: y = a*x1 + b*x2   (large/ours.py:269-270)
 # ------------------------------------------------------------------------------------------------
 class _Axpby(torch.autograd.Function):
@@ -741,10 +785,12 @@ class _Linear(torch.autograd.Function):
         if len(xs) == 1:
             y = torch.nn.functional.linear(xs[0], wc, bc)
         else:
-            y, off = bc, 0
-            for x, k in zip(xs, widths):
-                wt = wc[:, off:off + k].t()
-                y = x @ wt if y is None else torch.addmm(y, x, wt)
+            # first operand with the bias, the rest accumulated IN PLACE (torch.addmm(y, ...) out of
+            # place first copies y into the result: a 1.25 GB memcpy per call at products scale)
+            y = torch.addmm(bc, xs[0], wc[:, :widths[0]].t()) if bc is not None else xs[0] @ wc[:, :widths[0]].t()
+            off = widths[0]
+            for x, k in zip(xs[1:], widths[1:]):
+                y.addmm_(x, wc[:, off:off + k].t())
                 off += k
         ctx.save_for_backward(wc, *xs)
         ctx.meta = (w.dtype, None if b is None else b.dtype, widths)

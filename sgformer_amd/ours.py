@@ -188,10 +188,16 @@ class GraphConv(nn.Module):
         ops._require_cuda(x, edge_index)
         x = _lin(x, self.fcs[0])
         x = self._stage(self.bns[0], x, None, True)
-        x0 = x
+        # x0 = layer_[0] has up to 2 consumers per layer (the [. | x0] Linear and the residual) plus
+        # the first SpMM: hand out aliases through a hub whose backward sums all their gradients in
+        # ONE pass (ops.fan_out) instead of autograd's pairwise adds
+        uses_init = [c.use_init for c in self.convs]
+        k = 1 + sum(uses_init) + (len(self.convs) if self.use_residual else 0)
+        hub = list(ops.fan_out(x, k)) if k <= 8 else [x] * k
+        x = hub.pop()
         for i, conv in enumerate(self.convs):
-            x = conv(x, edge_index, x0)
-            x = self._stage(self.bns[i + 1], x, x0 if self.use_residual else None, self.use_act)
+            x = conv(x, edge_index, hub.pop() if uses_init[i] else None)
+            x = self._stage(self.bns[i + 1], x, hub.pop() if self.use_residual else None, self.use_act)
         return x
 
 

@@ -64,6 +64,13 @@ class CpuKernels:
         dden = -(gf * of).sum(1, keepdim=True) / den
         return (dnum @ M.t() + dden * w + hf @ D + ds).to(h.dtype)
 
+    @staticmethod
+    def sum_n(xs):
+        out = xs[0].float()
+        for x in xs[1:]:
+            out = out + x.float()
+        return out.to(xs[0].dtype)
+
     # ---- T4 ----
     @staticmethod
     def gram(a, b, out=None, want_colsum=True):

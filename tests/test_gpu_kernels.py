@@ -427,6 +427,24 @@ def test_axpby(cuda):
     assert torch.allclose(y, 0.8 * a + 0.2 * b, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k", [2, 3, 7, 8])
+def test_sum_n_and_fan_out(cuda, dtype, k):
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(k)
+    xs = [torch.randn(999, 100, generator=g).to(dtype) for _ in range(k)]
+    got = ops.K.sum_n([x.to(cuda) for x in xs])
+    ref = sum(x.double() for x in xs)
+    assert got.dtype == dtype
+    assert _rel(got.float(), ref) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    # the hub: k consumers, one fused gradient sum
+    x = xs[0].to(cuda).requires_grad_(True)
+    outs = ops.fan_out(x, k)
+    ws = [torch.randn(999, 100, generator=g).to(dtype).to(cuda) for _ in range(k)]
+    sum((o.float() * w.float()).sum() for o, w in zip(outs, ws)).backward()
+    assert _rel(x.grad.float(), sum(w.double().cpu() for w in ws)) <= (1e-6 if dtype == torch.float32 else 4e-3)
+
+
 def test_cpu_tensor_is_rejected():
     from sgformer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):

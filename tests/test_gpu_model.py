@@ -268,3 +268,67 @@ def test_medium_variant_parity(cuda, shape, gcn_layers, cfg):
     with torch.no_grad():
         le = m(_Data(x.to(cuda), ei.to(cuda)))
     assert float((le.double().cpu() - O.medium_forward(pe, x.double(), ei, cfg, training=False)).abs().max()) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs 2-5 at full hidden width, through size-independent properties
+# ------------------------------------------------------------------------------------------------
+def _recipe(name):
+    from sgformer_amd import synth
+    return dict(synth.RECIPES[name])
+
+
+@pytest.mark.parametrize("name,n,f,d,c,deg,dtype", [
+    ("ogbn-arxiv", 40000, 128, 256, 40, 13.7, torch.float32),       # config 2
+    ("ogbn-products", 60000, 100, 256, 47, 50.5, torch.bfloat16),   # config 3
+    ("pokec", 50000, 65, 256, 2, 27.3, torch.float32),              # config 4 (labels contain -1)
+])
+def test_baseline_configs_properties(cuda, name, n, f, d, c, deg, dtype):
+    """Recipes of large/run.sh at the hidden width BASELINE.json names, on graphs too large for the
+    fp64 oracle to be cheap: (1) node-permutation equivariance — relabelling the nodes permutes the
+    logits and leaves the loss unchanged (every reduction in the path is over all nodes, so this
+    exercises CSR build, SpMM, both attention reductions and BatchNorm statistics at once);
+    (2) all gradients finite, fp32 master grads; (3) a first-order check of the whole backward: a
+    gradient step sized for a 2 % decrease of the loss decreases it by about 2 %."""
+    from sgformer_amd.ours import SGFormer
+    cfg = _recipe(name)
+    torch.manual_seed(11)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, deg, seed=13)
+    y = torch.randint(0, c, (n,))
+    if name == "pokec":
+        y[torch.rand(n) < 0.3] = -1                                  # unlabeled nodes (large/data_utils.py:15-16)
+    labeled = (y >= 0).nonzero().view(-1)
+    idx = labeled[torch.randperm(labeled.numel())[: labeled.numel() // 2]]
+    m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
+                 compute_dtype=None if dtype == torch.float32 else dtype, **cfg).to(cuda).train()
+    xg, eig, yg, idxg = x.to(cuda), ei.to(cuda), y.to(cuda), idx.to(cuda)
+    logits = m(xg, eig)
+    loss = O.nll_loss(logits, yg, idxg)
+    # (1) permutation equivariance
+    perm = torch.randperm(n)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    xp, eip = x[perm], inv[ei]                                       # new id of old node v is inv[v]
+    logits_p = m(xp.to(cuda), eip.to(cuda))
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    scale = float(logits.detach().abs().max())
+    assert float((logits_p.detach()[inv.to(cuda)] - logits.detach()).abs().max()) <= tol * max(scale, 1.0)
+    # (2) + (3): all gradients finite and fp32; and a directional-derivative check of the WHOLE backward:
+    # a plain gradient step sized for a 0.4 % first-order decrease must decrease the loss by about that
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    ps = [prm for prm in m.parameters() if prm.grad is not None]
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            assert prm.grad.dtype == torch.float32 and bool(torch.isfinite(prm.grad).all()), k
+    gnorm2 = float(sum((prm.grad.double() ** 2).sum() for prm in ps))
+    l0 = float(loss)
+    frac = 0.004                                   # small enough for the first-order model to hold
+    eps = frac * l0 / gnorm2
+    with torch.no_grad():
+        for prm in ps:
+            prm.add_(prm.grad, alpha=-eps)
+        l1 = float(O.nll_loss(m(xg, eig), yg, idxg))
+    lo, hi = (0.75, 1.25) if dtype == torch.float32 else (0.5, 1.5)
+    assert lo * frac * l0 <= l0 - l1 <= hi * frac * l0, (l0, l1, frac * l0)

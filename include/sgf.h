@@ -76,6 +76,31 @@ int sgf_csr_transpose(const int64_t* edge_index, int64_t nnz, int64_t n, const i
                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N1 — induced subgraph of a node subset, the per-mini-batch step of the reference's
+ * random-partition trainer.   Replaces torch_geometric.utils.subgraph(idx_i, edge_index, num_nodes=n,
+ * relabel_nodes=True) at large/main-batch.py:139 and large/eval.py:94 (third-party PyG 1.7.2, run on
+ * the HOST by the reference: an O(E) mask + filter over all edges for every batch):
+ *     keep edge e iff both endpoints are in `subset`; kept edges stay in their ORIGINAL ORDER;
+ *     with relabel_nodes, node subset[j] becomes j.
+ * Two calls around one host read of the output size:
+ *     sgf_subgraph_plan : relabel[v] = position of v in subset (-1 = absent; int32 [n], out),
+ *                         *total (device int64) = number of kept edges; per-block offsets stay in
+ *                         `workspace`, which must be passed unchanged to
+ *     sgf_subgraph_emit : out int64 [2, total] (row 0 sources, row 1 targets); out_eid int64 [total]
+ *                         (optional, NULL to skip) = position of each kept edge in edge_index, for
+ *                         filtering edge attributes.
+ * `subset` must hold distinct node ids (the trainer's are slices of a permutation).  Ids outside
+ * [0, n) never match.  n < 2^31.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_subgraph_workspace_bytes(int64_t nnz, int64_t n);
+int sgf_subgraph_plan(const int64_t* edge_index, int64_t nnz, int64_t n, const int64_t* subset,
+                      int64_t m, int32_t* relabel, int64_t* total, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int sgf_subgraph_emit(const int64_t* edge_index, int64_t nnz, int64_t n, const int32_t* relabel,
+                      int32_t relabel_nodes, int64_t total, int64_t* out, int64_t* out_eid,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * T2 — sum-reduce CSR SpMM.   Replaces torch_sparse.matmul(adj, x) at large/ours.py:34
  * (third-party torch_sparse 0.6.10 spmm, reduce="sum"):  Y[i,:] = sum_e val[e] * X[colind[e],:]
  * for e in [rowptr[i], rowptr[i+1]), accumulated in fp32 in stored order.

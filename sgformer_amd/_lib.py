@@ -25,6 +25,9 @@ SIGNATURES = {
     "sgf_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_csr_build": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_csr_transpose": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_subgraph_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgf_subgraph_plan": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "sgf_subgraph_emit": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
     "sgf_spmm": (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P]),
     "sgf_attn_stats_len": (c_int64, [c_int32, c_int32]),
     "sgf_attn_bstats_len": (c_int64, [c_int32, c_int32]),

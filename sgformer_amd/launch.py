@@ -15,6 +15,8 @@ trainer's directory name — `large` -> sgformer_amd.ours, `100M` -> sgformer_am
 `medium` -> sgformer_amd.ours_medium (which also swaps `models.GCN`, the injected GNN branch, for
 the libsgf one) — or from --sgf-variant.  `--sgf-dtype bf16` switches every SGFormer the trainer builds to bf16
 activation storage (fp32 master weights / accumulation); the default is the reference's fp32.
+For `main-batch.py` the per-batch `torch_geometric.utils.subgraph` call is served by the GPU
+implementation in sgformer_amd.batching (`--sgf-host-subgraph 1` keeps PyG's host version).
 """
 from __future__ import annotations
 
@@ -52,6 +54,16 @@ def patch_medium_gcn():
     return models
 
 
+def patch_subgraph():
+    """Point torch_geometric.utils.subgraph at the GPU implementation (sgformer_amd.batching) before
+    the trainer imports it (large/main-batch.py:8, large/eval.py:4): the per-batch induced subgraph
+    then runs on the MI355X instead of as an O(E) host pass per batch."""
+    import importlib as _il
+    tgu = _il.import_module("torch_geometric.utils")
+    tgu.subgraph = _il.import_module("sgformer_amd.batching").subgraph
+    return tgu
+
+
 def _pop_option(argv, name):
     for i, a in enumerate(argv):
         if a == name and i + 1 < len(argv):
@@ -68,6 +80,7 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     variant = _pop_option(argv, "--sgf-variant")
     dtype = _pop_option(argv, "--sgf-dtype")
+    host_subgraph = _pop_option(argv, "--sgf-host-subgraph")   # any value: keep PyG's host subgraph
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -87,6 +100,8 @@ def main(argv=None):
     sys.path.insert(0, tdir)
     if variant == "medium":
         patch_medium_gcn()
+    if host_subgraph is None and os.path.basename(trainer) == "main-batch.py":
+        patch_subgraph()
     runpy.run_path(trainer, run_name="__main__")
 
 

@@ -123,6 +123,25 @@ class HipKernels:
                       _stream(dev))
         return t_rowptr, t_colind, t_val, bool(int(flag.item()))  # one host sync, once per graph
 
+    # ---- N1: induced subgraph ----
+    @staticmethod
+    def subgraph(ei: torch.Tensor, n: int, subset: torch.Tensor, relabel_nodes: bool, want_eid: bool):
+        """ei int64 [2, nnz] and subset int64 [m] on the GPU -> (edge_index_sub [2, k], eid [k] | None)."""
+        dev, nnz, m = ei.device, int(ei.shape[1]), int(subset.numel())
+        lib = _lib.load()
+        relabel = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = _workspace(dev, "subgraph", lib.sgf_subgraph_workspace_bytes(nnz, n))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_subgraph_plan", _ptr(ei), nnz, n, _ptr(subset), m, _ptr(relabel), _ptr(total),
+                      _ptr(ws), ws.numel(), _stream(dev))
+            k = int(total.item())              # the one host sync: the output size
+            out = torch.empty((2, k), dtype=torch.int64, device=dev)
+            eid = torch.empty(k, dtype=torch.int64, device=dev) if want_eid else None
+            _lib.call("sgf_subgraph_emit", _ptr(ei), nnz, n, _ptr(relabel), int(relabel_nodes), k, _ptr(out),
+                      _ptr(eid), _ptr(ws), ws.numel(), _stream(dev))
+        return out, eid
+
     # ---- T2 ----
     @staticmethod
     def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int) -> torch.Tensor:

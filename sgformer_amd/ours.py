@@ -38,6 +38,18 @@ _NO_SHARD = None
 # torch.bfloat16 so that an unchanged trainer gets the bf16 mode of BASELINE.json config 3.
 DEFAULT_COMPUTE_DTYPE = None
 
+# Run the attention branch on a side HIP stream next to the GCN branch (SGF_OVERLAP=0 disables).
+import os as _os
+OVERLAP_BRANCHES = _os.environ.get("SGF_OVERLAP", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
+
 
 def _lin(x, lin: nn.Linear):
     """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
@@ -361,6 +373,7 @@ class SGFormer(nn.Module):
         self.use_graph = use_graph
         self.graph_weight = graph_weight
         self.aggregate = aggregate
+        self.overlap_branches = OVERLAP_BRANCHES
         if aggregate == 'add':
             self.fc = nn.Linear(hidden_channels, out_channels)
         elif aggregate == 'cat':
@@ -396,9 +409,23 @@ class SGFormer(nn.Module):
         out_dtype = x.dtype
         if self.compute_dtype is not None and x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
-        x1 = self.trans_conv(x)
-        if self.use_graph:
+        if self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None:
+            # The two branches are independent until the combine: run the attention branch on a side
+            # HIP stream so that its latency-bound kernels fill the gaps of the GCN branch (autograd
+            # replays each backward node on its forward stream, so the backward overlaps too).
+            cur = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                x1 = self.trans_conv(x)
+            x.record_stream(side)
             x2 = self.graph_conv(x, edge_index)
+            cur.wait_stream(side)
+            x1.record_stream(cur)
+        else:
+            x1 = self.trans_conv(x)
+            x2 = self.graph_conv(x, edge_index) if self.use_graph else None
+        if self.use_graph:
             if self.aggregate == 'add':
                 gw = float(self.graph_weight)
                 x = ops.axpby(x2, x1, gw, 1.0 - gw)

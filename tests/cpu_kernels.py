@@ -33,6 +33,19 @@ class CpuKernels:
         return (torch.from_numpy(t_rowptr), torch.from_numpy(t_colind.astype(np.int32)),
                 torch.from_numpy(t_val), sym)
 
+    # ---- N1 ----
+    @staticmethod
+    def subgraph(ei, n, subset, relabel_nodes, want_eid):
+        mask_n = torch.zeros(n, dtype=torch.bool)
+        mask_n[subset] = True
+        keep = mask_n[ei[0]] & mask_n[ei[1]]
+        out = ei[:, keep]
+        if relabel_nodes:
+            idx = torch.zeros(n, dtype=torch.int64)
+            idx[subset] = torch.arange(subset.numel())
+            out = idx[out]
+        return out, (keep.nonzero().view(-1) if want_eid else None)
+
     # ---- T2 ----
     @staticmethod
     def spmm(rowptr, colind, val, x, n_rows):

@@ -445,6 +445,62 @@ def test_sum_n_and_fan_out(cuda, dtype, k):
     assert _rel(x.grad.float(), sum(w.double().cpu() for w in ws)) <= (1e-6 if dtype == torch.float32 else 4e-3)
 
 
+# ------------------------------------------------------------------------------------------------
+# N1 induced subgraph (sgf_subgraph_*): bit-exact against the PyG 1.7.2 semantics
+# ------------------------------------------------------------------------------------------------
+def _ref_subgraph(subset, ei, n, relabel):
+    mask_n = torch.zeros(n, dtype=torch.bool)
+    mask_n[subset] = True
+    keep = mask_n[ei[0]] & mask_n[ei[1]]
+    out = ei[:, keep]
+    if relabel:
+        idx = torch.zeros(n, dtype=torch.int64)
+        idx[subset] = torch.arange(subset.numel())
+        out = idx[out]
+    return out, keep
+
+
+@pytest.mark.parametrize("n,nnz,m", [(1000, 20000, 300), (50000, 1500000, 7000), (257, 513, 257), (100, 4000, 0),
+                                     (3000, 0, 50), (200000, 3000001, 60000)])
+@pytest.mark.parametrize("relabel", [True, False])
+def test_subgraph_bit_exact(cuda, n, nnz, m, relabel):
+    from sgformer_amd import batching
+    g = torch.Generator().manual_seed(n + nnz + m)
+    ei = torch.randint(0, n, (2, nnz), generator=g)            # duplicates and self-loops included
+    subset = torch.randperm(n, generator=g)[:m]
+    ref, keep = _ref_subgraph(subset, ei, n, relabel)
+    w = torch.randn(nnz, generator=g)
+    # host edge_index (what the trainer passes): staged once, result on the GPU
+    out, attr = batching.subgraph(subset, ei, edge_attr=w, relabel_nodes=relabel, num_nodes=n)
+    assert out.is_cuda and out.dtype == torch.int64 and out.shape == ref.shape
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(attr.cpu(), w[keep])
+    # device inputs, bool-mask subset, no attributes
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[subset] = True
+    out2, none = batching.subgraph(mask.to(cuda), ei.to(cuda), relabel_nodes=False, num_nodes=n)
+    assert none is None and torch.equal(out2.cpu(), _ref_subgraph(subset, ei, n, False)[0])
+
+
+def test_subgraph_feeds_the_model(cuda):
+    """large/main-batch.py:138-143 on the GPU: gather the batch rows, cut the induced subgraph, run
+    the model on it — identical logits to the host-side PyG-semantics cut."""
+    from sgformer_amd import batching
+    from sgformer_amd.ours import SGFormer
+    n, f, d, c = 4000, 16, 64, 5
+    torch.manual_seed(0)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 12.0, seed=3)
+    idx = torch.randperm(n)[:1500]
+    m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, gnn_num_layers=2, gnn_use_init=True).to(cuda).eval()
+    ei_ref, _ = _ref_subgraph(idx, ei, n, True)
+    ei_gpu, _ = batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)
+    with torch.no_grad():
+        a = m(x[idx].to(cuda), ei_ref.to(cuda))
+        b = m(x[idx].to(cuda), ei_gpu)
+    assert torch.equal(a, b)
+
+
 def test_cpu_tensor_is_rejected():
     from sgformer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -37,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from sgformer_amd import ops, synth  # noqa: E402
+from sgformer_amd.loss import log_softmax_nll  # noqa: E402
 from sgformer_amd.dist import ShardContext, shard_model, sharded_nll_loss  # noqa: E402
 from sgformer_amd.ours import SGFormer  # noqa: E402
 
@@ -61,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-sample-nodes", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--aten-loss", action="store_true",
+                    help="time the step with the trainer's own F.log_softmax + F.nll_loss (5 ATen kernels) "
+                         "instead of sgformer_amd.loss.log_softmax_nll")
     ap.add_argument("--no-locality-probe", action="store_true",
                     help="skip the SpMM-only measurement on the locality-structured graph")
     return ap.parse_args()
@@ -235,13 +239,17 @@ def main():
                             {"params": model.params2, "weight_decay": 1e-5}], lr=0.01)
     model.train()
 
+    aten_loss = args.aten_loss
+
     def step():
         opt.zero_grad(set_to_none=True)
         logits = model(x, ei)
-        if ctx is None:
+        if ctx is not None:
+            loss = sharded_nll_loss(logits, y, train_idx, n_train)
+        elif aten_loss:   # the three lines of large/main.py:139-141 as the trainer writes them
             loss = F.nll_loss(F.log_softmax(logits.float(), dim=1)[train_idx], y[train_idx])
-        else:
-            loss = sharded_nll_loss(logits.float(), y, train_idx, n_train)
+        else:             # the same arithmetic in one pass (sgf_nll_fwd / sgf_nll_bwd)
+            loss = log_softmax_nll(logits, y, train_idx)
         loss.backward()
         if ctx is not None:
             ctx.sync_grads(model.parameters())
@@ -266,7 +274,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    timer.active = False
+    timer.active = False   # (the extra ATen-loss steps below are not part of the roofline sample)
     loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -276,6 +284,18 @@ def main():
         dist.all_reduce(lt)
         loss_val = float(lt)
 
+    ms_aten = None
+    if world == 1 and not aten_loss:
+        # transparency: the same step with the trainer's own ATen loss ops
+        aten_loss = True
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(min(args.steps, 5)):
+            step()
+        fence()
+        ms_aten = (time.perf_counter() - t1) / min(args.steps, 5) * 1e3
+        aten_loss = False
     roof = timer.summary()
     if roof is not None and world == 1 and not args.nodes and (args.workload, args.dtype) in PMC_SPMM_TRAFFIC:
         roof["traffic"], roof["traffic_source"] = PMC_SPMM_TRAFFIC[(args.workload, args.dtype)]
@@ -288,14 +308,17 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "SGFormer fwd+bwd nodes/sec on ogbn-products full-graph",
+            "metric": f"SGFormer fwd+bwd nodes/sec on {args.workload} full-graph",
             "value": n * args.steps / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped uniform random graph, full-graph "
-                                   f"training step (fwd + log_softmax/NLL + bwd + Adam), "
-                                   f"large/run.sh:15-19 recipe, dropout 0",
+                                   f"training step (fwd + log_softmax/NLL on the training rows + bwd + Adam), "
+                                   f"large/run.sh recipe, dropout 0",
+                       "loss": "F.log_softmax + F.nll_loss (ATen, as large/main.py:139-141 writes it)" if args.aten_loss
+                               else "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
+                       "ms_per_step_with_aten_loss": None if ms_aten is None else round(ms_aten, 3),
                        "nodes": n, "nnz": int(ei.shape[1]), "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
                        "debug_override": bool(args.nodes)},

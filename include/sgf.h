@@ -283,6 +283,27 @@ int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
 int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
               int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * N4 — the trainer's loss.   Replaces large/main.py:139-141
+ *     out = F.log_softmax(out, dim=1);  loss = NLLLoss()(out[train_idx], label.squeeze(1)[train_idx])
+ * (5 ATen kernels over [N, C] and [M, C] temporaries; its nll_loss forward / backward kernels alone
+ * cost 4.2 ms per step at ogbn-products scale) as one pass over the M training rows:
+ *     sgf_nll_fwd : loss_sum[0] = - sum_j log_softmax(logits[idx[j]])[labels[idx[j]]]   (fp32; the
+ *                   caller divides by M, or by the GLOBAL count when node-sharded)
+ *     sgf_nll_bwd : dlogits = 0 everywhere except rows idx[j], where
+ *                   dlogits = gout[0] * inv_denom * (softmax(logits[row]) - onehot(label))
+ * logits / dlogits: [n, c] storage dtype with leading dims ldl / ldd; labels int64 [n] (indexed by
+ * NODE id); idx int64 [m] distinct rows; gout fp32 [1] on the device.  Labels outside [0, c) add
+ * nothing to the loss.  Deterministic (per-block partials, fixed-order sum).
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_nll_workspace_bytes(int64_t m);
+int sgf_nll_fwd(const void* logits, int64_t ldl, int64_t n, int32_t c, int32_t dtype,
+                const int64_t* labels, const int64_t* idx, int64_t m, float* loss_sum,
+                void* workspace, size_t workspace_bytes, void* stream);
+int sgf_nll_bwd(const void* logits, int64_t ldl, int64_t n, int32_t c, int32_t dtype,
+                const int64_t* labels, const int64_t* idx, int64_t m, const float* gout,
+                float inv_denom, void* dlogits, int64_t ldd, void* stream);
+
 /* y = sum_i xs[i] for 1 <= k <= 8 equally shaped [n, d] operands (fp32 accumulation in operand
  * order).  Replaces the pairwise gradient accumulation autograd performs for a tensor with several
  * consumers — GraphConv's x0 (large/ours.py:83-93) receives one gradient per layer from the

@@ -64,6 +64,10 @@ SIGNATURES = {
                                    c_int32, _P, _P, c_size_t, _P]),
     "sgf_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float,
                                    c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
+    "sgf_nll_workspace_bytes": (c_size_t, [c_int64]),
+    "sgf_nll_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, c_size_t, _P]),
+    "sgf_nll_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_float, _P,
+                              c_int64, _P]),
     "sgf_sum_n": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
     "sgf_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_colsum": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),

@@ -499,6 +499,86 @@ __global__ __launch_bounds__(kThreads) void k_sum_n(SumArgs a, int64_t n, int d,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N4: log_softmax + NLLLoss on the training rows (large/main.py:139-141), one wave per row.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNllMaxBlocks = 1024;
+
+// lse of row `r` (C classes), every lane returns it; lane-strided loads, fp32 math
+template <typename T>
+__device__ __forceinline__ float row_lse(const T* __restrict__ row, int c, int lane) {
+  float mx = -3.402823466e+38f;
+  for (int j = lane; j < c; j += 64) mx = fmaxf(mx, load1<T>(row + j));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float se = 0.f;
+  for (int j = lane; j < c; j += 64) se += expf(load1<T>(row + j) - mx);
+  se = group_sum<64>(se);
+  return mx + logf(se);
+}
+
+// part[blk] = - sum over this block's training rows of log_softmax(logits[row])[label[row]]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_nll_fwd(const T* __restrict__ logits, int64_t ldl, int c,
+                                                      const int64_t* __restrict__ labels,
+                                                      const int64_t* __restrict__ idx, int64_t m,
+                                                      float* __restrict__ part) {
+  __shared__ float red[kThreads / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.x) * per;
+  int64_t j1 = j0 + per;
+  if (j1 > m) j1 = m;
+  float acc = 0.f;  // lane 0 of each wave accumulates, rows in index order
+  for (int64_t j = j0 + wave; j < j1; j += kThreads / 64) {
+    const int64_t r = idx[j];
+    const T* row = logits + r * ldl;
+    const float lse = row_lse<T>(row, c, lane);
+    const int64_t y = labels[r];
+    if (lane == 0 && y >= 0 && y < c) acc += lse - load1<T>(row + y);
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kThreads / 64; ++w) s += red[w];
+    part[blockIdx.x] = s;
+  }
+}
+
+__global__ void k_nll_sum(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[b];
+    out[0] = s;
+  }
+}
+
+// dlogits[row] = scale * (softmax(logits[row]) - onehot(label[row])) on the training rows (the rest of
+// dlogits was zeroed by the caller)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_nll_bwd(const T* __restrict__ logits, int64_t ldl, int c,
+                                                      const int64_t* __restrict__ labels,
+                                                      const int64_t* __restrict__ idx, int64_t m,
+                                                      const float* __restrict__ gout, float inv_denom,
+                                                      T* __restrict__ dlogits, int64_t ldd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) >> 6;
+  const int64_t nw = (static_cast<int64_t>(gridDim.x) * kThreads) >> 6;
+  const float scale = gout[0] * inv_denom;
+  for (int64_t j = wid; j < m; j += nw) {
+    const int64_t r = idx[j];
+    const T* row = logits + r * ldl;
+    const float lse = row_lse<T>(row, c, lane);
+    const int64_t y = labels[r];
+    for (int k = lane; k < c; k += 64) {
+      const float p = expf(load1<T>(row + k) - lse);
+      store1<T>(dlogits + r * ldd + k, scale * (p - ((k == y) ? 1.f : 0.f)));
+    }
+  }
+}
+
 inline int ew_grid(int64_t total_vec) {
   int64_t b = (total_vec + kThreads - 1) / kThreads;
   const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
@@ -822,6 +902,69 @@ extern "C" int sgf_sum_n(const void* const* xs, const int64_t* lds, int32_t k, i
   else
     hipLaunchKernelGGL((k_sum_n<uint16_t>), grid, dim3(kThreads), 0, st, a, n, d,
                        static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" size_t sgf_nll_workspace_bytes(int64_t m) {
+  (void)m;
+  return static_cast<size_t>(kNllMaxBlocks) * sizeof(float);
+}
+
+extern "C" int sgf_nll_fwd(const void* logits, int64_t ldl, int64_t n, int32_t c, int32_t dtype,
+                           const int64_t* labels, const int64_t* idx, int64_t m, float* loss_sum,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(n >= 0 && m >= 0 && c >= 1 && ldl >= c, SGF_E_INVALID, "sgf_nll_fwd: bad sizes");
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "sgf_nll_fwd: unknown dtype");
+  SGF_REQUIRE(loss_sum, SGF_E_INVALID, "sgf_nll_fwd: null loss_sum");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (m == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(logits && labels && idx, SGF_E_INVALID, "sgf_nll_fwd: null pointer");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_nll_workspace_bytes(m), SGF_E_WORKSPACE,
+              "sgf_nll_fwd: workspace too small");
+  int64_t b = (m + 63) / 64;
+  if (b > kNllMaxBlocks) b = kNllMaxBlocks;
+  const int nblk = static_cast<int>(b);
+  float* part = static_cast<float*>(workspace);
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_nll_fwd<float>), dim3(nblk), dim3(kThreads), 0, st,
+                       static_cast<const float*>(logits), ldl, c, labels, idx, m, part);
+  else
+    hipLaunchKernelGGL((k_nll_fwd<uint16_t>), dim3(nblk), dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(logits), ldl, c, labels, idx, m, part);
+  SGF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_nll_sum, dim3(1), dim3(64), 0, st, part, nblk, loss_sum);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_nll_bwd(const void* logits, int64_t ldl, int64_t n, int32_t c, int32_t dtype,
+                           const int64_t* labels, const int64_t* idx, int64_t m, const float* gout,
+                           float inv_denom, void* dlogits, int64_t ldd, void* stream) {
+  SGF_REQUIRE(n >= 0 && m >= 0 && c >= 1 && ldl >= c && ldd >= c, SGF_E_INVALID, "sgf_nll_bwd: bad sizes");
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "sgf_nll_bwd: unknown dtype");
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(dlogits && gout, SGF_E_INVALID, "sgf_nll_bwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t esz = dtype == SGF_BF16 ? 2 : 4;
+  SGF_CHECK_HIP(hipMemset2DAsync(dlogits, static_cast<size_t>(ldd) * esz, 0, static_cast<size_t>(c) * esz,
+                                 static_cast<size_t>(n), st));
+  if (m == 0) return SGF_OK;
+  SGF_REQUIRE(logits && labels && idx, SGF_E_INVALID, "sgf_nll_bwd: null pointer");
+  int64_t b = (m + 3) / 4;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (b > cap) b = cap;
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_nll_bwd<float>), dim3(static_cast<unsigned>(b)), dim3(kThreads), 0, st,
+                       static_cast<const float*>(logits), ldl, c, labels, idx, m, gout, inv_denom,
+                       static_cast<float*>(dlogits), ldd);
+  else
+    hipLaunchKernelGGL((k_nll_bwd<uint16_t>), dim3(static_cast<unsigned>(b)), dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(logits), ldl, c, labels, idx, m, gout, inv_denom,
+                       static_cast<uint16_t*>(dlogits), ldd);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -134,7 +134,5 @@ def shard_model(model: torch.nn.Module, ctx: Optional[ShardContext]):
 def sharded_nll_loss(logits_local: torch.Tensor, y_local: torch.Tensor, train_idx_local: torch.Tensor,
                      n_train_global: int) -> torch.Tensor:
     """log_softmax + NLL (large/main.py:139-141) summed over the LOCAL training rows and divided by
-    the GLOBAL count: the sum over ranks is the full-graph mean loss."""
-    lp = torch.log_softmax(logits_local, dim=1)
-    picked = lp[train_idx_local, y_local[train_idx_local]]
-    return -picked.sum() / float(n_train_global)
+    the GLOBAL count: the sum over ranks is the full-graph mean loss (fused: ops.nll_loss_rows)."""
+    return ops.nll_loss_rows(logits_local, y_local, train_idx_local, denom=n_train_global)

@@ -1,0 +1,17 @@
+"""Row N4 of SURVEY.md §8f: the loss of the reference's trainers on the GPU in one pass.
+
+    from sgformer_amd.loss import log_softmax_nll
+    loss = log_softmax_nll(out, dataset.label, train_idx)
+
+is the arithmetic of large/main.py:139-141
+(`out = F.log_softmax(out, dim=1); loss = criterion(out[train_idx], label.squeeze(1)[train_idx])`
+with `criterion = nn.NLLLoss()`) on sgf_nll_fwd / sgf_nll_bwd.  Optional: the unchanged trainers keep
+their own three lines (5 ATen kernels; 4.2 ms of `nll_loss` kernels per step at ogbn-products
+scale); a maintainer who edits those lines gets the fused form.  `bench.py` times the step with it.
+"""
+from . import ops
+
+
+def log_softmax_nll(out, label, train_idx, denom=None):
+    """`label` may be [N] or [N, 1] (the trainers keep [N, 1], large/main.py:48-50)."""
+    return ops.nll_loss_rows(out, label, train_idx, denom)

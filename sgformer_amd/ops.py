@@ -341,6 +341,29 @@ class HipKernels:
                       _stream(dev))
         return out
 
+    # ---- N4: log_softmax + NLL on the training rows ----
+    @staticmethod
+    def nll_fwd(logits, labels, idx) -> torch.Tensor:
+        n, c = logits.shape
+        dev = logits.device
+        out = torch.empty(1, dtype=_F32, device=dev)
+        ws = _workspace(dev, "nll", _lib.load().sgf_nll_workspace_bytes(idx.numel()))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_nll_fwd", _ptr(logits), logits.stride(0), n, c, _code(logits), _ptr(labels),
+                      _ptr(idx), idx.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
+        return out
+
+    @staticmethod
+    def nll_bwd(logits, labels, idx, gout, inv_denom: float) -> torch.Tensor:
+        n, c = logits.shape
+        dev = logits.device
+        d = torch.empty((n, c), dtype=logits.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_nll_bwd", _ptr(logits), logits.stride(0), n, c, _code(logits), _ptr(labels),
+                      _ptr(idx), idx.numel(), _ptr(gout), float(inv_denom), _ptr(d), d.stride(0),
+                      _stream(dev))
+        return d
+
     @staticmethod
     def sum_n(xs) -> torch.Tensor:
         """sum of up to 8 equally shaped [n, d] tensors in one pass."""
@@ -726,6 +749,37 @@ class _BNActRes(torch.autograd.Function):
 
 def bn_act_res(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard=None):
     return _BNActRes.apply(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard)
+
+
+# ------------------------------------------------------------------------------------------------
+# N4: the trainer's loss, log_softmax + NLLLoss on the training rows (large/main.py:139-141)
+# ------------------------------------------------------------------------------------------------
+class _NllRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, idx, denom):
+        K.check(logits, labels, idx)
+        logits = logits if logits.stride(-1) == 1 else logits.contiguous()
+        labels = labels.reshape(-1).contiguous()
+        idx = idx.contiguous()
+        if idx.dtype == torch.bool:
+            idx = idx.nonzero().view(-1)
+        m = idx.numel() if denom is None else denom
+        ctx.save_for_backward(logits, labels, idx)
+        ctx.inv = 1.0 / float(max(m, 1))
+        return (K.nll_fwd(logits, labels, idx) * ctx.inv).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, idx = ctx.saved_tensors
+        return K.nll_bwd(logits, labels, idx, g.reshape(1).float().contiguous(), ctx.inv), None, None, None
+
+
+def nll_loss_rows(logits, labels, idx, denom=None):
+    """mean_j -log_softmax(logits[idx[j]])[labels[idx[j]]]  ==  the three lines large/main.py:139-141
+    (`F.log_softmax` + `NLLLoss` on `out[train_idx]`) in one pass over the training rows; `denom`
+    overrides the divisor (the GLOBAL training-row count of a node-sharded run).  fp32 math on fp32
+    or bf16 logits; the gradient is written for all N rows (zeros off the training rows)."""
+    return _NllRows.apply(logits, labels, idx, denom)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -78,6 +78,19 @@ class CpuKernels:
         return (dnum @ M.t() + dden * w + hf @ D + ds).to(h.dtype)
 
     @staticmethod
+    def nll_fwd(logits, labels, idx):
+        lp = torch.log_softmax(logits.float(), dim=1)
+        return -lp[idx, labels[idx]].sum().reshape(1)
+
+    @staticmethod
+    def nll_bwd(logits, labels, idx, gout, inv_denom):
+        d = torch.zeros_like(logits, dtype=torch.float32)
+        p = torch.softmax(logits.float()[idx], dim=1)
+        p[torch.arange(idx.numel()), labels[idx]] -= 1.0
+        d[idx] = p * (gout[0] * inv_denom)
+        return d.to(logits.dtype)
+
+    @staticmethod
     def sum_n(xs):
         out = xs[0].float()
         for x in xs[1:]:

@@ -501,6 +501,40 @@ def test_subgraph_feeds_the_model(cuda):
     assert torch.equal(a, b)
 
 
+# ------------------------------------------------------------------------------------------------
+# N4 fused log_softmax + NLL on the training rows (sgf_nll_*)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c,m", [(1000, 2, 400), (5000, 7, 140), (30000, 47, 15000), (4000, 172, 4000),
+                                   (700, 300, 350), (50, 40, 0)])
+def test_fused_loss(cuda, dtype, n, c, m):
+    from sgformer_amd.loss import log_softmax_nll
+    g = torch.Generator().manual_seed(n + c)
+    logits = (torch.randn(n, c, generator=g) * 3).to(dtype)
+    y = torch.randint(0, c, (n, 1), generator=g)               # [N, 1] as the trainers keep it
+    idx = torch.randperm(n, generator=g)[:m]
+    ld = logits.double().requires_grad_(True)
+    if m > 0:
+        ref = O.nll_loss(ld, y.squeeze(1), idx)
+        ref.backward()
+    lg = logits.to(cuda).requires_grad_(True)
+    loss = log_softmax_nll(lg, y.to(cuda), idx.to(cuda))
+    loss.backward()
+    assert loss.dtype == torch.float32 and lg.grad.dtype == dtype and lg.grad.shape == (n, c)
+    if m == 0:
+        assert float(loss) == 0.0 and torch.count_nonzero(lg.grad) == 0
+        return
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6
+    assert _rel(lg.grad.float(), ld.grad) <= (2e-6 if dtype == torch.float32 else 5e-3)
+    off = torch.ones(n, dtype=torch.bool)
+    off[idx] = False
+    assert torch.count_nonzero(lg.grad[off.to(cuda)]) == 0      # exact zeros off the training rows
+    # bool-mask index + explicit divisor (node-sharded form)
+    mask = ~off
+    l2 = log_softmax_nll(lg.detach(), y.to(cuda), mask.to(cuda), denom=2 * m)
+    assert abs(float(l2) * 2 - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6
+
+
 def test_cpu_tensor_is_rejected():
     from sgformer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -563,6 +563,25 @@ def attention(qkv: torch.Tensor, v_ext: Optional[torch.Tensor], heads: int, d: i
 # ------------------------------------------------------------------------------------------------
 # T3 + T4 fused: attention straight from the un-projected input (H = 1, query == source)
 # ------------------------------------------------------------------------------------------------
+class _SmallGemms:
+    """The d x d algebra is ~20 fp32 GEMMs of 256^3 per step.  hipBLASLt's pick for that shape runs
+    63 us, rocBLAS's 6.8 us (measured on MI355X, ROCm 7.2), while for the [N, 256] x [256, 256] bf16
+    GEMMs hipBLASLt is the faster library — so prefer rocBLAS only inside this block.  The flag is
+    process-wide; forward and backward are each issued by one host thread, so there is no race."""
+
+    def __enter__(self):
+        self.prev = None
+        if K.name == "hip":
+            self.prev = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library("cublas")     # = rocBLAS on ROCm
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.backends.cuda.preferred_blas_library(self.prev)
+        return False
+
+
 def _attn_h_small(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv):
     """The d x d algebra of include/sgf.h (sgf_attn_h_*): fp32, tiny, differentiable torch ops.
     G = h^T h, s = sum_n h_n over ALL rows (n_rows of them); weights [d, d_in], biases [d]."""
@@ -602,7 +621,8 @@ class _AttentionFromInput(torch.autograd.Function):
             G, s = gs[:d * d].reshape(d, d), gs[d * d:]
             n_rows = float(shard.n_global)
         n_total = n_rows if n_override is None else float(n_override)
-        M, m, w, beta = _attn_h_small(G, s, n_rows, n_total, *f32)
+        with _SmallGemms():
+            M, m, w, beta = _attn_h_small(G, s, n_rows, n_total, *f32)
         out, den = K.attn_h_fwd(h, M, m, w, beta)
         ctx.save_for_backward(h, out, den, G, s, M, w, *f32)
         ctx.meta = (n_rows, n_total, shard, wv is None,
@@ -621,7 +641,7 @@ class _AttentionFromInput(torch.autograd.Function):
         dM, dw_, dm = hstats[:d * d].reshape(d, d), hstats[d * d:d * d + d], hstats[d * d + d:d * d + 2 * d]
         dbeta = hstats[d * d + 2 * d:]
         # backward through the d x d algebra: re-run it under autograd on leaf copies (microseconds)
-        with torch.enable_grad():
+        with torch.enable_grad(), _SmallGemms():
             leaves = [t.detach().requires_grad_(True) for t in (G, s, *f32)]
             outs = _attn_h_small(leaves[0], leaves[1], n_rows, n_total, *leaves[2:])
             grads = torch.autograd.grad(outs, leaves, grad_outputs=(dM, dm, dw_, dbeta), allow_unused=True)
@@ -826,7 +846,8 @@ class _Axpby(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.ab
-        return g * a, g * b, None, None
+        ga = g * a
+        return ga, (ga if a == b else g * b), None, None   # one pass when both weights are equal (gw = 0.5)
 
 
 def axpby(x1, x2, a, b):

@@ -52,13 +52,15 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--workload", default="ogbn-products")
     ap.add_argument("--skip-uniform", action="store_true")
+    ap.add_argument("--hidden", type=int, default=0, help="override the feature width d")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     n, avg_deg, _, _, d = synth.SHAPES[args.workload]
+    d = args.hidden or d
     if not args.skip_uniform:
         ei = synth.synthetic_graph(n, avg_deg, seed=123, device=dev)
-        print(json.dumps({"graph": "uniform", "dtype": args.dtype, **measure(ei, n, d, dtype, args.reps, dev)}), flush=True)
+        print(json.dumps({"graph": "uniform", "d": d, "dtype": args.dtype, **measure(ei, n, d, dtype, args.reps, dev)}), flush=True)
         del ei
     for w in [int(v) for v in args.windows.split(",") if v]:
         ei = synth.synthetic_graph_local(n, avg_deg, locality=args.locality, window=w, seed=123, device=dev)

@@ -271,3 +271,83 @@ def test_medium_state_dict_matches_reference_keys():
         assert sa[k].shape == sb[k].shape, k
         assert torch.equal(sa[k], sb[k]), k          # same creation order -> same seeded init
     b.load_state_dict(sa)
+
+
+# ------------------------------------------------------------------------------------------------
+# trainer-side helpers (rows N1 / N4) and the launcher's patches, host logic
+# ------------------------------------------------------------------------------------------------
+def test_batching_subgraph_semantics(cpu_table):
+    """sgformer_amd.batching.subgraph == torch_geometric.utils.subgraph (PyG 1.7.2 semantics as
+    restated in tests/standins): index / bool-mask subsets, relabelling, edge attributes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "_standin_tg_utils", os.path.join(ROOT, "tests", "standins", "torch_geometric", "utils", "__init__.py"))
+    tgu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tgu)
+    pyg_subgraph = tgu.subgraph
+    from sgformer_amd import batching
+    g = torch.Generator().manual_seed(0)
+    n = 300
+    ei = torch.randint(0, n, (2, 4000), generator=g)
+    w = torch.randn(4000, generator=g)
+    sub = torch.randperm(n, generator=g)[:90]
+    for relabel in (False, True):
+        a, aw = batching.subgraph(sub, ei, edge_attr=w, relabel_nodes=relabel, num_nodes=n)
+        b, bw = pyg_subgraph(sub, ei, edge_attr=w, relabel_nodes=relabel, num_nodes=n)
+        assert torch.equal(a, b) and torch.equal(aw, bw)
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[sub] = True
+    a, none = batching.subgraph(mask, ei, num_nodes=n)
+    assert none is None and torch.equal(a, pyg_subgraph(mask, ei, num_nodes=n)[0])
+
+
+def test_fused_loss_matches_trainer_lines(cpu_table):
+    """sgformer_amd.loss.log_softmax_nll == large/main.py:139-141 (value and gradient)."""
+    from sgformer_amd.loss import log_softmax_nll
+    g = torch.Generator().manual_seed(1)
+    out = torch.randn(500, 11, generator=g)
+    label = torch.randint(0, 11, (500, 1), generator=g)
+    idx = torch.randperm(500, generator=g)[:200]
+    a = out.clone().requires_grad_(True)
+    ref = torch.nn.NLLLoss()(torch.log_softmax(a, dim=1)[idx], label.squeeze(1)[idx])
+    ref.backward()
+    b = out.clone().requires_grad_(True)
+    loss = log_softmax_nll(b, label, idx)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6
+    assert _rel(b.grad, a.grad) <= 1e-6
+
+
+def test_launcher_variants_and_patches(monkeypatch, tmp_path):
+    """launch.install registers the right drop-in per variant; the medium / main-batch patches swap
+    `models.GCN` and `torch_geometric.utils.subgraph` before the trainer imports them."""
+    import sys
+    import types
+    from sgformer_amd import launch
+    monkeypatch.setitem(sys.modules, "ours", None)
+    for variant, modname in (("large", "sgformer_amd.ours"), ("100M", "sgformer_amd.ours_100m"),
+                             ("medium", "sgformer_amd.ours_medium")):
+        mod = launch.install(variant)
+        assert mod.__name__ == modname and sys.modules["ours"] is mod
+        assert hasattr(mod, "SGFormer") and hasattr(mod, "TransConv") and hasattr(mod, "full_attention_conv")
+    with pytest.raises(SystemExit):
+        launch.install("nope")
+    fake_models = types.ModuleType("models")
+    fake_models.GCN = object
+    monkeypatch.setitem(sys.modules, "models", fake_models)
+    launch.patch_medium_gcn()
+    from sgformer_amd import ours_medium
+    assert fake_models.GCN is ours_medium.GCN
+    tg = types.ModuleType("torch_geometric")
+    tgu = types.ModuleType("torch_geometric.utils")
+    tgu.subgraph = object
+    tg.utils = tgu
+    monkeypatch.setitem(sys.modules, "torch_geometric", tg)
+    monkeypatch.setitem(sys.modules, "torch_geometric.utils", tgu)
+    launch.patch_subgraph()
+    from sgformer_amd import batching
+    assert tgu.subgraph is batching.subgraph
+    # option parsing
+    argv = ["--sgf-dtype", "bf16", "x.py", "--sgf-variant=large", "--foo"]
+    assert launch._pop_option(argv, "--sgf-dtype") == "bf16" and launch._pop_option(argv, "--sgf-variant") == "large"
+    assert argv == ["x.py", "--foo"]

@@ -7,7 +7,8 @@ four exchange points, all designed into the kernels' partial-sum layouts:
 
   attention fwd/bwd   one all-reduce each of [K^T V | sum K | ||Q||^2 | ||K||^2] (H(d^2+d)+2 fp32)
                       and [dS0 | dz0 | .] (H(d^2+d)+1 fp32): <= 257 KB at d = 256 — latency bound
-  SpMM fwd/bwd        all-gather of the operand rows (X forward, dY backward).  With the equal
+  SpMM fwd/bwd        all-gather of the operand rows (X forward, dY backward), in up to 4 column
+                      chunks whose gathers are pipelined against the chunk SpMMs (ops._sharded_spmm).  With the equal
                       contiguous partition the gathered buffer is indexed by GLOBAL node id, so the
                       local CSR keeps global column ids and needs no relabelling.  (A uniform random
                       graph cuts (P-1)/P of its edges, so a halo list would be the whole matrix
@@ -22,6 +23,7 @@ The loss is normalised by the GLOBAL number of training rows (`sharded_nll_loss`
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, Optional
 
 import torch
@@ -94,17 +96,27 @@ class ShardContext:
         self.bytes_all_reduced += t.numel() * t.element_size()
         return t
 
-    def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
-        """[n_local, d] on every rank -> [world * n_max, d]; row g is global node g (rows >= N pad)."""
+    def all_gather_rows(self, x: torch.Tensor, async_op: bool = False):
+        """[n_local, d] on every rank -> [world * n_max, d]; row g is global node g (rows >= N pad).
+        async_op=True returns (buffer, work): the buffer is valid after work.wait()."""
         d = x.shape[1]
         if x.shape[0] != self.n_max:
             pad = torch.zeros((self.n_max, d), dtype=x.dtype, device=x.device)
             pad[: x.shape[0]] = x
             x = pad
         out = torch.empty((self.world * self.n_max, d), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+        work = dist.all_gather_into_tensor(out, x.contiguous(), group=self.group, async_op=async_op)
         self.bytes_all_gathered += out.numel() * out.element_size()
-        return out
+        return (out, work) if async_op else out
+
+    def gather_chunks(self, d: int) -> int:
+        """Column chunks the SpMM operand is gathered in (ops._sharded_spmm): up to 4, each at least
+        SGF_DIST_CHUNK_COLS (default 64) columns wide and a multiple of 4; 1 = no pipelining."""
+        width = max(4, int(os.environ.get("SGF_DIST_CHUNK_COLS", "64")))
+        c = max(1, min(4, d // width))
+        while c > 1 and d % (4 * c) != 0:
+            c -= 1
+        return c
 
     def unsum(self, t: Optional[torch.Tensor]):
         return None if t is None else t / self.world

@@ -144,10 +144,14 @@ class HipKernels:
 
     # ---- T2 ----
     @staticmethod
-    def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int) -> torch.Tensor:
+    def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`out`: optional [n_rows, d] destination, possibly a column slice of a wider buffer."""
         x = _rows(x)
         d = x.shape[1]
-        y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device)
+        y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device) if out is None else out
+        if out is not None and (out.shape != (n_rows, d) or out.dtype != x.dtype or out.stride(1) != 1
+                                or out.stride(0) % 4 != 0 or out.data_ptr() % (4 * out.element_size()) != 0):
+            raise ValueError("spmm: `out` must be [n_rows, d], same dtype, row-contiguous and 4-element aligned")
         if n_rows == 0 or d == 0:
             return y
         with torch.cuda.device(x.device):
@@ -474,6 +478,26 @@ graph_cache = _GraphCache()
 # ------------------------------------------------------------------------------------------------
 # T2: SpMM (large/ours.py:34)
 # ------------------------------------------------------------------------------------------------
+def _sharded_spmm(rowptr, colind, val, x, n_local: int, shard):
+    """Local rows of A times the all-gathered operand, with the gather PIPELINED against the
+    product: the operand is split into column chunks, every chunk's all-gather is issued up front
+    (asynchronously, on the collective's own stream), and the SpMM of chunk c starts as soon as chunk
+    c has arrived while chunks c+1.. are still on the xGMI links.  The all-gather is the one
+    bandwidth-bound exchange of the path (N*d*s bytes per SpMM into every GPU), the SpMM the one
+    HBM-bound kernel: they use different resources, so overlapping them hides the shorter of the two."""
+    d = x.shape[1]
+    chunks = shard.gather_chunks(d)
+    if chunks <= 1:
+        return K.spmm(rowptr, colind, val, shard.all_gather_rows(x), n_local)
+    w = d // chunks
+    pending = [shard.all_gather_rows(x[:, c * w:(c + 1) * w].contiguous(), async_op=True) for c in range(chunks)]
+    y = torch.empty((n_local, d), dtype=x.dtype, device=x.device)
+    for c, (buf, work) in enumerate(pending):
+        work.wait()                                   # the compute stream waits for THIS chunk only
+        K.spmm(rowptr, colind, val, buf, n_local, out=y[:, c * w:(c + 1) * w])
+    return y
+
+
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph, shard):
@@ -481,8 +505,7 @@ class _SpMM(torch.autograd.Function):
         ctx.graph, ctx.shard = graph, shard
         if shard is not None:
             # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
-            xg = shard.all_gather_rows(x)
-            return K.spmm(graph.rowptr, graph.colind, graph.val, xg, graph.n_local)
+            return _sharded_spmm(graph.rowptr, graph.colind, graph.val, x, graph.n_local, shard)
         return K.spmm(graph.rowptr, graph.colind, graph.val, x, graph.n)
 
     @staticmethod
@@ -490,9 +513,8 @@ class _SpMM(torch.autograd.Function):
         graph, shard = ctx.graph, ctx.shard
         if shard is not None:
             # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the gathered dY
-            gyg = shard.all_gather_rows(gy.contiguous())
             rp, ci, va = graph.transposed()
-            return K.spmm(rp, ci, va, gyg, graph.n_local), None, None
+            return _sharded_spmm(rp, ci, va, gy.contiguous(), graph.n_local, shard), None, None
         rp, ci, va = graph.transposed()
         return K.spmm(rp, ci, va, gy.contiguous(), graph.n), None, None
 

@@ -48,13 +48,16 @@ class CpuKernels:
 
     # ---- T2 ----
     @staticmethod
-    def spmm(rowptr, colind, val, x, n_rows):
+    def spmm(rowptr, colind, val, x, n_rows, out=None):
         y = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
-        if n_rows == 0 or colind.numel() == 0:
-            return y
-        counts = (rowptr[1:] - rowptr[:-1])
-        rows = torch.repeat_interleave(torch.arange(n_rows), counts)
-        return y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
+        if n_rows > 0 and colind.numel() > 0:
+            counts = (rowptr[1:] - rowptr[:-1])
+            rows = torch.repeat_interleave(torch.arange(n_rows), counts)
+            y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     # ---- T3+T4 fused ----
     @staticmethod

@@ -25,9 +25,10 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, cfg_name, directed, ret):
+def _worker(rank, world, port, cfg_name, directed, ret, chunk_cols="4"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # d = 16 in this test: 4-column chunks -> the pipelined 4-chunk all-gather / SpMM path runs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_CHUNK_COLS=chunk_cols)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
@@ -86,13 +87,15 @@ def _worker(rank, world, port, cfg_name, directed, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_name,directed", [(2, "products", False), (2, "heads_cat", True),
-                                                     (3, "arxiv", False)])
-def test_sharded_step_matches_full_graph(world, cfg_name, directed):
+@pytest.mark.parametrize("world,cfg_name,directed,chunk_cols", [(2, "products", False, "4"), (2, "heads_cat", True, "4"),
+                                                                (3, "arxiv", False, "8"), (2, "products", False, "64")])
+def test_sharded_step_matches_full_graph(world, cfg_name, directed, chunk_cols):
+    """chunk_cols 4 / 8: the SpMM operand (d = 16) is all-gathered in 4 / 2 pipelined column chunks
+    (async all-gathers, chunk SpMMs into column slices); 64: the single-gather path."""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, cfg_name, directed, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, cfg_name, directed, ret, chunk_cols), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         e = ret[rank]

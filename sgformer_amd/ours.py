@@ -11,10 +11,14 @@ backward run on the hand-written gfx950 kernels behind include/sgf.h.
     ----------------------------------------    ---------------------------------------------------
     large/ours.py:26-33  degree+argsort / layer one cached CSR per edge_index   (ops.CSRGraph)
     large/ours.py:34     torch_sparse.matmul    ops.spmm            (k_spmm_wave / k_spmm_sub)
-    large/ours.py:123-128 three Linear calls    one [d -> 3Hd] GEMM (hipBLASLt via F.linear)
-    large/ours.py:130-157 2 norms + 4 einsums   ops.attention       (k_attn_reduce / k_attn_apply)
+    large/ours.py:123-157 Wq/Wk/Wv + 2 norms    ops.attention_from_input: Gram of the layer input +
+                          + 4 einsums           d x d algebra + one apply pass, Q/K/V never
+                                                materialised (one head, query == source); otherwise
+                                                one [d -> 3Hd] GEMM + ops.attention (materialised)
+    nn.Linear weights / biases under autograd   ops.linear / linear_cat: dW, db on sgf_gram
     large/ours.py:198-216 LN / relu / residual  ops.ln_res_act      (k_ln_fwd / k_ln_bwd)
     large/ours.py:77-93  BN / relu / residual   ops.batch_stats + ops.bn_act_res
+    large/ours.py:83-93  x0 used 7 times        ops.fan_out         (one fused gradient sum)
     large/ours.py:269-270 weighted add          ops.axpby
 
 GPU only: a CPU tensor raises (no eager fallback by design).

@@ -97,6 +97,29 @@ def test_spmm_bf16(cuda):
     assert _rel(y.float(), ref) <= 4e-3  # one bf16 rounding of the fp32 accumulator (2^-9)
 
 
+def test_spmm_into_column_slice(cuda):
+    """sgf_spmm with ldx / ldy wider than d: the chunked, pipelined all-gather path of a node-sharded
+    run multiplies column chunks of the gathered operand into column slices of ONE output buffer
+    (ops._sharded_spmm)."""
+    from sgformer_amd import ops
+    n, d = 3000, 256
+    ei = O.synthetic_graph(n, 9.0, seed=2)
+    g = ops.CSRGraph(ei.to(cuda), n)
+    x = torch.randn(n, d)
+    ref = ops.K.spmm(g.rowptr, g.colind, g.val, x.to(cuda), n)
+    for dtype in (torch.float32, torch.bfloat16):
+        xg = x.to(cuda, dtype)
+        full = ops.K.spmm(g.rowptr, g.colind, g.val, xg, n)
+        y = torch.full((n, d), 7.0, dtype=dtype, device=cuda)
+        for c in range(4):
+            ops.K.spmm(g.rowptr, g.colind, g.val, xg[:, 64 * c:64 * (c + 1)].contiguous(), n,
+                       out=y[:, 64 * c:64 * (c + 1)])
+        assert torch.equal(y, full)                      # same per-feature accumulation order
+        assert _rel(y.float(), ref) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    with pytest.raises(ValueError):
+        ops.K.spmm(g.rowptr, g.colind, g.val, x.to(cuda), n, out=torch.empty(n, d + 4, device=cuda))
+
+
 def test_spmm_empty_rows_and_n0(cuda):
     from sgformer_amd import ops
     ei, n = _graphs()["empty"]

@@ -122,7 +122,7 @@ class SpmmTimer:
     """HIP-event timing of every SpMM launch on the launch stream (torch's current stream)."""
 
     def __init__(self):
-        self.pairs, self.bytes_alg, self.bytes_gather, self.active = [], [], [], False
+        self.pairs, self.bytes_alg, self.bytes_gather, self.active, self.d = [], [], [], False, 0
         self._orig = ops.K.spmm
 
     def install(self):
@@ -137,6 +137,7 @@ class SpmmTimer:
             b.record()
             s = x.element_size()
             nnz, d = colind.numel(), x.shape[1]
+            timer.d = d
             timer.pairs.append((a, b))
             timer.bytes_alg.append(nnz * 8 + (n_rows + 1) * 8 + x.shape[0] * d * s + n_rows * d * s)
             timer.bytes_gather.append(nnz * (8 + d * s) + (n_rows + 1) * 8 + n_rows * d * s)
@@ -152,7 +153,8 @@ class SpmmTimer:
         alg = sum(self.bytes_alg) / len(self.bytes_alg)
         gat = sum(self.bytes_gather) / len(self.bytes_gather)
         achieved = alg / (mean_ms * 1e-3) / 1e9
-        return {"kernel": "k_spmm_wave (sgf_spmm)", "bound": "hbm", "achieved": round(achieved, 1),
+        kern = "k_spmm_wave" if self.d > 128 else "k_spmm_sub"
+        return {"kernel": f"{kern} (sgf_spmm)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": len(ms), "mean_launch_ms": round(mean_ms, 4),
                 "algorithmic_bytes": int(alg), "gather_bytes": int(gat),

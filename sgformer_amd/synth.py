@@ -15,6 +15,9 @@ SHAPES = {
     "ogbn-arxiv": (169343, 13.7, 128, 40, 256),
     "ogbn-products": (2449029, 50.5, 100, 47, 256),
     "pokec": (1632803, 27.3, 65, 2, 256),
+    # BASELINE.json config 5 (ogbn-papers100M-shaped: 111,059,956 nodes, ~30 stored entries per row,
+    # 128 features, 172 classes, hidden 128) cut to the share ONE of 8 GPUs holds
+    "papers100M-shard8": (13882494, 29.0, 128, 172, 128),
 }
 
 # constructor keywords of the large/run.sh recipes (dropout overridden by the caller)
@@ -29,6 +32,11 @@ RECIPES = {
                           trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
                           gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
                           use_graph=True, graph_weight=0.5, aggregate="add"),
+    # 100M/run.sh:3-7 (alpha residual; dropout overridden)
+    "papers100M-shard8": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
+                              trans_use_weight=True, trans_use_act=False, gnn_num_layers=3, gnn_use_bn=True,
+                              gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
+                              use_graph=True, graph_weight=0.8, aggregate="add", alpha=0.5),
     # large/run.sh:22-26
     "pokec": dict(trans_num_layers=1, trans_num_heads=1, trans_use_bn=True, trans_use_residual=True,
                   trans_use_weight=True, trans_use_act=False, gnn_num_layers=2, gnn_use_bn=True,

@@ -128,12 +128,12 @@ class SpmmTimer:
     def install(self):
         timer, orig = self, self._orig
 
-        def timed(rowptr, colind, val, x, n_rows):
+        def timed(rowptr, colind, val, x, n_rows, **kw):
             if not timer.active:
-                return orig(rowptr, colind, val, x, n_rows)
+                return orig(rowptr, colind, val, x, n_rows, **kw)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            y = orig(rowptr, colind, val, x, n_rows)
+            y = orig(rowptr, colind, val, x, n_rows, **kw)
             b.record()
             s = x.element_size()
             nnz, d = colind.numel(), x.shape[1]

@@ -112,6 +112,19 @@ int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val, con
              int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
              void* stream);
 
+/* sgf_spmm with long rows split across workgroups (power-law graphs: a hub row of 17 k entries walked
+ * by ONE wave is a latency-bound tail).  Rows with more than `long_len` stored entries are cut into
+ * segments of sgf_spmm_segment_len() entries, each reduced by a whole workgroup into an fp32 partial;
+ * a row's partials are then added in segment order (deterministic).  `long_segments` = the number of
+ * such segments, sum over rows with len > long_len of ceil(len / segment_len), computed by the caller
+ * once per CSR (0 = plain sgf_spmm).  Same result as sgf_spmm up to fp32 summation order. */
+int32_t sgf_spmm_segment_len(void);
+size_t sgf_spmm_split_workspace_bytes(int64_t long_segments, int32_t d);
+int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
+                   int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
+                   int64_t long_len, int64_t long_segments, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * T3 — linear global attention core.   Replaces large/ours.py:130-149,157
  * (= medium/ours.py:14-46 full_attention_conv, 100M/ours.py:12-53), per head h:

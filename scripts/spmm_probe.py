@@ -21,17 +21,18 @@ sys.path.insert(0, ROOT)
 from sgformer_amd import ops, synth  # noqa: E402
 
 
-def measure(ei, n, d, dtype, reps, dev):
+def measure(ei, n, d, dtype, reps, dev, split=True):
     graph = ops.CSRGraph(ei, n, validate=False)
     nnz = int(ei.shape[1])
+    segs = graph.long_segments if split else 0
     x = torch.randn(n, d, device=dev).to(dtype)
     for _ in range(2):
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n)
+        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=segs)
     evs = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n)
+        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=segs)
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()
@@ -39,7 +40,8 @@ def measure(ei, n, d, dtype, reps, dev):
     s = x.element_size()
     alg = nnz * 8 + (n + 1) * 8 + 2 * n * d * s
     gat = nnz * (8 + d * s) + (n + 1) * 8 + n * d * s
-    return {"nnz": nnz, "launch_ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1),
+    lens = graph.rowptr[1:] - graph.rowptr[:-1]
+    return {"nnz": nnz, "max_row": int(lens.max()), "long_segments": segs, "launch_ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1),
             "frac_of_8TBps": round(alg / ms / 1e6 / 8000.0, 4), "gather_GBps": round(gat / ms / 1e6, 1),
             "algorithmic_bytes": alg, "gather_bytes": gat}
 
@@ -53,6 +55,7 @@ def main():
     ap.add_argument("--workload", default="ogbn-products")
     ap.add_argument("--skip-uniform", action="store_true")
     ap.add_argument("--hidden", type=int, default=0, help="override the feature width d")
+    ap.add_argument("--skewed", default="", help="comma list of gamma values: power-law graphs, split vs unsplit")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
@@ -62,6 +65,14 @@ def main():
         ei = synth.synthetic_graph(n, avg_deg, seed=123, device=dev)
         print(json.dumps({"graph": "uniform", "d": d, "dtype": args.dtype, **measure(ei, n, d, dtype, args.reps, dev)}), flush=True)
         del ei
+    for gamma in [float(v) for v in args.skewed.split(",") if v]:
+        ei = synth.synthetic_graph_skewed(n, avg_deg, gamma=gamma, seed=123, device=dev)
+        for split in (False, True):
+            print(json.dumps({"graph": f"skewed gamma={gamma}", "split_long_rows": split, "d": d, "dtype": args.dtype,
+                              **measure(ei, n, d, dtype, args.reps, dev, split=split)}), flush=True)
+        del ei
+        ops.graph_cache.clear()
+        torch.cuda.empty_cache()
     for w in [int(v) for v in args.windows.split(",") if v]:
         ei = synth.synthetic_graph_local(n, avg_deg, locality=args.locality, window=w, seed=123, device=dev)
         print(json.dumps({"graph": f"local p={args.locality} window={w}", "dtype": args.dtype,

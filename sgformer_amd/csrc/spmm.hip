@@ -14,22 +14,33 @@
 //   * k_spmm_sub<LPR>: for d <= 128 a row needs fewer than 64 lanes, so 64/LPR rows share a wave.
 //   * accumulation is fp32 in stored (ascending-source) order per feature — the same order as the
 //     sequential CPU kernel of torch_sparse, so fp32 results agree to the last few ulps.
-//   * block -> row-range mapping is XCD-aware: the dispatcher places block b on XCD b % 8, so the
-//     remap gives each XCD a contiguous range of rows and its private 4 MiB L2 caches the X rows of
-//     ONE graph neighbourhood instead of 1/8 of everybody's.
+//   * block -> row-range mapping is XCD-aware (xcd_remap): each XCD walks 4096-row chunks, so its
+//     private 4 MiB L2 caches the X rows of ONE graph neighbourhood instead of 1/8 of everybody's;
+//     chunks are dealt round-robin so that skewed graphs stay load-balanced across XCDs.
 #include "common.h"
+
+#include <climits>
 
 namespace sgf {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
 
+// Blocks are dealt to the 8 XCDs in STRIPES: the hardware places block b on XCD b % 8; virtual block
+// v(b) is chosen so that each XCD walks chunks of kChunkBlocks consecutive virtual blocks (4096 rows: its
+// private 4 MiB L2 caches the X rows of one graph neighbourhood instead of 1/8 of everybody's), and
+// consecutive chunks go round-robin over the XCDs.  Round-robin rather than 8 contiguous ranges: when the
+// degree correlates with the node id (datasets sorted by popularity or time) contiguous ranges put most of
+// the work on one XCD — a power-law graph ran 1.5x slower that way.  Bijective for any nblocks.
+constexpr int64_t kChunkBlocks = 1024;
+
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks) {
-  // bijective for any nblocks: the first `full` blocks are spread as 8 contiguous chunks.
-  const int64_t per = nblocks / kNumXCD;
-  const int64_t full = per * kNumXCD;
-  if (b >= full) return b;
-  return (b % kNumXCD) * per + b / kNumXCD;
+  const int64_t stripe = kNumXCD * kChunkBlocks;
+  const int64_t full = nblocks / stripe * stripe;
+  if (b >= full) return b;   // ragged tail: identity
+  const int64_t xcd = b % kNumXCD;
+  const int64_t j = b / kNumXCD;              // arrival order inside this XCD
+  return ((j / kChunkBlocks) * kNumXCD + xcd) * kChunkBlocks + j % kChunkBlocks;
 }
 
 __device__ __forceinline__ void fma4(float4& acc, float v, const float4& x) {
@@ -39,11 +50,41 @@ __device__ __forceinline__ void fma4(float4& acc, float v, const float4& x) {
   acc.w = fmaf(v, x.w, acc.w);
 }
 
+// ---- long rows (power-law graphs: ogbn-products has rows of 17 k entries) ----------------------------
+// One wave walks a row serially with UNROLL gathers in flight, so a hub row would be a long latency-bound
+// tail.  Rows longer than `long_len` are therefore not processed by the row kernels: the wave that meets
+// one reserves ceil(len / kSegLen) consecutive queue slots with ONE atomic and enqueues (row, seg, k);
+// k_spmm_long_seg then reduces each segment with a whole workgroup (wave-strided slices, fixed-order
+// LDS combine) into an fp32 partial, and k_spmm_long_fin adds a row's partials in segment order.  The
+// slot reservation order is arbitrary, the arithmetic is not: results are deterministic.
+constexpr int kSegLen = 1024;
+
+struct LongEntry {
+  int32_t row, seg, k, pad;
+};
+
+struct LongQueue {
+  int32_t* count;       // [1]
+  LongEntry* entries;   // [cap]
+  int32_t cap;
+  int64_t long_len;     // rows with more stored entries than this are queued (INT64_MAX: never)
+};
+
+__device__ __forceinline__ void push_long_row(const LongQueue& q, int64_t row, int64_t len, int lane_in_group,
+                                              int group_width) {
+  const int k = static_cast<int>((len + kSegLen - 1) / kSegLen);
+  int base = 0;
+  if (lane_in_group == 0) base = atomicAdd(q.count, k);
+  base = __shfl(base, (threadIdx.x & 63) - lane_in_group, 64);
+  for (int s = lane_in_group; s < k; s += group_width)
+    if (base + s < q.cap) q.entries[base + s] = LongEntry{static_cast<int32_t>(row), s, k, 0};
+}
+
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_wave(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
     const float* __restrict__ val, const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-    int64_t ldy, int64_t n_rows, int32_t d) {
+    int64_t ldy, int64_t n_rows, int32_t d, LongQueue lq) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -51,6 +92,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_wave(
   if (row >= n_rows) return;
   const int64_t e0 = rowptr[row];
   const int64_t e1 = rowptr[row + 1];
+  if (e1 - e0 > lq.long_len) {   // wave-uniform
+    push_long_row(lq, row, e1 - e0, lane, 64);
+    return;
+  }
 
   for (int f0 = 0; f0 < d; f0 += 256) {
     const int fc = f0 + lane * 4;
@@ -88,16 +133,21 @@ template <typename T, int LPR, int UNROLL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_sub(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
     const float* __restrict__ val, const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-    int64_t ldy, int64_t n_rows, int32_t d) {
+    int64_t ldy, int64_t n_rows, int32_t d, LongQueue lq) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t row = (blk * kWavesPerBlock + wid) * RPW + lane / LPR;
   const int fc = (lane % LPR) * 4;
-  if (row >= n_rows || fc >= d) return;
+  if (row >= n_rows) return;
   const int64_t e0 = rowptr[row];
   const int64_t e1 = rowptr[row + 1];
+  if (e1 - e0 > lq.long_len) {   // uniform over the LPR lanes of this row
+    push_long_row(lq, row, e1 - e0, lane % LPR, LPR);
+    return;
+  }
+  if (fc >= d) return;
   const T* xl = x + fc;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t e = e0;
@@ -122,22 +172,91 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_sub(
   store4<T>(y + row * ldy + fc, acc);
 }
 
+// one workgroup per queued (row, segment): wave w takes the entries e0 + w*UNROLL + j*4*UNROLL ...;
+// lane l owns features [4l, 4l+4) of each 256-feature panel; partial[slot][d] fp32
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_long_seg(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const float* __restrict__ val, const T* __restrict__ x, int64_t ldx, int32_t d, LongQueue lq,
+    float* __restrict__ partial) {
+  __shared__ float4 red[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int cnt = *lq.count;
+  if (cnt > lq.cap) cnt = lq.cap;
+  for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+    const LongEntry en = lq.entries[i];
+    const int64_t r0 = rowptr[en.row];
+    const int64_t e0 = r0 + static_cast<int64_t>(en.seg) * kSegLen;
+    int64_t e1 = e0 + kSegLen;
+    const int64_t rend = rowptr[en.row + 1];
+    if (e1 > rend) e1 = rend;
+    for (int f0 = 0; f0 < d; f0 += 256) {
+      const int fc = f0 + lane * 4;
+      const bool active = fc < d;
+      const T* xl = x + (active ? fc : 0);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t e = e0 + wave * UNROLL; e < e1; e += kWavesPerBlock * UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          if (e + u < e1) {
+            const float4 xv = load4<T>(xl + static_cast<int64_t>(colind[e + u]) * ldx);
+            fma4(acc, val[e + u], xv);
+          }
+        }
+      }
+      red[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && active) {
+        float4 t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+          t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w;
+        }
+        *reinterpret_cast<float4*>(&partial[static_cast<int64_t>(i) * d + fc]) = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmm_long_fin(LongQueue lq, const float* __restrict__ partial,
+                                                        int32_t d, T* __restrict__ y, int64_t ldy) {
+  int cnt = *lq.count;
+  if (cnt > lq.cap) cnt = lq.cap;
+  const int f4 = d / 4;
+  for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+    const LongEntry en = lq.entries[i];
+    if (en.seg != 0) continue;   // the head entry of a row owns slots [i, i + k)
+    for (int c = threadIdx.x; c < f4; c += blockDim.x) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < en.k; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(&partial[static_cast<int64_t>(i + s) * d + 4 * c]);
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      store4<T>(y + static_cast<int64_t>(en.row) * ldy + 4 * c, t);
+    }
+  }
+}
+
 template <typename T>
 int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const T* x, int64_t ldx,
-           T* y, int64_t ldy, int64_t n_rows, int32_t d, hipStream_t st) {
+           T* y, int64_t ldy, int64_t n_rows, int32_t d, hipStream_t st, const LongQueue& lq,
+           float* partial) {
   constexpr int UNROLL = 8;
   const dim3 block(kWavesPerBlock * 64);
   if (d > 128) {
     const int64_t nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL((k_spmm_wave<T, UNROLL>), dim3(static_cast<unsigned>(nb)), block, 0, st,
-                       rowptr, colind, val, x, ldx, y, ldy, n_rows, d);
+                       rowptr, colind, val, x, ldx, y, ldy, n_rows, d, lq);
   } else {
 #define SGF_SUB(LPR_)                                                                         \
   {                                                                                           \
     constexpr int RPB = kWavesPerBlock * (64 / LPR_);                                         \
     const int64_t nb = (n_rows + RPB - 1) / RPB;                                              \
     hipLaunchKernelGGL((k_spmm_sub<T, LPR_, UNROLL>), dim3(static_cast<unsigned>(nb)), block, \
-                       0, st, rowptr, colind, val, x, ldx, y, ldy, n_rows, d);                \
+                       0, st, rowptr, colind, val, x, ldx, y, ldy, n_rows, d, lq);            \
   }
     if (d > 64) SGF_SUB(32)
     else if (d > 32) SGF_SUB(16)
@@ -148,6 +267,14 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
 #undef SGF_SUB
   }
   SGF_LAUNCH_CHECK();
+  if (lq.cap > 0) {
+    const int nb = lq.cap < 2048 ? lq.cap : 2048;
+    hipLaunchKernelGGL((k_spmm_long_seg<T, UNROLL>), dim3(nb), block, 0, st, rowptr, colind, val, x, ldx, d,
+                       lq, partial);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_spmm_long_fin<T>), dim3(nb), dim3(256), 0, st, lq, partial, d, y, ldy);
+    SGF_LAUNCH_CHECK();
+  }
   return SGF_OK;
 }
 
@@ -156,28 +283,72 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
 
 using namespace sgf;
 
-extern "C" int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val,
-                        const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows,
-                        int32_t d, int32_t dtype, void* stream) {
-  SGF_REQUIRE(n_rows >= 0 && d >= 0, SGF_E_INVALID, "sgf_spmm: negative size");
+namespace {
+int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x, int64_t ldx,
+                void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, const LongQueue& lq,
+                float* partial, hipStream_t st, const char* fn) {
+  SGF_REQUIRE(n_rows >= 0 && d >= 0, SGF_E_INVALID, "%s: negative size", fn);
   if (n_rows == 0 || d == 0) return SGF_OK;
-  SGF_REQUIRE(rowptr && x && y, SGF_E_INVALID, "sgf_spmm: null pointer");
+  SGF_REQUIRE(rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
   SGF_REQUIRE(n_rows < (static_cast<int64_t>(1) << 31) * kWavesPerBlock, SGF_E_UNSUPPORTED,
-              "sgf_spmm: n_rows too large for one launch");
+              "%s: n_rows too large for one launch", fn);
   SGF_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, SGF_E_INVALID,
-              "sgf_spmm: d, ldx, ldy must be multiples of 4 with ld >= d (d=%d ldx=%lld ldy=%lld)",
-              d, static_cast<long long>(ldx), static_cast<long long>(ldy));
+              "%s: d, ldx, ldy must be multiples of 4 with ld >= d (d=%d ldx=%lld ldy=%lld)", fn, d,
+              static_cast<long long>(ldx), static_cast<long long>(ldy));
   const size_t esz = dtype == SGF_BF16 ? 2 : 4;
   SGF_REQUIRE(reinterpret_cast<uintptr_t>(x) % (4 * esz) == 0 &&
                   reinterpret_cast<uintptr_t>(y) % (4 * esz) == 0,
-              SGF_E_INVALID, "sgf_spmm: x / y must be aligned to 4 elements");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+              SGF_E_INVALID, "%s: x / y must be aligned to 4 elements", fn);
   if (dtype == SGF_F32)
-    return launch<float>(rowptr, colind, val, static_cast<const float*>(x), ldx,
-                         static_cast<float*>(y), ldy, n_rows, d, st);
+    return launch<float>(rowptr, colind, val, static_cast<const float*>(x), ldx, static_cast<float*>(y), ldy,
+                         n_rows, d, st, lq, partial);
   if (dtype == SGF_BF16)
     return launch<uint16_t>(rowptr, colind, val, static_cast<const uint16_t*>(x), ldx,
-                            static_cast<uint16_t*>(y), ldy, n_rows, d, st);
-  set_error("sgf_spmm: unknown dtype %d", dtype);
+                            static_cast<uint16_t*>(y), ldy, n_rows, d, st, lq, partial);
+  set_error("%s: unknown dtype %d", fn, dtype);
   return SGF_E_INVALID;
+}
+}  // namespace
+
+extern "C" int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val,
+                        const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows,
+                        int32_t d, int32_t dtype, void* stream) {
+  const LongQueue none{nullptr, nullptr, 0, INT64_MAX};
+  return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, none, nullptr,
+                     static_cast<hipStream_t>(stream), "sgf_spmm");
+}
+
+extern "C" int32_t sgf_spmm_segment_len(void) { return kSegLen; }
+
+extern "C" size_t sgf_spmm_split_workspace_bytes(int64_t long_segments, int32_t d) {
+  if (long_segments < 0 || d < 0) return 0;
+  return 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256) +
+         static_cast<size_t>(long_segments) * static_cast<size_t>(d) * sizeof(float);
+}
+
+extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val,
+                              const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows,
+                              int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31),
+              SGF_E_INVALID, "sgf_spmm_split: bad long_len / long_segments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (long_segments == 0) {
+    const LongQueue none{nullptr, nullptr, 0, INT64_MAX};
+    return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, none, nullptr, st,
+                       "sgf_spmm_split");
+  }
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_spmm_split_workspace_bytes(long_segments, d),
+              SGF_E_WORKSPACE, "sgf_spmm_split: workspace too small");
+  char* ws = static_cast<char*>(workspace);
+  LongQueue lq;
+  lq.count = reinterpret_cast<int32_t*>(ws);
+  lq.entries = reinterpret_cast<LongEntry*>(ws + 256);
+  lq.cap = static_cast<int32_t>(long_segments);
+  lq.long_len = long_len;
+  float* partial = reinterpret_cast<float*>(
+      ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
+  SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
+  return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, lq, partial, st,
+                     "sgf_spmm_split");
 }

@@ -44,12 +44,15 @@ class ShardedGraph:
         self.n_local = ctx.n_local
         self.device = full.device
         self.rowptr, self.colind, self.val = self._slice(full.rowptr, full.colind, full.val, ctx)
+        self.long_segments = ops.long_row_segments(self.rowptr)
         t_rowptr, t_colind, t_val = full.transposed()
         self.symmetric = full.symmetric
         if full.symmetric:
             self._t = (self.rowptr, self.colind, self.val)
+            self.t_long_segments = self.long_segments
         else:
             self._t = self._slice(t_rowptr, t_colind, t_val, ctx)
+            self.t_long_segments = ops.long_row_segments(self._t[0])
 
     @staticmethod
     def _slice(rowptr, colind, val, ctx):

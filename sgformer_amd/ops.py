@@ -144,8 +144,11 @@ class HipKernels:
 
     # ---- T2 ----
     @staticmethod
-    def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`out`: optional [n_rows, d] destination, possibly a column slice of a wider buffer."""
+    def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None,
+             long_segments: int = 0) -> torch.Tensor:
+        """`out`: optional [n_rows, d] destination, possibly a column slice of a wider buffer.
+        `long_segments` > 0 (see long_row_segments): rows longer than LONG_ROW are split across
+        workgroups (sgf_spmm_split)."""
         x = _rows(x)
         d = x.shape[1]
         y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device) if out is None else out
@@ -155,8 +158,14 @@ class HipKernels:
         if n_rows == 0 or d == 0:
             return y
         with torch.cuda.device(x.device):
-            _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
-                      _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
+            if long_segments > 0:
+                ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(long_segments, d))
+                _lib.call("sgf_spmm_split", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
+                          _ptr(y), y.stride(0), n_rows, d, _code(x), LONG_ROW, long_segments, _ptr(ws),
+                          ws.numel(), _stream(x.device))
+            else:
+                _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
+                          _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
         return y
 
     # ---- T3 ----  q, k: [n, H*d] views (ld = stride(0)); v: [n, Hv*d]
@@ -394,6 +403,21 @@ class HipKernels:
 
 K = HipKernels()
 
+# Rows with more stored entries than this are reduced by whole workgroups, segment by segment
+# (sgf_spmm_split): one wave walking a 17 k-entry hub row of a power-law graph is a latency-bound tail.
+LONG_ROW = 1024
+_SEGMENT = 1024   # = sgf_spmm_segment_len()
+
+
+def long_row_segments(rowptr: torch.Tensor) -> int:
+    """sum over rows longer than LONG_ROW of ceil(len / segment): the `long_segments` argument of
+    sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built)."""
+    if rowptr.numel() <= 1:
+        return 0
+    lens = rowptr[1:] - rowptr[:-1]
+    segs = torch.where(lens > LONG_ROW, (lens + (_SEGMENT - 1)) // _SEGMENT, torch.zeros_like(lens))
+    return int(segs.sum())
+
 
 def set_kernels(table):
     """Install a kernel table (tests only; see module docstring).  Returns the previous one."""
@@ -432,6 +456,8 @@ class CSRGraph:
         self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
         self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
+        self.long_segments = long_row_segments(self.rowptr)
+        self.t_long_segments = 0
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None
 
@@ -442,6 +468,7 @@ class CSRGraph:
                                                              self.rowptr, self.colind)
             self.symmetric = sym
             self._t = (self.rowptr, self.colind, self.val) if sym else (t_rowptr, t_colind, t_val)
+            self.t_long_segments = self.long_segments if sym else long_row_segments(t_rowptr)
         return self._t
 
 
@@ -478,7 +505,7 @@ graph_cache = _GraphCache()
 # ------------------------------------------------------------------------------------------------
 # T2: SpMM (large/ours.py:34)
 # ------------------------------------------------------------------------------------------------
-def _sharded_spmm(rowptr, colind, val, x, n_local: int, shard):
+def _sharded_spmm(rowptr, colind, val, x, n_local: int, shard, long_segments: int = 0):
     """Local rows of A times the all-gathered operand, with the gather PIPELINED against the
     product: the operand is split into column chunks, every chunk's all-gather is issued up front
     (asynchronously, on the collective's own stream), and the SpMM of chunk c starts as soon as chunk
@@ -488,13 +515,13 @@ def _sharded_spmm(rowptr, colind, val, x, n_local: int, shard):
     d = x.shape[1]
     chunks = shard.gather_chunks(d)
     if chunks <= 1:
-        return K.spmm(rowptr, colind, val, shard.all_gather_rows(x), n_local)
+        return K.spmm(rowptr, colind, val, shard.all_gather_rows(x), n_local, long_segments=long_segments)
     w = d // chunks
     pending = [shard.all_gather_rows(x[:, c * w:(c + 1) * w].contiguous(), async_op=True) for c in range(chunks)]
     y = torch.empty((n_local, d), dtype=x.dtype, device=x.device)
     for c, (buf, work) in enumerate(pending):
         work.wait()                                   # the compute stream waits for THIS chunk only
-        K.spmm(rowptr, colind, val, buf, n_local, out=y[:, c * w:(c + 1) * w])
+        K.spmm(rowptr, colind, val, buf, n_local, out=y[:, c * w:(c + 1) * w], long_segments=long_segments)
     return y
 
 
@@ -505,8 +532,9 @@ class _SpMM(torch.autograd.Function):
         ctx.graph, ctx.shard = graph, shard
         if shard is not None:
             # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
-            return _sharded_spmm(graph.rowptr, graph.colind, graph.val, x, graph.n_local, shard)
-        return K.spmm(graph.rowptr, graph.colind, graph.val, x, graph.n)
+            return _sharded_spmm(graph.rowptr, graph.colind, graph.val, x, graph.n_local, shard,
+                                 graph.long_segments)
+        return K.spmm(graph.rowptr, graph.colind, graph.val, x, graph.n, long_segments=graph.long_segments)
 
     @staticmethod
     def backward(ctx, gy):
@@ -514,9 +542,10 @@ class _SpMM(torch.autograd.Function):
         if shard is not None:
             # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the gathered dY
             rp, ci, va = graph.transposed()
-            return _sharded_spmm(rp, ci, va, gy.contiguous(), graph.n_local, shard), None, None
+            return _sharded_spmm(rp, ci, va, gy.contiguous(), graph.n_local, shard,
+                                 graph.t_long_segments), None, None
         rp, ci, va = graph.transposed()
-        return K.spmm(rp, ci, va, gy.contiguous(), graph.n), None, None
+        return K.spmm(rp, ci, va, gy.contiguous(), graph.n, long_segments=graph.t_long_segments), None, None
 
 
 def spmm(graph, x: torch.Tensor, shard=None) -> torch.Tensor:

@@ -83,6 +83,23 @@ def synthetic_graph_local(n: int, avg_deg: float, locality: float = 0.9, window:
     return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
 
 
+def synthetic_graph_skewed(n: int, avg_deg: float, gamma: float = 2.0, seed: int = 123, device="cpu") -> torch.Tensor:
+    """Same prologue as `synthetic_graph`, but one endpoint of every pair is drawn from a heavy-tailed
+    distribution (id = floor(n * u^gamma)): a few hub nodes collect a large share of the edges — node 0
+    about n^(-1/gamma) of them — the long-row regime of power-law graphs (ogbn-products' largest row has
+    ~17 k entries) that a uniform random graph never exercises (input class (b))."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    m = int(n * avg_deg / 2)
+    src = torch.randint(0, n, (m,), generator=g).to(device)
+    dst = (torch.rand(m, generator=g, dtype=torch.float64) ** gamma * n).long().clamp_(0, n - 1).to(device)
+    src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
 def synthetic_task(n: int, f: int, c: int, seed: int = 123, device="cpu", dtype=torch.float32):
     """randn features, uniform labels, first half of a seeded permutation as the training split
     (rand_train_test_idx, large/data_utils.py:13-37, with train_prop = 0.5)."""

@@ -173,12 +173,12 @@ def spmm_locality_probe(n, avg_deg, d, dtype, seed, dev, reps=5, locality=0.9, w
     del ei
     x = torch.randn(n, d, device=dev).to(dtype)
     for _ in range(2):
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n)
+        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=graph.long_segments)
     evs = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n)
+        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=graph.long_segments)
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()

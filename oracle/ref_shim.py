@@ -160,6 +160,8 @@ def load_reference(variant: str = "large"):
     if not reference_available():
         raise FileNotFoundError(f"reference not found under {REFERENCE_ROOT}")
     install_stand_ins()
+    if variant == "difformer":      # medium/difformer.py (self-contained: torch_sparse + PyG degree only)
+        return _exec(os.path.join(REFERENCE_ROOT, "medium", "difformer.py"), "_sgf_reference_medium_difformer")
     path = os.path.join(REFERENCE_ROOT, variant, "ours.py")
     if variant != "medium":
         return _exec(path, f"_sgf_reference_{variant}_ours")

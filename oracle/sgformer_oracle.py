@@ -321,6 +321,57 @@ def medium_forward(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dic
     return _linear(p, "fc", xx)
 
 
+# ------------------------------------------------------------------------------------------------
+# DIFFormer (medium/difformer.py): the "simple" kernel + gcn_conv
+# ------------------------------------------------------------------------------------------------
+def difformer_attention(qs: Tensor, ks: Tensor, vs: Tensor) -> Tensor:
+    """medium/difformer.py:18-39: SGFormer's attention with sum_l V_l in place of N * V_n."""
+    qn = qs / torch.norm(qs, p=2)
+    kn = ks / torch.norm(ks, p=2)
+    n = qs.shape[0]
+    kvs = torch.einsum("lhm,lhd->hmd", kn, vs.expand(-1, qs.shape[1], -1))
+    num = torch.einsum("nhm,hmd->nhd", qn, kvs) + vs.sum(dim=0, keepdim=True)
+    den = torch.einsum("nhm,hm->nh", qn, kn.sum(dim=0)).unsqueeze(-1) + n
+    return num / den
+
+
+DIFFORMER_DEFAULT_CFG = dict(num_layers=2, num_heads=1, alpha=0.5, use_bn=True, use_residual=True,
+                             use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+
+
+def difformer_forward(p: Dict[str, Tensor], x: Tensor, edge_index: Tensor, cfg: dict) -> Tensor:
+    """DIFFormer.forward with kernel='simple' and dropout inactive (medium/difformer.py:180-207)."""
+    c = dict(DIFFORMER_DEFAULT_CFG)
+    c.update(cfg)
+    h = c["num_heads"]
+    x = _linear(p, "fcs.0", x)
+    if c["use_bn"]:
+        x = _layer_norm(p, "bns.0", x)
+    x = torch.relu(x)
+    layer_ = [x]
+    for i in range(c["num_layers"]):
+        pre = f"convs.{i}."
+        d = p[pre + "Wq.weight"].shape[0] // h
+        qs = _linear(p, pre + "Wq", x).reshape(-1, h, d)
+        ks = _linear(p, pre + "Wk", x).reshape(-1, h, d)
+        vs = _linear(p, pre + "Wv", x).reshape(-1, h, d) if c["use_weight"] else x.reshape(-1, 1, d)
+        out = difformer_attention(qs, ks, vs)                                   # :118-121
+        if c["use_graph"]:                                                      # :124-129
+            g = torch.stack([gcn_propagate(vs[:, j], edge_index) for j in range(vs.shape[1])], dim=1)
+            gw = c["graph_weight"]
+            out = (1 - gw) * out + gw * g if gw > 0 else out + g
+        out = out.mean(dim=1)                                                   # :132
+        if c["use_source"]:
+            out = out + layer_[0]                                               # :134-135 (x_0 = layer_[0], :195)
+        if c["use_residual"]:
+            out = c["alpha"] * out + (1 - c["alpha"]) * layer_[i]               # :197
+        if c["use_bn"]:
+            out = _layer_norm(p, f"bns.{i + 1}", out)                           # :199
+        x = out
+        layer_.append(x)
+    return _linear(p, "fcs.1", x)                                               # :205
+
+
 def nll_loss(logits: Tensor, y: Tensor, idx: Tensor) -> Tensor:
     """large/main.py:139-141: log_softmax + NLLLoss on the training rows."""
     lp = torch.log_softmax(logits, dim=1)

@@ -40,6 +40,8 @@ def install(variant: str = "large", dtype: str | None = None):
     elif dtype not in (None, "f32", "fp32", "float32"):
         raise SystemExit(f"sgformer_amd.launch: unknown --sgf-dtype {dtype!r}")
     sys.modules["ours"] = mod
+    if variant == "medium":   # medium/parse.py:4 `from difformer import *` (--method difformer)
+        sys.modules["difformer"] = importlib.import_module("sgformer_amd.difformer")
     return mod
 
 

@@ -633,17 +633,23 @@ class _SmallGemms:
         return False
 
 
-def _attn_h_small(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv):
+def _attn_h_small(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv, sum_v: bool = False):
     """The d x d algebra of include/sgf.h (sgf_attn_h_*): fp32, tiny, differentiable torch ops.
-    G = h^T h, s = sum_n h_n over ALL rows (n_rows of them); weights [d, d_in], biases [d]."""
+    G = h^T h, s = sum_n h_n over ALL rows (n_rows of them); weights [d, d_in], biases [d].
+    sum_v=False: SGFormer's numerator  q S + N V_n   (large/ours.py:137-138);
+    sum_v=True : DIFFormer's numerator q S + sum_l V_l (medium/difformer.py:26-29)."""
     wk_s, wv_s, wq_s = wk @ s, wv @ s, wq @ s
     s0 = wk @ G @ wv.t() + torch.outer(wk_s, bv) + torch.outer(bk, wv_s) + n_rows * torch.outer(bk, bv)
     z0 = wk_s + n_rows * bk
     ssq_q = ((wq @ G) * wq).sum() + 2.0 * torch.dot(bq, wq_s) + n_rows * torch.dot(bq, bq)
     ssq_k = ((wk @ G) * wk).sum() + 2.0 * torch.dot(bk, wk_s) + n_rows * torch.dot(bk, bk)
     c = 1.0 / (torch.sqrt(ssq_q) * torch.sqrt(ssq_k))
-    M = c * (wq.t() @ s0) + n_total * wv.t()
-    m = c * (bq @ s0) + n_total * bv
+    if sum_v:
+        M = c * (wq.t() @ s0)
+        m = c * (bq @ s0) + wv_s + n_rows * bv
+    else:
+        M = c * (wq.t() @ s0) + n_total * wv.t()
+        m = c * (bq @ s0) + n_total * bv
     w = c * (wq.t() @ z0)
     beta = (c * torch.dot(bq, z0) + n_total).reshape(1)
     return M.contiguous(), m.contiguous(), w.contiguous(), beta.contiguous()
@@ -655,7 +661,7 @@ class _AttentionFromInput(torch.autograd.Function):
     input").  wv / bv None = V is h itself (use_weight=False, large/ours.py:128)."""
 
     @staticmethod
-    def forward(ctx, h, wq, bq, wk, bk, wv, bv, shard, n_override):
+    def forward(ctx, h, wq, bq, wk, bk, wv, bv, shard, n_override, sum_v=False):
         K.check(h)
         h = _rows(h)
         n, d = h.shape
@@ -673,17 +679,17 @@ class _AttentionFromInput(torch.autograd.Function):
             n_rows = float(shard.n_global)
         n_total = n_rows if n_override is None else float(n_override)
         with _SmallGemms():
-            M, m, w, beta = _attn_h_small(G, s, n_rows, n_total, *f32)
+            M, m, w, beta = _attn_h_small(G, s, n_rows, n_total, *f32, sum_v=sum_v)
         out, den = K.attn_h_fwd(h, M, m, w, beta)
         ctx.save_for_backward(h, out, den, G, s, M, w, *f32)
         ctx.meta = (n_rows, n_total, shard, wv is None,
-                    [None if t is None else t.dtype for t in (wq, bq, wk, bk, wv, bv)])
+                    [None if t is None else t.dtype for t in (wq, bq, wk, bk, wv, bv)], bool(sum_v))
         return out
 
     @staticmethod
     def backward(ctx, g):
         h, out, den, G, s, M, w, *f32 = ctx.saved_tensors
-        n_rows, n_total, shard, v_is_h, dtypes = ctx.meta
+        n_rows, n_total, shard, v_is_h, dtypes, sum_v = ctx.meta
         d = h.shape[1]
         g = _rows(g.contiguous())
         hstats = K.attn_h_bwd_reduce(h, g, out, den)      # [dM | dw | dm | dbeta]
@@ -694,7 +700,7 @@ class _AttentionFromInput(torch.autograd.Function):
         # backward through the d x d algebra: re-run it under autograd on leaf copies (microseconds)
         with torch.enable_grad(), _SmallGemms():
             leaves = [t.detach().requires_grad_(True) for t in (G, s, *f32)]
-            outs = _attn_h_small(leaves[0], leaves[1], n_rows, n_total, *leaves[2:])
+            outs = _attn_h_small(leaves[0], leaves[1], n_rows, n_total, *leaves[2:], sum_v=sum_v)
             grads = torch.autograd.grad(outs, leaves, grad_outputs=(dM, dm, dw_, dbeta), allow_unused=True)
         dG, ds = grads[0], grads[1]
         D = (dG + dG.t()).contiguous()
@@ -705,11 +711,13 @@ class _AttentionFromInput(torch.autograd.Function):
         if v_is_h:
             pg[4] = pg[5] = None
         pg = [None if (t is None or dt is None) else t.to(dt) for t, dt in zip(pg, dtypes)]
-        return (dh, *pg, None, None)
+        return (dh, *pg, None, None, None)
 
 
-def attention_from_input(h, wq, bq, wk, bk, wv=None, bv=None, shard=None, n_total=None):
-    return _AttentionFromInput.apply(h, wq, bq, wk, bk, wv, bv, shard, n_total)
+def attention_from_input(h, wq, bq, wk, bk, wv=None, bv=None, shard=None, n_total=None, sum_v=False):
+    """One-head linear attention from the un-projected input.  sum_v=True: DIFFormer's 'simple' kernel
+    (numerator q S + sum_l V_l instead of q S + N V_n; medium/difformer.py:18-39)."""
+    return _AttentionFromInput.apply(h, wq, bq, wk, bk, wv, bv, shard, n_total, sum_v)
 
 
 def attention_stats(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):

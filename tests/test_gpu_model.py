@@ -334,6 +334,46 @@ def test_baseline_configs_properties(cuda, name, n, f, d, c, deg, dtype):
     assert lo * frac * l0 <= l0 - l1 <= hi * frac * l0, (l0, l1, frac * l0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg,d", [(dict(num_layers=2, num_heads=1), 64),
+                                   (dict(num_layers=1, num_heads=2, use_weight=False, graph_weight=0.3, use_source=True), 32),
+                                   (dict(num_layers=2, num_heads=1, alpha=0.2, graph_weight=0.7), 256)])
+def test_difformer_parity(cuda, dtype, cfg, d):
+    """medium/difformer.py drop-in (row N4): logits and parameter gradients against the fp64 oracle."""
+    from sgformer_amd import difformer as M
+    n, f, c = 3000, 40, 7
+    torch.manual_seed(5)
+    m = M.DIFFormer(f, d, c, dropout=0.0, **cfg)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith("bias"):
+                v.normal_(0, 0.1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 8.0, seed=6)
+    y = torch.randint(0, c, (n,))
+    idx = torch.randperm(n)[: n // 2]
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(cuda).train()
+    logits = m(_Data(x.to(cuda, dtype), ei.to(cuda)))
+    O.nll_loss(logits.float(), y.to(cuda), idx.to(cuda)).backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    ref = O.difformer_forward(p64, x.to(dtype).double(), ei, cfg)
+    O.nll_loss(ref, y, idx).backward()
+    if dtype == torch.float32:
+        assert float((logits.detach().double().cpu() - ref.detach()).abs().max()) <= 1e-4
+    else:
+        assert float((logits.detach().double().cpu() - ref.detach()).norm() / ref.detach().norm()) <= 3e-2
+    gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+    for k, prm in m.named_parameters():
+        g = p64[k].grad
+        if g is None:
+            continue
+        assert prm.grad is not None and prm.grad.dtype == torch.float32, k
+        err = float((prm.grad.double().cpu() - g).norm())
+        tol = 1e-3 if dtype == torch.float32 else 8e-2
+        assert err <= tol * (float(g.norm()) + 1e-2 * gmax), (k, err, float(g.norm()))
+
+
 # ------------------------------------------------------------------------------------------------
 # property test over the constructor-flag space (SURVEY.md §8c G7)
 # ------------------------------------------------------------------------------------------------

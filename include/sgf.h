@@ -297,6 +297,17 @@ int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2,
               int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dropout.   Replaces F.dropout(x, p, training=True) at large/ours.py:81,92,202,216 (and the
+ * residual add that follows it in GraphConv, :92-93):   y = x * keep / (1 - p) [+ res]
+ * keep ~ Bernoulli(1 - p) is a pure function of (seed, logical element index row*d + col) —
+ * Philox4x32-10 — so NO mask is stored: the backward is the same call on dL/dy with the same seed
+ * and res = NULL.  (The RNG stream differs from ATen's, as the CPU and CUDA streams of the
+ * reference differ from each other; parity with dropout on is statistical.)  d % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int sgf_dropout(const void* x, int64_t ldx, const void* res, int64_t ldr, float p, uint64_t seed,
+                int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * N4 — the trainer's loss.   Replaces large/main.py:139-141
  *     out = F.log_softmax(out, dim=1);  loss = NLLLoss()(out[train_idx], label.squeeze(1)[train_idx])
  * (5 ATen kernels over [N, C] and [M, C] temporaries; its nll_loss forward / backward kernels alone

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsgf.so")
@@ -68,6 +68,8 @@ SIGNATURES = {
                                    c_int32, _P, _P, c_size_t, _P]),
     "sgf_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float,
                                    c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
+    "sgf_dropout": (c_int32, [_P, c_int64, _P, c_int64, c_float, c_uint64, c_int64, c_int32, c_int32, _P,
+                              c_int64, _P]),
     "sgf_nll_workspace_bytes": (c_size_t, [c_int64]),
     "sgf_nll_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, c_size_t, _P]),
     "sgf_nll_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_float, _P,

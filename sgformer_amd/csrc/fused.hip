@@ -500,6 +500,64 @@ __global__ __launch_bounds__(kThreads) void k_sum_n(SumArgs a, int64_t n, int d,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dropout (F.dropout in large/ours.py:81,92,202,216), fused with the residual add that follows it in
+// GraphConv (:92-93) and WITHOUT a stored mask: the keep decisions are a pure function of
+// (seed, element index) — Philox4x32-10, one counter per 4 consecutive elements of a row — so the
+// backward recomputes them.  ATen's native_dropout writes and re-reads an [N, d] mask.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c[0];
+  const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c[2];
+  const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+  const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// 4 keep flags (bit j = element 4*chunk + j is kept) for chunk index `chunk` under `seed`
+__device__ __forceinline__ uint32_t dropout_keep4(uint64_t seed, uint64_t chunk, float p) {
+  uint32_t c[4] = {static_cast<uint32_t>(chunk), static_cast<uint32_t>(chunk >> 32), 0x5347464du, 0u};
+  uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float u = static_cast<float>(c[j] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+    bits |= (u >= p ? 1u : 0u) << j;
+  }
+  return bits;
+}
+
+// y = x * keep / (1 - p) [+ res];  MODE 1 (backward): y = x * keep / (1 - p) with x = dL/dy
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_dropout(const T* __restrict__ x, int64_t ldx,
+                                                      const T* __restrict__ res, int64_t ldr, float p,
+                                                      float scale, uint64_t seed, int64_t n, int d,
+                                                      T* __restrict__ y, int64_t ldy) {
+  const int f4 = d / 4;
+  const int64_t total = n * f4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / f4;
+    const int col = static_cast<int>(i % f4) * 4;
+    const uint32_t keep = dropout_keep4(seed, static_cast<uint64_t>(i), p);
+    const float4 v = load4<T>(x + row * ldx + col);
+    float4 o = make_float4((keep & 1u) ? v.x * scale : 0.f, (keep & 2u) ? v.y * scale : 0.f,
+                           (keep & 4u) ? v.z * scale : 0.f, (keep & 8u) ? v.w * scale : 0.f);
+    if (res != nullptr) {
+      const float4 r = load4<T>(res + row * ldr + col);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    store4<T>(y + row * ldy + col, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // N4: log_softmax + NLLLoss on the training rows (large/main.py:139-141), one wave per row.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNllMaxBlocks = 1024;
@@ -901,6 +959,29 @@ extern "C" int sgf_sum_n(const void* const* xs, const int64_t* lds, int32_t k, i
     hipLaunchKernelGGL((k_sum_n<float>), grid, dim3(kThreads), 0, st, a, n, d, static_cast<float*>(y), ldy);
   else
     hipLaunchKernelGGL((k_sum_n<uint16_t>), grid, dim3(kThreads), 0, st, a, n, d,
+                       static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_dropout(const void* x, int64_t ldx, const void* res, int64_t ldr, float p,
+                           uint64_t seed, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,
+                           void* stream) {
+  int rc = check_ew("sgf_dropout", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(p >= 0.f && p <= 1.f, SGF_E_INVALID, "sgf_dropout: p must be in [0, 1] (p=%f)", p);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(x && y && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SGF_E_INVALID,
+              "sgf_dropout: bad pointer / ld");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float scale = p < 1.f ? 1.0f / (1.0f - p) : 0.f;
+  const dim3 grid(ew_grid(n * (d / 4)));
+  if (dtype == SGF_F32)
+    hipLaunchKernelGGL((k_dropout<float>), grid, dim3(kThreads), 0, st, static_cast<const float*>(x), ldx,
+                       static_cast<const float*>(res), ldr, p, scale, seed, n, d, static_cast<float*>(y), ldy);
+  else
+    hipLaunchKernelGGL((k_dropout<uint16_t>), grid, dim3(kThreads), 0, st, static_cast<const uint16_t*>(x),
+                       ldx, static_cast<const uint16_t*>(res), ldr, p, scale, seed, n, d,
                        static_cast<uint16_t*>(y), ldy);
   SGF_LAUNCH_CHECK();
   return SGF_OK;

@@ -354,6 +354,16 @@ class HipKernels:
                       _stream(dev))
         return out
 
+    # ---- dropout (+ residual), mask recomputed from the seed ----
+    @staticmethod
+    def dropout(x, res, p: float, seed: int) -> torch.Tensor:
+        n, d = x.shape
+        y = torch.empty((n, d), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("sgf_dropout", _ptr(x), _ld(x), _ptr(res), _ld(res), float(p), int(seed), n, d,
+                      _code(x), _ptr(y), y.stride(0), _stream(x.device))
+        return y
+
     # ---- N4: log_softmax + NLL on the training rows ----
     @staticmethod
     def nll_fwd(logits, labels, idx) -> torch.Tensor:
@@ -828,6 +838,34 @@ class _BNActRes(torch.autograd.Function):
 
 def bn_act_res(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard=None):
     return _BNActRes.apply(x, res, gamma, beta, mean, rstd, relu, training, n_tot, shard)
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout [+ residual]  (F.dropout at large/ours.py:81,92,202,216; the add of :93)
+# ------------------------------------------------------------------------------------------------
+class _DropoutRes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, p: float):
+        K.check(x, res)
+        x, res = _rows(x), _rows(res)
+        # a fresh 62-bit seed from torch's CPU generator: reproducible under torch.manual_seed, no sync
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # ranks seeded alike must not drop the same pattern in their row shards
+            seed = (seed + (torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15) % (2 ** 62)
+        ctx.meta = (float(p), seed, res is not None)
+        return K.dropout(x, res, p, seed)
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, seed, has_res = ctx.meta
+        gy = _rows(gy.contiguous())
+        return K.dropout(gy, None, p, seed), (gy if has_res else None), None
+
+
+def dropout_res(x, res, p: float):
+    """y = dropout(x, p) [+ res] in one pass, no stored mask (the backward recomputes it from the seed)."""
+    return _DropoutRes.apply(x, res, p)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -65,14 +65,18 @@ def _lin(x, lin: nn.Linear):
     return ops.linear(x, lin.weight, lin.bias)
 
 
-def _drop(x, p, training):
+def _drop(x, p, training, res=None):
+    """F.dropout(x, p, training) [+ res]; the fused kernel (no stored mask) when the width allows."""
     if training and p is not None and p > 0.0:
-        return F.dropout(x, p=p, training=True)
+        if x.dim() == 2 and x.shape[1] % 4 == 0:
+            return ops.dropout_res(x, res, float(p))
+        x = F.dropout(x, p=p, training=True)
+        return x if res is None else x + res
     if p is None:
         # large/parse.py:95 leaves --trans_dropout without a default: the reference then crashes
         # inside F.dropout(p=None); surface the same misuse early and clearly.
         raise TypeError("dropout probability is None (pass --trans_dropout / --gnn_dropout)")
-    return x
+    return x if res is None else x + res
 
 
 def full_attention_conv(qs, ks, vs, output_attn=False, shard=None):
@@ -198,10 +202,8 @@ class GraphConv(nn.Module):
                 x = torch.relu(x)
             if fuse_res:
                 x = x + res
-        x = _drop(x, self.dropout, self.training)
-        if res is not None and not fuse_res:
-            x = x + res
-        return x
+        # dropout active: the residual add of large/ours.py:93 rides along in the dropout kernel
+        return _drop(x, self.dropout, self.training, res if (res is not None and not fuse_res) else None)
 
     def forward(self, x, edge_index):
         ops._require_cuda(x, edge_index)

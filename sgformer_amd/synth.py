@@ -18,6 +18,9 @@ SHAPES = {
     # BASELINE.json config 5 (ogbn-papers100M-shaped: 111,059,956 nodes, ~30 stored entries per row,
     # 128 features, 172 classes, hidden 128) cut to the share ONE of 8 GPUs holds
     "papers100M-shard8": (13882494, 29.0, 128, 172, 128),
+    # the same, as a WEAK-scaling workload: N is the node count PER RANK, the graph spans world * N nodes and
+    # every rank generates only its own rows (synthetic_graph_shard): 8 ranks = the full 111 M-node shape
+    "papers100M-weak": (13882494, 29.0, 128, 172, 128),
 }
 
 # constructor keywords of the large/run.sh recipes (dropout overridden by the caller)
@@ -43,6 +46,9 @@ RECIPES = {
                   gnn_use_residual=True, gnn_use_weight=True, gnn_use_init=True, gnn_use_act=True,
                   use_graph=True, graph_weight=0.5, aggregate="add"),
 }
+
+
+RECIPES["papers100M-weak"] = RECIPES["papers100M-shard8"]
 
 
 def synthetic_graph(n: int, avg_deg: float, seed: int = 123, directed: bool = False,
@@ -98,6 +104,48 @@ def synthetic_graph_skewed(n: int, avg_deg: float, gamma: float = 2.0, seed: int
     del src, dst, keep
     loops = torch.arange(n, device=device)
     return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
+def synthetic_graph_shard(n_per_rank: int, avg_deg: float, rank: int, world: int, seed: int = 123,
+                          device="cpu") -> torch.Tensor:
+    """Rank `rank`'s share of a uniform random graph over world * n_per_rank nodes, generated WITHOUT
+    ever materialising (or sorting) the global edge list — the weak-scaling workload of BASELINE.json
+    config 5 (papers100M-shaped: 111 M nodes over 8 GPUs).
+
+    Returns int64 [2, nnz_local] with GLOBAL node ids: exactly the edges whose target
+    (edge_index[1], the row of the normalised adjacency, large/ours.py:25-33) lies in
+    [rank * n_per_rank, (rank + 1) * n_per_rank), after the trainer prologue (symmetrise + coalesce,
+    no self pairs, one self-loop per node).  The undirected pairs between the node ranges of ranks
+    a <= b are drawn from a generator seeded by (seed, a, b), so ranks a and b produce the SAME
+    pairs independently and the union over ranks is a symmetric graph; every pair of ranges gets
+    its uniform share of the n_total * avg_deg / 2 pairs.  (Use a generator of the same device
+    type on every rank — the two sides of a block must see the same stream.)"""
+    n_total = n_per_rank * world
+    m_block = n_total * avg_deg / 2 / (world * world)      # pairs per ORDERED pair of ranges
+    src_parts, dst_parts = [], []
+    base = rank * n_per_rank
+    for peer in range(world):
+        a, b = min(rank, peer), max(rank, peer)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + a * 1009 + b)
+        m = int(round(m_block if a == b else 2 * m_block))
+        u = torch.randint(0, n_per_rank, (m,), generator=g, device=device) + a * n_per_rank
+        v = torch.randint(0, n_per_rank, (m,), generator=g, device=device) + b * n_per_rank
+        if a == b:                       # both ends mine: both directions
+            src_parts += [u, v]
+            dst_parts += [v, u]
+        elif rank == a:                  # u is mine: the stored entry is (source v -> target u)
+            src_parts.append(v)
+            dst_parts.append(u)
+        else:
+            src_parts.append(u)
+            dst_parts.append(v)
+    src, dst = torch.cat(src_parts), torch.cat(dst_parts)
+    del src_parts, dst_parts
+    keep = src != dst
+    key = torch.unique(dst[keep] * n_total + src[keep])     # coalesce
+    del src, dst, keep
+    loops = torch.arange(base, base + n_per_rank, device=device)
+    return torch.stack([torch.cat([key % n_total, loops]), torch.cat([key // n_total, loops])])
 
 
 def synthetic_task(n: int, f: int, c: int, seed: int = 123, device="cpu", dtype=torch.float32):

@@ -104,3 +104,166 @@ def test_sharded_step_matches_full_graph(world, cfg_name, directed, chunk_cols):
         assert e["grad"] < 2e-3, e
         assert e["running_var"] < 1e-5, e
         assert e["gathered"] > 0 and e["reduced"] > 0
+
+
+def _worker_local_edges(rank, world, port, ret):
+    """Weak-scaling mode: every rank generates ONLY its own rows of the graph (synthetic_graph_shard) and
+    hands `model` those local edges; the union over ranks is the reference graph."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_CHUNK_COLS="4")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import sgformer_oracle as O
+        from sgformer_amd import ops, synth
+        from sgformer_amd.dist import ShardContext, ShardedGraph, shard_model, sharded_nll_loss
+        from sgformer_amd.ours import SGFormer
+        from tests.cpu_kernels import CpuKernels
+        from tests.test_host import CONFIGS
+
+        ops.set_kernels(CpuKernels())
+        cfg = CONFIGS["products"]
+        n_per, f, d, c = 67, 10, 16, 4
+        n = n_per * world
+        ei_local = synth.synthetic_graph_shard(n_per, 6.0, rank, world, seed=9)
+        parts = [None] * world
+        dist.all_gather_object(parts, ei_local)
+        ei = torch.cat(parts, dim=1)                      # the global graph, for the reference only
+        errs = {"targets_local": bool(((ei_local[1] >= rank * n_per) & (ei_local[1] < (rank + 1) * n_per)).all())}
+        key = ei[0] * n + ei[1]
+        errs["symmetric"] = bool(torch.equal(torch.sort(key)[0], torch.sort(ei[1] * n + ei[0])[0]))
+        errs["coalesced"] = bool(torch.unique(key).numel() == key.numel())
+        errs["self_loops"] = int((ei[0] == ei[1]).sum()) == n
+
+        torch.manual_seed(5)
+        x = torch.randn(n, f)
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: n // 2]
+        p = O.init_params(cfg, f, d, c, seed=6)
+
+        ctx = ShardContext(n, local_edges=True)
+        # the block built from local edges alone == the block cut out of the full CSR
+        g_loc = ShardedGraph(ei_local, ctx)
+        g_ref = ShardedGraph(ei, ShardContext(n))
+        errs["csr_bit_exact"] = bool(torch.equal(g_loc.rowptr, g_ref.rowptr) and torch.equal(g_loc.colind, g_ref.colind)
+                                     and torch.equal(g_loc.val, g_ref.val))
+
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        shard_model(m, ctx)
+        m.train()
+        logits = m(ctx.shard_rows(x), ei_local)
+        loss = sharded_nll_loss(logits, ctx.shard_rows(y), ctx.local_index(idx), idx.numel())
+        loss.backward()
+        ctx.sync_grads(m.parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+
+        p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+        ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True, bn_stats={})
+        lref = O.nll_loss(ref, y, idx)
+        lref.backward()
+        errs["logits"] = float((logits.detach().double() - ref.detach()[ctx.r0:ctx.r1]).abs().max())
+        errs["loss"] = abs(float(total) - float(lref))
+        gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+        gerr = 0.0
+        for k, prm in m.named_parameters():
+            if p64[k].grad is not None:
+                e = float((prm.grad.double() - p64[k].grad).norm())
+                gerr = max(gerr, e / (float(p64[k].grad.norm()) + 1e-3 * gmax))
+        errs["grad"] = gerr
+
+        # contract violations fail loudly: a foreign target, an asymmetric graph
+        bad = ei_local.clone()
+        if rank == world - 1:   # on ONE rank only: the others must raise too (no rank left in a collective)
+            bad[1, 0] = (int(bad[1, 0]) + n_per) % n
+        try:
+            ShardedGraph(bad, ctx)
+            errs["foreign_target_raises"] = False
+        except ValueError:
+            errs["foreign_target_raises"] = True
+        asym = ei_local
+        if rank == 0:   # drop one off-diagonal edge on one rank only
+            off = (ei_local[0] != ei_local[1]).nonzero()[0, 0]
+            asym = torch.cat([ei_local[:, :off], ei_local[:, off + 1:]], dim=1)
+        try:
+            ShardedGraph(asym, ctx)
+            errs["asymmetric_raises"] = False
+        except ValueError:
+            errs["asymmetric_raises"] = True
+        ret[rank] = errs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_local_edge_shards_match_full_graph(world):
+    """BASELINE.json config 5 (weak scaling): no rank ever sees the global edge list."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_local_edges, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        e = ret[rank]
+        for flag in ("targets_local", "symmetric", "coalesced", "self_loops", "csr_bit_exact",
+                     "foreign_target_raises", "asymmetric_raises"):
+            assert e[flag], (flag, e)
+        assert e["logits"] < 5e-5, e
+        assert e["loss"] < 1e-5, e
+        assert e["grad"] < 2e-3, e
+
+
+def _worker_bench_inputs(rank, world, port, workload, ret):
+    """bench.py's own input builder + step sequence (make_inputs -> shard_model -> sharded loss ->
+    sync_grads) under gloo with the CPU kernel table: what `bench.py --gpus N` runs on RCCL."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import bench
+        from sgformer_amd import ops
+        from sgformer_amd.dist import shard_model, sharded_nll_loss
+        from sgformer_amd.ours import SGFormer
+        from tests.cpu_kernels import CpuKernels
+
+        ops.set_kernels(CpuKernels())
+        n, f, c, d, cfg, weak, ei, x, y, idx, n_train, ctx = bench.make_inputs(workload, 90, 3, rank, world, "cpu")
+        torch.manual_seed(3)
+        m = SGFormer(f, 16, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        shard_model(m, ctx)
+        m.train()
+        logits = m(x, ei)
+        loss = sharded_nll_loss(logits, y, idx, n_train)
+        loss.backward()
+        ctx.sync_grads(m.parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        g0 = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+        gs = [None] * world
+        dist.all_gather_object(gs, g0)
+        ret[rank] = {"weak": weak, "n": n, "rows": x.shape[0], "logit_rows": logits.shape[0], "loss": float(total),
+                     "n_train": n_train, "local_edges": ctx.local_edges,
+                     "targets_local": bool(((ei[1] >= ctx.r0) & (ei[1] < ctx.r1)).all()),
+                     "grads_equal": all(torch.equal(g, gs[0]) for g in gs)}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("workload", ["papers100M-weak", "ogbn-products"])
+def test_bench_inputs_and_step_under_gloo(workload):
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_bench_inputs, args=(world, port, workload, ret), nprocs=world, join=True)
+    for rank in range(world):
+        e = ret[rank]
+        weak = workload.endswith("-weak")
+        assert e["weak"] == weak and e["local_edges"] == weak
+        assert e["n"] == (90 * world if weak else 90)            # weak: N grows with the world
+        assert e["rows"] == e["logit_rows"] == (90 if weak else 45)
+        assert e["n_train"] == (90 if weak else 45)              # GLOBAL count of training rows
+        if weak:
+            assert e["targets_local"]
+        assert e["grads_equal"] and e["loss"] == e["loss"] and 0 < e["loss"] < 50
+    assert ret[0]["loss"] == ret[1]["loss"]

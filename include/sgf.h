@@ -14,9 +14,9 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host.
  *   - the caller allocates and owns every buffer, including outputs and workspaces
  *     (sizes from the *_workspace_bytes queries).  No hidden allocation, no host sync,
- *     no thread-local state: calls are re-entrant and may come from the autograd thread.
+ *     no per-thread compute state: calls are re-entrant and may come from the autograd thread.
  *   - return value: 0 = ok, negative = error (SGF_E_*); sgf_last_error() gives the text of the
- *     most recent failure on the calling thread's process (best effort, not thread-local).
+ *     most recent failure ON THE CALLING THREAD (errno-style; valid until that thread's next failure).
  *   - matrices are row-major with an explicit leading dimension `ld*` counted in ELEMENTS.
  *   - dtype codes: SGF_F32 = 0 (fp32 storage), SGF_BF16 = 1 (bf16 storage, fp32 accumulate).
  */

@@ -1,16 +1,14 @@
 // capi.hip — version + error plumbing of the C ABI (include/sgf.h).
 #include "common.h"
 
-#include <mutex>
-
 namespace sgf {
 namespace {
-std::mutex g_err_mu;
-char g_err[1024] = "";
+// errno-style: the text belongs to the calling thread (the autograd engine calls the backward entry
+// points from its own thread; a failure there must not overwrite or tear the main thread's message)
+thread_local char g_err[1024] = "";
 }  // namespace
 
 void set_error(const char* fmt, ...) {
-  std::lock_guard<std::mutex> lk(g_err_mu);
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);

@@ -53,6 +53,56 @@ def test_header_binding_and_library_agree():
     assert lib.sgf_attn_bstats_len(1, 256) == 256 * 256 + 256 + 1
 
 
+def test_argument_errors_are_reported_per_thread():
+    """Bad arguments are rejected on the host BEFORE any HIP call (safe without a GPU) with
+    SGF_E_INVALID and an errno-style, per-thread message."""
+    import threading
+    from sgformer_amd import _lib
+    if not _lib.available():
+        pytest.skip("libsgf.so not built (run `make`)")
+    lib = _lib.load()
+    assert lib.sgf_spmm(None, None, None, None, 0, None, 0, 10, 256, 0, None) == -1      # null pointers
+    main_msg = lib.sgf_last_error()
+    assert b"sgf_spmm" in main_msg
+    seen = {}
+
+    def other():
+        seen["before"] = lib.sgf_last_error()
+        seen["rc"] = lib.sgf_axpby(None, 0, 1.0, None, 0, 1.0, 5, 4, 0, None, 0, None)
+        seen["after"] = lib.sgf_last_error()
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen["before"] == b"" and seen["rc"] < 0 and b"sgf_axpby" in seen["after"]
+    assert lib.sgf_last_error() == main_msg          # the other thread's failure did not overwrite ours
+
+
+def test_every_entry_point_rejects_null_pointers_on_the_host():
+    """All-NULL device pointers with otherwise plausible sizes and a valid dtype: every compute entry
+    point must return a negative SGF_E_* code and name itself in sgf_last_error() — validated on the
+    host, before any launch (so this runs, and cannot crash, on the GPU-less build host)."""
+    from sgformer_amd import _lib
+    if not _lib.available():
+        pytest.skip("libsgf.so not built (run `make`)")
+    lib = _lib.load()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sgf.h")).read(), flags=re.S)
+    checked = 0
+    for name, (_res, argtypes) in sorted(_lib.SIGNATURES.items()):
+        if name in ("sgf_version", "sgf_last_error") or name.endswith(("_bytes", "_len")):
+            continue
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        pnames = [a.strip().split()[-1].lstrip("*") for a in m.group(1).split(",")]
+        assert len(pnames) == len(argtypes), name
+        vals = [None if t is ctypes.c_void_p else 0.5 if t in (ctypes.c_float, ctypes.c_double)
+                else 0 if "dtype" in pn else 8 for t, pn in zip(argtypes, pnames)]
+        rc = getattr(lib, name)(*vals)
+        assert rc < 0, (name, rc)
+        assert name.encode() in lib.sgf_last_error(), (name, lib.sgf_last_error())
+        checked += 1
+    assert checked >= 25
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from sgformer_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -462,3 +462,19 @@ def test_difformer_state_dict_matches_reference_keys():
     assert list(sa.keys()) == list(sb.keys())
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_kernel_probe_drives_the_kernel_table(cpu_table):
+    """scripts/kernel_probe.py (the per-kernel GB/s loop for the GPU box) calls every table entry with
+    the right signature — checked here through the CPU table so it cannot rot between GPU sessions."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_probe", os.path.join(ROOT, "scripts", "kernel_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for dtype in (torch.float32, torch.bfloat16):
+        rows = mod.run(200, 64, dtype, "cpu", reps=1)
+        assert len(rows) >= 15 and all(r["ms"] >= 0 and r["GBps"] >= 0 for r in rows)
+        unit = 200 * 64 * (4 if dtype == torch.float32 else 2) / 1e9
+        assert abs(rows[0]["algorithmic_GB"] - round(2 * unit, 3)) < 1e-9
+    assert [r["kernel"] for r in mod.run(200, 64, torch.float32, "cpu", reps=1, only=("apply",))] == \
+        ["sgf_attn_h_bwd_apply", "sgf_bn_apply (residual, relu)", "sgf_bn_bwd_apply"]

@@ -478,3 +478,58 @@ def test_kernel_probe_drives_the_kernel_table(cpu_table):
         assert abs(rows[0]["algorithmic_GB"] - round(2 * unit, 3)) < 1e-9
     assert [r["kernel"] for r in mod.run(200, 64, torch.float32, "cpu", reps=1, only=("apply",))] == \
         ["sgf_attn_h_bwd_apply", "sgf_bn_apply (residual, relu)", "sgf_bn_bwd_apply"]
+
+
+# ------------------------------------------------------------------------------------------------
+# the constructor-flag space on the CPU table (the GPU suite runs the same property on libsgf)
+# ------------------------------------------------------------------------------------------------
+try:
+    from hypothesis import HealthCheck, assume, given, settings, strategies as st
+    _HAVE_HYP = True
+except Exception:  # pragma: no cover
+    _HAVE_HYP = False
+
+if _HAVE_HYP:
+    _flags = st.fixed_dictionaries(dict(
+        trans_num_layers=st.integers(1, 2), trans_num_heads=st.integers(1, 2), trans_use_bn=st.booleans(),
+        trans_use_residual=st.booleans(), trans_use_weight=st.booleans(), trans_use_act=st.booleans(),
+        gnn_num_layers=st.integers(1, 3), gnn_use_weight=st.booleans(), gnn_use_init=st.booleans(),
+        gnn_use_bn=st.booleans(), gnn_use_residual=st.booleans(), gnn_use_act=st.booleans(),
+        use_graph=st.booleans(), graph_weight=st.sampled_from([0.2, 0.5, 0.8]),
+        aggregate=st.sampled_from(["add", "cat"]), alpha=st.sampled_from([None, 0.3])))
+
+    @settings(max_examples=25, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(cfg=_flags, n=st.integers(3, 150), d=st.sampled_from([8, 12, 16]), directed=st.booleans(),
+           seed=st.integers(0, 10 ** 6))
+    def test_flag_space_host_logic(cpu_table, cfg, n, d, directed, seed):
+        """Random points of the constructor-flag space (which fast paths the module picks — attention
+        from the input vs materialised Q/K/V, fan-out hub, fused BN/LN glue, cat vs add — depends on
+        them) x ragged sizes x directed graphs: the module's wiring equals the fp64 oracle."""
+        from sgformer_amd.ours import SGFormer
+        # use_graph=False with aggregate='cat' crashes in the reference too (large/ours.py:257-259 vs :273-275)
+        assume(cfg["use_graph"] or cfg["aggregate"] == "add")
+        f, c = 7, 3
+        torch.manual_seed(seed)
+        x = torch.randn(n, f)
+        ei = O.synthetic_graph(n, 4.0, seed=seed % 1000, directed=directed)
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: max(n // 2, 1)]
+        p = O.init_params(cfg, f, d, c, seed=seed % 97)
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        m.train()
+        logits = m(x, ei)
+        O.nll_loss(logits, y, idx).backward()
+        p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+        ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True)
+        O.nll_loss(ref, y, idx).backward()
+        assert float((logits.detach().double() - ref.detach()).abs().max()) <= 1e-4
+        gmax = max([float(v.grad.norm()) for v in p64.values() if v.grad is not None] + [1e-30])
+        for k, prm in m.named_parameters():
+            g = p64[k].grad
+            if g is None:
+                continue
+            assert prm.grad is not None, k
+            err = float((prm.grad.double() - g).norm())
+            assert err <= 2e-3 * (float(g.norm()) + 1e-3 * gmax), (k, err, float(g.norm()))

@@ -94,7 +94,7 @@ class ShardedGraph:
         # same arithmetic as k_finalize (csr.hip): sqrt(1/d_t) * sqrt(1/d_s) in fp32, inf -> 0
         dinv = (1.0 / deg.to(torch.float32)).sqrt()
         counts = self.rowptr[1:] - self.rowptr[:-1]
-        row_of = torch.repeat_interleave(torch.arange(ctx.r0, ctx.r1, device=self.device), counts)
+        row_of = torch.repeat_interleave(torch.arange(ctx.r0, ctx.r1, device=self.device), counts, output_size=full.nnz)
         val = dinv[row_of] * dinv[self.colind.long()]
         self.val = torch.nan_to_num(val, nan=0.0, posinf=0.0, neginf=0.0)
         self.long_segments = ops.long_row_segments(self.rowptr)

@@ -37,6 +37,19 @@ import torch.distributed as dist
 from . import ops
 
 
+def _mix64(x: torch.Tensor, stream: int) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap = arithmetic mod 2^64; the
+    logical right shifts are emulated by masking the sign extension away)."""
+    def shr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    def c(u):   # unsigned 64-bit constant as the int64 with the same bits
+        return u - (1 << 64) if u >= (1 << 63) else u
+    z = x + c((0x9E3779B97F4A7C15 * (stream + 1)) & 0xFFFFFFFFFFFFFFFF)
+    z = (z ^ shr(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ shr(z, 27)) * c(0x94D049BB133111EB)
+    return z ^ shr(z, 31)
+
+
 class ShardedGraph:
     """Local row block of the normalised adjacency (and of its transpose) with global column ids.
 
@@ -78,13 +91,19 @@ class ShardedGraph:
         lo, hi = int(full.rowptr[ctx.r0]), int(full.rowptr[ctx.r1])
         src, dst = edge_index[0], edge_index[1]
         # both contract checks ride on ONE collective so that every rank raises (or none does)
-        chk = torch.stack([(src * 1000003 + dst).sum(), (dst * 1000003 + src).sum(),      # wrap mod 2^64
-                           torch.tensor(full.nnz - (hi - lo), dtype=torch.int64, device=self.device)])
+        # symmetry: the multiset {(s, t)} must equal {(t, s)}.  Sum of a NON-LINEAR per-edge hash (two
+        # independent splitmix64 streams): a linear checksum such as sum(s*c + t) is blind to every
+        # directed graph whose in- and out-degrees agree node by node (a directed ring passes it).
+        n_g = ctx.n_global
+        fwd, bwd = src * n_g + dst, dst * n_g + src
+        chk = torch.stack([_mix64(fwd, 0).sum(), _mix64(bwd, 0).sum(),                     # wrap mod 2^64
+                           torch.tensor(full.nnz - (hi - lo), dtype=torch.int64, device=self.device),
+                           _mix64(fwd, 1).sum(), _mix64(bwd, 1).sum()])
         ctx.all_reduce_exact(chk)
         if int(chk[2]) != 0:
             raise ValueError(f"local_edges mode: {int(chk[2])} edge(s) were handed to a rank that does not own "
                              f"their target (rank {ctx.rank}: {full.nnz - (hi - lo)} outside [{ctx.r0}, {ctx.r1}))")
-        if int(chk[0]) != int(chk[1]):
+        if int(chk[0]) != int(chk[1]) or int(chk[3]) != int(chk[4]):
             raise ValueError("local_edges mode needs a symmetric global graph (every edge present in both "
                              "directions): the backward applies the same row block as A^T")
         deg = full.deg.clone()

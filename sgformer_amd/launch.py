@@ -34,6 +34,10 @@ def install(variant: str = "large", dtype: str | None = None):
     if variant not in VARIANTS:
         raise SystemExit(f"sgformer_amd.launch: unknown variant {variant!r} (choose from {sorted(set(VARIANTS))})")
     mod = importlib.import_module(VARIANTS[variant])
+    if dtype in ("bf16", "bfloat16") and variant == "medium":
+        # ours_medium / difformer never read DEFAULT_COMPUTE_DTYPE: refuse rather than silently run fp32
+        raise SystemExit("sgformer_amd.launch: --sgf-dtype bf16 is implemented for the large and 100M variants "
+                         "only (BASELINE.json config 3); the medium trainers run in fp32")
     if dtype in ("bf16", "bfloat16"):
         import torch
         importlib.import_module("sgformer_amd.ours").DEFAULT_COMPUTE_DTYPE = torch.bfloat16

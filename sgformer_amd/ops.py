@@ -1006,8 +1006,11 @@ class _Linear(torch.autograd.Function):
             dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
             off = 0
             for i, (x, k) in enumerate(zip(xs, widths)):
-                if k % 4 == 0:
+                if k % 4 == 0 and off % 4 == 0:   # sgf_gram stores float4s: the slice must stay 16-B aligned
                     _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
+                elif k % 4 == 0:
+                    blk, cs = K.gram(gp, _rows(x), want_colsum=(i == 0 and need_b))
+                    dw[:, off:off + k] = blk
                 else:
                     xp = _rows(torch.nn.functional.pad(x, (0, 4 - k % 4)))
                     blk, cs = K.gram(gp, xp, want_colsum=(i == 0 and need_b))

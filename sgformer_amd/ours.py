@@ -304,6 +304,10 @@ class TransConv(nn.Module):
         self.use_act = use_act
         self.alpha = alpha
 
+    # get_attentions applies the post-layer activation in the large variant only (large/ours.py:234-235);
+    # 100M/ours.py:273-290 and medium/ours.py:162-176 never do, whatever use_act says
+    _attn_post_act = True
+
     def reset_parameters(self):
         for conv in self.convs:
             conv.reset_parameters()
@@ -352,7 +356,7 @@ class TransConv(nn.Module):
             attentions.append(attn)
             res = layer_[i] if self.use_residual else None
             x = self._ln(self.bns[i + 1], h, res, a if res is not None else 1.0,
-                         b if res is not None else 0.0, self.use_act)
+                         b if res is not None else 0.0, self.use_act and self._attn_post_act)
             layer_.append(x)
         return torch.stack(attentions, dim=0)
 

@@ -40,6 +40,8 @@ class TransConv(_large.TransConv):
                          use_residual, use_weight, use_act, alpha=alpha,
                          layer_cls=TransConvLayer)
 
+    _attn_post_act = False   # this variant's get_attentions has no activation after a layer
+
     def forward(self, x, edge_index=None):
         return super().forward(x)
 

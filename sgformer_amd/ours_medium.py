@@ -62,10 +62,17 @@ class GCNConv(nn.Module):
         if edge_weight is not None:
             raise NotImplementedError("sgformer_amd GCNConv: edge weights are not on the sgformer recipes' path")
         ops._require_cuda(x, edge_index)
-        if self.out_channels % 4 != 0:
-            raise RuntimeError(f"GCNConv: out_channels {self.out_channels} must be a multiple of 4")
-        xw = ops.linear(x, self.weight.t(), None)
+        w_t = self.weight.t()
+        pad = -self.out_channels % 4
+        if pad:
+            # the kernels move 4 features per lane: compute on the width rounded up to a multiple of 4
+            # (zero weight rows) and slice — `--method gcn` uses this class with out_channels = the
+            # class count (7 on Cora, medium/parse.py:19-23)
+            w_t = F.pad(w_t, (0, 0, 0, pad))
+        xw = ops.linear(x, w_t, None)
         y = ops.spmm(_gcn_graph(edge_index, x.shape[0]), xw)
+        if pad:
+            y = y[:, :self.out_channels]
         return y + self.bias.to(y.dtype)
 
 
@@ -121,6 +128,8 @@ class TransConv(_large.TransConv):
         super().__init__(in_channels, hidden_channels, num_layers, num_heads, dropout, use_bn,
                          use_residual, use_weight, use_act, alpha=alpha, layer_cls=TransConvLayer)
         self.residual = use_residual
+
+    _attn_post_act = False   # this variant's get_attentions has no activation after a layer
 
     def forward(self, data):
         return super().forward(data.graph['node_feat'])

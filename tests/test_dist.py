@@ -191,6 +191,15 @@ def _worker_local_edges(rank, world, port, ret):
             errs["asymmetric_raises"] = False
         except ValueError:
             errs["asymmetric_raises"] = True
+        # a directed RING over all nodes (+ self-loops): every node has equal in- and out-degree, so any
+        # LINEAR checksum of (src, dst) passes it; the per-edge hash must not
+        ring_t = torch.arange(ctx.r0, ctx.r1)
+        ring = torch.stack([torch.cat([(ring_t + 1) % n, ring_t]), torch.cat([ring_t, ring_t])])
+        try:
+            ShardedGraph(ring, ctx)
+            errs["directed_ring_raises"] = False
+        except ValueError:
+            errs["directed_ring_raises"] = True
         ret[rank] = errs
     finally:
         dist.destroy_process_group()
@@ -206,7 +215,7 @@ def test_local_edge_shards_match_full_graph(world):
     for rank in range(world):
         e = ret[rank]
         for flag in ("targets_local", "symmetric", "coalesced", "self_loops", "csr_bit_exact",
-                     "foreign_target_raises", "asymmetric_raises"):
+                     "foreign_target_raises", "asymmetric_raises", "directed_ring_raises"):
             assert e[flag], (flag, e)
         assert e["logits"] < 5e-5, e
         assert e["loss"] < 1e-5, e

@@ -479,11 +479,22 @@ def test_bn_act_res(cuda, d, relu, use_res, training):
         assert _rel(gs[1].grad, xs[1].grad) <= 1e-6
 
 
-def test_axpby(cuda):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_axpby(cuda, dtype):
+    """large/ours.py:269-270 `graph_weight * x2 + (1 - graph_weight) * x1`: forward and both gradients
+    against the same arithmetic in fp64 on the HOST (never against torch on the GPU)."""
     from sgformer_amd import ops
-    a, b = torch.randn(1000, 256, device=cuda), torch.randn(1000, 256, device=cuda)
-    y = ops.axpby(a, b, 0.8, 0.2)
-    assert torch.allclose(y, 0.8 * a + 0.2 * b, atol=1e-6)
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(1000, 256, generator=g).to(dtype), torch.randn(1000, 256, generator=g).to(dtype)
+    w = torch.randn(1000, 256, generator=g)
+    ag, bg = a.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    y = ops.axpby(ag, bg, 0.8, 0.2)
+    ref = 0.8 * a.double() + 0.2 * b.double()
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((y.double().cpu() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    (y.float() * w.to(cuda)).sum().backward()
+    assert _rel(ag.grad.float(), 0.8 * w.double()) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    assert _rel(bg.grad.float(), 0.2 * w.double()) <= (1e-6 if dtype == torch.float32 else 4e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

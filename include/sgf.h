@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 100 /* 0.1.0 */
+#define SGF_VERSION 200 /* 0.2.0 */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -101,6 +101,25 @@ int sgf_subgraph_emit(const int64_t* edge_index, int64_t nnz, int64_t n, const i
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N2 — the trainer's graph prologue.   Replaces large/main.py:75-79 (and
+ * 100M/nb-sample.py:79-80), three torch_geometric 1.7.2 utilities the trainers run on the HOST:
+ *     to_undirected      : concatenate both directions, coalesce = sort by row*N+col, drop duplicates
+ *     remove_self_loops  : keep entries with row != col, order preserved
+ *     add_self_loops     : append (i, i) for i in [0, n)
+ * Any subset of the three, applied in that order, selected by the flags.  Two calls around one host
+ * read of the output size (as sgf_subgraph_*): _plan leaves the sorted keys / scan in `workspace`
+ * and writes *total (device int64); _emit writes out int64 [2, total] (row 0 = edge_index[0]).
+ * Without to_undirected the entries keep the caller's order.  n < 2^31, 2 m < 2^32 - 1.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_graph_prologue_workspace_bytes(int64_t m, int64_t n);
+int sgf_graph_prologue_plan(const int64_t* edge_index, int64_t m, int64_t n, int32_t to_undirected,
+                            int32_t remove_self_loops, int32_t add_self_loops, int64_t* total,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int sgf_graph_prologue_emit(int64_t m, int64_t n, int32_t to_undirected, int32_t add_self_loops,
+                            int64_t total, int64_t* out, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * T2 — sum-reduce CSR SpMM.   Replaces torch_sparse.matmul(adj, x) at large/ours.py:34
  * (third-party torch_sparse 0.6.10 spmm, reduce="sum"):  Y[i,:] = sum_e val[e] * X[colind[e],:]
  * for e in [rowptr[i], rowptr[i+1]), accumulated in fp32 in stored order.
@@ -124,6 +143,60 @@ int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* va
                    int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
                    int64_t long_len, int64_t long_segments, void* workspace, size_t workspace_bytes,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T2 with on-chip reuse: a locality-restoring node order + an LDS-staged row-block SpMM.
+ * Same arithmetic as sgf_spmm (large/ours.py:34, torch_sparse.matmul, sum-reduce) — what changes is
+ * how often a neighbour row crosses the L2 / HBM boundary.
+ *
+ * sgf_reorder — a numbering that puts communities next to each other, from the graph alone: two
+ *   levels of synchronous label propagation (nodes, then communities over the inter-community edges;
+ *   a node adopts the label most of its in-neighbours carry, ties to the smallest), then nodes sorted
+ *   by (level-2 label, level-1 community, id).  perm[p] = old id at new position p, inv[v] = new
+ *   position of old node v, community[v] (optional, NULL to skip) = level-1 community index of v.
+ *   Deterministic.  The caller relabels edge_index with inv and calls sgf_csr_build again; the module
+ *   permutes x once on entry and the logits once on exit (everything in between is
+ *   permutation-equivariant).  nnz < 2^32.
+ *
+ * sgf_spmm_plan — for a CSR (rowptr, colind, val) and blocks of `rows_per_block` consecutive rows: the
+ *   sources referenced by >= 2 stored entries of a block, at most `lds_rows` of them (most-referenced
+ *   first), are listed in sh_cols[sh_ptr[b] .. sh_ptr[b+1]) — the rows block b stages in LDS, slot =
+ *   position in that list.  ecode / eval are colind / val with, inside every row, the entries served
+ *   from LDS moved to the front (stable) and their code set to 0x80000000 | slot; nlds[row] = their
+ *   number.  Rows longer than `long_len` keep plain source ids.  stats (int64[4], device): entries
+ *   served from LDS, rows staged (sum over blocks), distinct (block, source) pairs, nnz.
+ *   sh_cols must hold ceil(n / rows_per_block) * lds_rows entries.  nnz < 2^32 - 1.
+ *
+ * sgf_spmm_blocked — Y = A X with that plan: one workgroup per block (rows_per_block / 8 waves), the
+ *   staged rows fetched once per block into LDS (144 KiB: lds_rows <= sgf_spmm_lds_rows_len(dtype)
+ *   = 288 bf16 / 144 fp32), every other entry gathered as in sgf_spmm.  rows_per_block: multiple of 8,
+ *   <= 128; d <= 256.  long_len / long_segments / workspace as for sgf_spmm_split (0 segments = none).
+ *   Per row the LDS entries are accumulated first, then the gathered ones, each in ascending source
+ *   order: equal to sgf_spmm up to fp32 summation order, deterministic.
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_reorder_workspace_bytes(int64_t nnz, int64_t n);
+int sgf_reorder(const int64_t* edge_index, int64_t nnz, int64_t n, int32_t iters1, int32_t iters2,
+                int32_t* perm, int32_t* inv, int32_t* community, void* workspace, size_t workspace_bytes,
+                void* stream);
+size_t sgf_spmm_plan_workspace_bytes(int64_t nnz, int64_t n, int32_t rows_per_block);
+int sgf_spmm_plan(const int64_t* rowptr, const int32_t* colind, const float* val, int64_t n, int64_t nnz,
+                  int32_t rows_per_block, int32_t lds_rows, int64_t long_len, int32_t* ecode, float* eval,
+                  int32_t* nlds, int32_t* sh_ptr, int32_t* sh_cols, int64_t* stats, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int32_t sgf_spmm_lds_rows_len(int32_t dtype);
+int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eval, const int32_t* nlds,
+                     const int32_t* sh_ptr, const int32_t* sh_cols, const void* x, int64_t ldx, void* y,
+                     int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, int32_t rows_per_block,
+                     int32_t lds_rows, int64_t long_len, int64_t long_segments, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* dst[i, :] = src[idx[i], :] with an optional fp32 <-> bf16 storage change.  Replaces the row
+ * gathers at the module boundary: x[idx_i] of a mini-batch (large/main-batch.py:138) and the
+ * x[perm] / logits[inv] pair around a re-ordered graph.  idx: int32 or int64 (idx_is_int64) device
+ * array of n_out row numbers; numbers outside [0, n_src) give zero rows.  Any d. */
+int sgf_gather_rows(const void* src, int64_t lds, int32_t src_dtype, int64_t n_src, const void* idx,
+                    int32_t idx_is_int64, int64_t n_out, int32_t d, void* dst, int64_t ldd,
+                    int32_t dst_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T3 — linear global attention core.   Replaces large/ours.py:130-149,157

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Profiling target: a few launches of each SpMM kernel on one graph, nothing else on the GPU clock.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/x -- python scripts/spmm_pmc_target.py --graph community
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/y -- python scripts/spmm_pmc_target.py ...
+
+(counters in their own passes, never combined with tracing — MI355X_MICROARCH.md §rocprofv3).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgformer_amd import ops, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", default="community", choices=["community", "uniform"])
+    ap.add_argument("--n", type=int, default=2449029)
+    ap.add_argument("--deg", type=float, default=50.5)
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--shapes", default="128x288,64x144")
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    gen = synth.synthetic_graph_community if a.graph == "community" else synth.synthetic_graph
+    ei = gen(a.n, a.deg, seed=123, device=dev)
+    n = a.n
+    x = torch.randn(n, a.d, device=dev).to(dtype)
+    g = ops.CSRGraph(ei, n, validate=False)
+    for _ in range(a.reps):
+        ops.K.spmm(g.rowptr, g.colind, g.val, x, n, long_segments=g.long_segments)
+    if a.graph == "community":
+        perm, inv, _ = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
+        g2 = ops.CSRGraph(inv.long()[ei], n, validate=False)
+        del ei
+        xp = ops.gather_rows(x, perm)
+        torch.cuda.synchronize()
+        for _ in range(a.reps):
+            ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments)
+        for shape in a.shapes.split(","):
+            r, c = (int(t) for t in shape.split("x"))
+            plan = ops.BlockedPlan(g2.rowptr, g2.colind, g2.val, n, dtype, rows_per_block=r, lds_rows=c)
+            for _ in range(a.reps):
+                ops.K.spmm_blocked(g2.rowptr, plan, xp, n, long_segments=g2.long_segments)
+            del plan
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,3 +60,55 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
     if edge_attr is not None:
         edge_attr = edge_attr.to(device)[eid]
     return out, edge_attr
+
+
+# ------------------------------------------------------------------------------------------------
+# Row N2 of SURVEY.md §8f: the trainer's graph prologue (large/main.py:75-79, 100M/nb-sample.py:79-80)
+# ------------------------------------------------------------------------------------------------
+def _device_for(edge_index):
+    if ops.K.name == "hip":
+        if not torch.cuda.is_available():
+            ops.K.check(edge_index)   # raises the standard no-CPU-path error
+        return edge_index.device if edge_index.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return edge_index.device
+
+
+def _nodes(edge_index, num_nodes):
+    if num_nodes is not None:
+        return int(num_nodes)
+    return int(edge_index.max()) + 1 if edge_index.numel() else 0
+
+
+def graph_prologue(edge_index, num_nodes=None, undirected=True, remove_loops=True, add_loops=True):
+    """to_undirected -> remove_self_loops -> add_self_loops (each optional) in ONE device pass
+    (sgf_graph_prologue_*: one radix sort of the symmetrised keys + a flag scan).  Returns the new
+    edge_index ON THE GPU."""
+    dev = _device_for(edge_index)
+    n = _nodes(edge_index, num_nodes)
+    ei = edge_index.to(dev).contiguous()
+    if ei.dtype != torch.int64:
+        ei = ei.long()
+    return ops.K.graph_prologue(ei, n, bool(undirected), bool(remove_loops), bool(add_loops))
+
+
+def to_undirected(edge_index, num_nodes=None):
+    """torch_geometric.utils.to_undirected (PyG 1.7.2): both directions, coalesced (sorted by row*N+col)."""
+    return graph_prologue(edge_index, num_nodes, True, False, False)
+
+
+def remove_self_loops(edge_index, edge_attr=None):
+    """torch_geometric.utils.remove_self_loops: entries with row != col, order kept."""
+    if edge_attr is not None:          # attributes ride along: plain mask (not on the sgformer recipes' path)
+        mask = edge_index[0] != edge_index[1]
+        return edge_index[:, mask], edge_attr[mask]
+    return graph_prologue(edge_index, 0, False, True, False), None
+
+
+def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):
+    """torch_geometric.utils.add_self_loops: (i, i) for every node appended at the end."""
+    n = _nodes(edge_index, num_nodes)
+    if edge_weight is not None:
+        loops = torch.arange(n, dtype=edge_index.dtype, device=edge_index.device)
+        return (torch.cat([edge_index, torch.stack([loops, loops])], dim=1),
+                torch.cat([edge_weight, edge_weight.new_full((n,), fill_value)]))
+    return graph_prologue(edge_index, n, False, False, True), None

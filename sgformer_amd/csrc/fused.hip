@@ -468,6 +468,37 @@ __global__ __launch_bounds__(kThreads) void k_axpby(const T* __restrict__ x1, in
   }
 }
 
+// out[i, :] = cast(src[idx[i], :])  — row gather with an optional storage-dtype change on the way
+// (x[perm] at the module boundary when the graph is re-ordered; x[idx_i] of a mini-batch,
+// large/main-batch.py:138).  TI int32 / int64 indices; any d (vector path when d % 4 == 0).
+template <typename TS, typename TD, typename TI>
+__global__ __launch_bounds__(kThreads) void k_gather_rows(const TS* __restrict__ src, int64_t lds,
+                                                          const TI* __restrict__ idx, int64_t n_out, int d,
+                                                          int64_t n_src, TD* __restrict__ dst, int64_t ldd,
+                                                          int vec) {
+  if (vec) {
+    const int f4 = d / 4;
+    const int64_t total = n_out * f4;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * kThreads) {
+      const int64_t row = i / f4;
+      const int col = static_cast<int>(i % f4) * 4;
+      const int64_t r = static_cast<int64_t>(idx[row]);
+      const float4 v = (r >= 0 && r < n_src) ? load4<TS>(src + r * lds + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      store4<TD>(dst + row * ldd + col, v);
+    }
+  } else {
+    const int64_t total = n_out * d;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * kThreads) {
+      const int64_t row = i / d;
+      const int col = static_cast<int>(i % d);
+      const int64_t r = static_cast<int64_t>(idx[row]);
+      store1<TD>(dst + row * ldd + col, (r >= 0 && r < n_src) ? load1<TS>(src + r * lds + col) : 0.f);
+    }
+  }
+}
+
 // y = sum_i x_i for up to 8 equally shaped operands: the fused form of the pairwise gradient
 // accumulation autograd performs for a tensor with many consumers (GraphConv's x0 feeds every
 // layer's [.|x0] Linear and residual, large/ours.py:86-93: 7 gradients -> one 8-stream pass
@@ -935,6 +966,34 @@ extern "C" int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, i
     hipLaunchKernelGGL((k_axpby<uint16_t>), grid, dim3(kThreads), 0, st,
                        static_cast<const uint16_t*>(x1), ld1, a, static_cast<const uint16_t*>(x2),
                        ld2, b, n, d, static_cast<uint16_t*>(y), ldy);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_gather_rows(const void* src, int64_t lds, int32_t src_dtype, int64_t n_src, const void* idx,
+                               int32_t idx_is_int64, int64_t n_out, int32_t d, void* dst, int64_t ldd,
+                               int32_t dst_dtype, void* stream) {
+  SGF_REQUIRE(n_out >= 0 && d >= 0 && n_src >= 0, SGF_E_INVALID, "sgf_gather_rows: negative size");
+  SGF_REQUIRE((src_dtype == SGF_F32 || src_dtype == SGF_BF16) && (dst_dtype == SGF_F32 || dst_dtype == SGF_BF16),
+              SGF_E_INVALID, "sgf_gather_rows: unknown dtype");
+  if (n_out == 0 || d == 0) return SGF_OK;
+  SGF_REQUIRE(src && idx && dst && lds >= d && ldd >= d, SGF_E_INVALID, "sgf_gather_rows: bad pointer / ld");
+  const size_t es = src_dtype == SGF_BF16 ? 2 : 4, ed = dst_dtype == SGF_BF16 ? 2 : 4;
+  const int vec = d % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && reinterpret_cast<uintptr_t>(src) % (4 * es) == 0 &&
+                  reinterpret_cast<uintptr_t>(dst) % (4 * ed) == 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(ew_grid(vec ? n_out * (d / 4) : n_out * d));
+#define SGF_GATHER(TS_, TD_, TI_)                                                                            \
+  hipLaunchKernelGGL((k_gather_rows<TS_, TD_, TI_>), grid, dim3(kThreads), 0, st, static_cast<const TS_*>(src), \
+                     lds, static_cast<const TI_*>(idx), n_out, d, n_src, static_cast<TD_*>(dst), ldd, vec)
+#define SGF_GATHER_I(TS_, TD_) \
+  do { if (idx_is_int64) SGF_GATHER(TS_, TD_, int64_t); else SGF_GATHER(TS_, TD_, int32_t); } while (0)
+  if (src_dtype == SGF_F32 && dst_dtype == SGF_F32) SGF_GATHER_I(float, float);
+  else if (src_dtype == SGF_F32) SGF_GATHER_I(float, uint16_t);
+  else if (dst_dtype == SGF_F32) SGF_GATHER_I(uint16_t, float);
+  else SGF_GATHER_I(uint16_t, uint16_t);
+#undef SGF_GATHER_I
+#undef SGF_GATHER
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -37,13 +37,13 @@ constexpr int kWavesPerBlock = 4;
 // the work on one XCD — a power-law graph ran 1.5x slower that way.  Bijective for any nblocks.
 constexpr int64_t kChunkBlocks = 1024;
 
-__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks) {
-  const int64_t stripe = kNumXCD * kChunkBlocks;
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks, int64_t chunk = kChunkBlocks) {
+  const int64_t stripe = kNumXCD * chunk;
   const int64_t full = nblocks / stripe * stripe;
   if (b >= full) return b;   // ragged tail: identity
   const int64_t xcd = b % kNumXCD;
   const int64_t j = b / kNumXCD;              // arrival order inside this XCD
-  return ((j / kChunkBlocks) * kNumXCD + xcd) * kChunkBlocks + j % kChunkBlocks;
+  return ((j / chunk) * kNumXCD + xcd) * chunk + j % chunk;
 }
 
 __device__ __forceinline__ void fma4(float4& acc, float v, const float4& x) {
@@ -243,6 +243,260 @@ __global__ __launch_bounds__(256) void k_spmm_long_fin(LongQueue lq, const float
   }
 }
 
+
+// ---- row-block kernel with LDS staging of shared neighbour rows (plan: spmm_plan.hip) ------------------
+// One workgroup = R consecutive target rows, 8 CONSECUTIVE rows per wave.
+//   Phase 1  the rows of X that at least two of the block's stored entries reference (sh_cols, at most
+//            `lds_rows`, most-referenced first) are fetched ONCE — one coalesced 512 B / 1 KiB wave load each,
+//            all of a wave's loads in flight together — and parked in LDS in storage format.
+//   Phase 2  wave per row, but built so that no step of the per-row dependency chain is a scalar-memory
+//            latency (the wave-per-row kernels wait for an s_load of codes / values before every batch of
+//            gathers; with 8-entry batches that is ~12 dependent memory latencies per 46-entry row, and it —
+//            not bandwidth — bounds them once the gathers hit in L2):
+//              * a row's codes and values are fetched as ONE coalesced vector load (lane j <- entry j of the
+//                current <= 64-entry piece), issued one piece AHEAD and parked in a 512-byte per-wave LDS
+//                scratch; an entry is then read back with a broadcast ds_read_b64 (~100 cycles, LDS port);
+//              * the piece's first gathers (entries the plan left on the L2 / HBM path) are issued BEFORE its
+//                LDS entries are processed, so their latency is covered by LDS work;
+//              * an LDS entry costs two ds_reads (code/value broadcast, then the staged row: lane l owns bytes
+//                [l*8, l*8+8) of the slot, conflict-free) and no scalar or vector memory instruction.
+// Per row the LDS entries are accumulated in stored order into one accumulator and the gathered ones into
+// another, added at the end: a fixed order, so results are deterministic (and equal to k_spmm_wave up to fp32
+// rounding of the different summation order).
+template <typename T> struct Stored;
+template <> struct Stored<float> { using type = float4; };
+template <> struct Stored<uint16_t> { using type = uint2; };
+
+template <typename T>
+__device__ __forceinline__ typename Stored<T>::type load_raw(const T* p) {
+  return *reinterpret_cast<const typename Stored<T>::type*>(p);
+}
+__device__ __forceinline__ float4 widen(const float4& r) { return r; }
+__device__ __forceinline__ float4 widen(const uint2& r) {
+  float4 f;
+  f.x = __uint_as_float(r.x << 16);
+  f.y = __uint_as_float(r.x & 0xffff0000u);
+  f.z = __uint_as_float(r.y << 16);
+  f.w = __uint_as_float(r.y & 0xffff0000u);
+  return f;
+}
+
+constexpr int kBlkRowsPerWave = 8;
+constexpr int kPiece = 64;                       // entries per piece = lanes per wave
+constexpr int kScratchPerWave = 2 * kPiece * 8;  // bytes: two pieces of {code, value}
+
+template <typename T, int DG, int LB, int MINW>
+__global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ ecode, const float* __restrict__ eval,
+    const int32_t* __restrict__ nlds, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_cols,
+    const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t n_rows, int32_t d,
+    int32_t rows_per_block, int32_t lds_rows, int32_t chunk_blocks, LongQueue lq) {
+  using V = typename Stored<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  V* tile = reinterpret_cast<V*>(smem_raw);           // [slot][64 lanes]
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(blockDim.x >> 6);
+  uint2* scratch = reinterpret_cast<uint2*>(smem_raw + static_cast<size_t>(lds_rows) * 64 * sizeof(V)) +
+                   wid * (2 * kPiece);                 // [2][64] {code, value bits}, private to this wave
+  const int64_t blk = xcd_remap(blockIdx.x, gridDim.x, chunk_blocks);
+  const int fc = lane * 4;
+  const bool active = fc < d;
+  const T* xl = x + (active ? fc : 0);
+
+  // ---- phase 1: stage the shared rows.  Wave w takes slots w, w + nw, ...; kStage loads are issued back to
+  // back before the first LDS write, so a full block costs one or two memory latencies, not one per row.
+  const int s0 = sh_ptr[blk];
+  const int ns = sh_ptr[blk + 1] - s0;
+  constexpr int kStage = 9;
+  for (int u0 = wid; u0 < ns; u0 += nw * kStage) {
+    V r[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int u = u0 + k * nw;
+      const int uu = u < ns ? u : u0;                 // clamp: the tail re-reads a row it already has (no branch)
+      r[k] = load_raw<T>(xl + static_cast<int64_t>(sh_cols[s0 + uu]) * ldx);
+    }
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int u = u0 + k * nw;
+      if (u < ns) tile[u * 64 + lane] = r[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2
+  const int64_t r_first = blk * rows_per_block + static_cast<int64_t>(wid) * kBlkRowsPerWave;
+  if (r_first >= n_rows) return;
+  const int nr = n_rows - r_first < kBlkRowsPerWave ? static_cast<int>(n_rows - r_first) : kBlkRowsPerWave;
+  const int64_t nnz = rowptr[n_rows];
+  // lane i holds rowptr[r_first + i] (i <= nr) and nlds[r_first + i] (i < nr)
+  const int64_t rp_v = rowptr[r_first + (lane < nr ? lane : nr)];
+  const int32_t nl_v = nlds[r_first + (lane < nr ? lane : nr - 1)];
+  auto rp = [&](int i) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(rp_v & 0xffffffff), i);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(rp_v >> 32), i);
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+  };
+
+  // piece iterator: (row i, piece start p, row end e1); rows without entries are written (zeros) and long
+  // rows handed to the queue as the iterator passes them — it visits every row of the wave exactly once
+  int it_i = -1;
+  int64_t it_p = 0, it_e1 = 0;
+  auto next_piece = [&]() {     // returns false at the end
+    it_p += kPiece;
+    while (it_p >= it_e1) {
+      ++it_i;
+      if (it_i >= nr) return false;
+      const int64_t e0 = rp(it_i), e1 = rp(it_i + 1);
+      if (e1 - e0 > lq.long_len) {                      // the plan left plain source ids for these rows
+        push_long_row(lq, r_first + it_i, e1 - e0, lane, 64);
+        continue;
+      }
+      if (e1 == e0) {
+        if (active) store4<T>(y + (r_first + it_i) * ldy + fc, make_float4(0.f, 0.f, 0.f, 0.f));
+        continue;
+      }
+      it_p = e0;
+      it_e1 = e1;
+    }
+    return true;
+  };
+  auto fetch = [&](int64_t p) -> uint2 {                // lane j <- entry p + j (clamped inside the arrays)
+    int64_t i = p + lane;
+    if (i >= nnz) i = nnz - 1;
+    return make_uint2(static_cast<uint32_t>(ecode[i]), __float_as_uint(eval[i]));
+  };
+
+  it_p = -kPiece;   // so that the first next_piece() starts at row 0
+  it_e1 = -kPiece;
+  if (!next_piece()) return;
+  uint2 pre = fetch(it_p);
+  int buf = 0;
+  float4 acc_l = make_float4(0.f, 0.f, 0.f, 0.f), acc_d = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (;;) {
+    const int ci = it_i;
+    const int64_t cp = it_p, ce1 = it_e1;
+    uint2* sc = scratch + buf * kPiece;
+    sc[lane] = pre;                                     // this piece's codes / values -> LDS scratch
+    const bool more = next_piece();
+    if (more) pre = fetch(it_p);                        // the NEXT piece's loads fly while this one is processed
+
+    const int64_t e0 = rp(ci);
+    const int64_t el = e0 + __builtin_amdgcn_readlane(nl_v, ci);
+    const int len = ce1 - cp < kPiece ? static_cast<int>(ce1 - cp) : kPiece;
+    const int l0 = 0;                                   // piece-local [l0, l1) = LDS entries, [d0, len) = gathered
+    const int l1 = el > cp ? (el - cp < len ? static_cast<int>(el - cp) : len) : 0;
+    const int d0 = l1;
+    if (cp == e0) {
+      acc_l = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc_d = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // first group of gathers: issue now, consume after the LDS entries
+    uint2 cv[DG];
+    V xv[DG];
+    const int dg0 = len - d0 < DG ? len - d0 : DG;
+    if (dg0 > 0) {
+#pragma unroll
+      for (int u = 0; u < DG; ++u) cv[u] = sc[d0 + (u < dg0 ? u : dg0 - 1)];
+#pragma unroll
+      for (int u = 0; u < DG; ++u) xv[u] = load_raw<T>(xl + static_cast<int64_t>(static_cast<int32_t>(cv[u].x)) * ldx);
+    }
+    // LDS entries
+    int j = l0;
+    for (; j + LB <= l1; j += LB) {
+      uint2 c[LB];
+      V t[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) c[u] = sc[j + u];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) t[u] = tile[(c[u].x & 0x7fffffffu) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) fma4(acc_l, __uint_as_float(c[u].y), widen(t[u]));
+    }
+    if (j < l1) {
+      uint2 c[LB];
+      V t[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) c[u] = sc[j + u < l1 ? j + u : l1 - 1];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) t[u] = tile[(c[u].x & 0x7fffffffu) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < LB; ++u)
+        if (j + u < l1) fma4(acc_l, __uint_as_float(c[u].y), widen(t[u]));
+    }
+    // gathered entries
+    if (dg0 > 0) {
+#pragma unroll
+      for (int u = 0; u < DG; ++u)
+        if (u < dg0) fma4(acc_d, __uint_as_float(cv[u].y), widen(xv[u]));
+      for (int g = d0 + DG; g < len; g += DG) {
+        const int dg = len - g < DG ? len - g : DG;
+#pragma unroll
+        for (int u = 0; u < DG; ++u) cv[u] = sc[g + (u < dg ? u : dg - 1)];
+#pragma unroll
+        for (int u = 0; u < DG; ++u) xv[u] = load_raw<T>(xl + static_cast<int64_t>(static_cast<int32_t>(cv[u].x)) * ldx);
+#pragma unroll
+        for (int u = 0; u < DG; ++u)
+          if (u < dg) fma4(acc_d, __uint_as_float(cv[u].y), widen(xv[u]));
+      }
+    }
+    if (cp + kPiece >= ce1 && active)                   // last piece of the row
+      store4<T>(y + (r_first + ci) * ldy + fc,
+                make_float4(acc_l.x + acc_d.x, acc_l.y + acc_d.y, acc_l.z + acc_d.z, acc_l.w + acc_d.w));
+    if (!more) break;
+    buf ^= 1;
+  }
+}
+
+template <typename T>
+int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eval, const int32_t* nlds,
+                   const int32_t* sh_ptr, const int32_t* sh_cols, const T* x, int64_t ldx, T* y, int64_t ldy,
+                   int64_t n_rows, int32_t d, int32_t rows_per_block, int32_t lds_rows, hipStream_t st,
+                   const LongQueue& lq, float* partial) {
+  constexpr int UNROLL = 8;
+  using V = typename Stored<T>::type;
+  const int threads = rows_per_block / kBlkRowsPerWave * 64;
+  const size_t lds_bytes = static_cast<size_t>(lds_rows) * 64 * sizeof(V) +
+                           static_cast<size_t>(threads / 64) * kScratchPerWave;
+  const int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
+  // one XCD walks ~4096 consecutive rows at a time (its L2 then holds one neighbourhood, as in xcd_remap)
+  int chunk = 4096 / rows_per_block;
+  if (chunk < 1) chunk = 1;
+  // Two register budgets: "deep" keeps 4 KiB of gathers + 8 LDS entries in flight per wave (<= 128 VGPRs, 16 waves
+  // per CU); "lean" halves both and fits 64 VGPRs, for block shapes of which the LDS admits 32 waves per CU.
+  const size_t per_cu = 160 * 1024;
+  const bool lean = (per_cu / lds_bytes) * static_cast<size_t>(threads / 64) > 16;
+  constexpr int DGd = sizeof(T) == 4 ? 4 : 8, DGl = sizeof(T) == 4 ? 2 : 4;
+  auto deep_fn = &k_spmm_blk<T, DGd, DGd, 4>;
+  auto lean_fn = &k_spmm_blk<T, DGl, DGl, 8>;
+  static thread_local size_t attr_set[4] = {0, 0, 0, 0};   // per (dtype, variant): largest dynamic LDS enabled so far
+  const int which = (sizeof(T) == 4 ? 0 : 2) + (lean ? 1 : 0);
+  if (lds_bytes > attr_set[which]) {
+    SGF_CHECK_HIP(hipFuncSetAttribute(lean ? reinterpret_cast<const void*>(lean_fn) : reinterpret_cast<const void*>(deep_fn),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    attr_set[which] = lds_bytes;
+  }
+  if (lean)
+    hipLaunchKernelGGL(lean_fn, dim3(static_cast<unsigned>(nb)), dim3(threads), lds_bytes, st, rowptr, ecode, eval,
+                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq);
+  else
+    hipLaunchKernelGGL(deep_fn, dim3(static_cast<unsigned>(nb)), dim3(threads), lds_bytes, st, rowptr, ecode, eval,
+                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq);
+  SGF_LAUNCH_CHECK();
+  if (lq.cap > 0) {
+    const dim3 block(kWavesPerBlock * 64);
+    const int nbl = lq.cap < 2048 ? lq.cap : 2048;
+    hipLaunchKernelGGL((k_spmm_long_seg<T, UNROLL>), dim3(nbl), block, 0, st, rowptr, ecode, eval, x, ldx, d, lq,
+                       partial);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_spmm_long_fin<T>), dim3(nbl), dim3(256), 0, st, lq, partial, d, y, ldy);
+    SGF_LAUNCH_CHECK();
+  }
+  return SGF_OK;
+}
+
 template <typename T>
 int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const T* x, int64_t ldx,
            T* y, int64_t ldy, int64_t n_rows, int32_t d, hipStream_t st, const LongQueue& lq,
@@ -354,4 +608,55 @@ extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, cons
   SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
   return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, lq, partial, st,
                      "sgf_spmm_split");
+}
+
+// ---- LDS-staged row-block SpMM (plan from sgf_spmm_plan) ------------------------------------------------
+extern "C" int32_t sgf_spmm_lds_rows_len(int32_t dtype) {
+  // 144 KiB of the CU's 160 KiB LDS for staged rows (64 lanes x 8 B = 512 B per bf16 slot, 1 KiB per fp32 slot)
+  return dtype == SGF_BF16 ? 288 : 144;   // + 1 KiB of code / value scratch per wave = exactly 160 KiB at 16 waves
+}
+
+extern "C" int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eval,
+                                const int32_t* nlds, const int32_t* sh_ptr, const int32_t* sh_cols,
+                                const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d,
+                                int32_t dtype, int32_t rows_per_block, int32_t lds_rows, int64_t long_len,
+                                int64_t long_segments, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_spmm_blocked";
+  SGF_REQUIRE(n_rows >= 0 && d >= 0, SGF_E_INVALID, "%s: negative size", fn);
+  if (n_rows == 0 || d == 0) return SGF_OK;
+  SGF_REQUIRE(rowptr && ecode && eval && nlds && sh_ptr && sh_cols && x && y, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "%s: unknown dtype %d", fn, dtype);
+  SGF_REQUIRE(d <= 256, SGF_E_UNSUPPORTED, "%s: d = %d > 256 (one wave per row)", fn, d);
+  SGF_REQUIRE(rows_per_block >= kBlkRowsPerWave && rows_per_block <= 128 && rows_per_block % kBlkRowsPerWave == 0,
+              SGF_E_INVALID, "%s: rows_per_block must be a multiple of %d in [%d, 128]", fn, kBlkRowsPerWave,
+              kBlkRowsPerWave);
+  SGF_REQUIRE(lds_rows >= 1 && lds_rows <= sgf_spmm_lds_rows_len(dtype), SGF_E_INVALID,
+              "%s: lds_rows %d outside [1, %d]", fn, lds_rows, sgf_spmm_lds_rows_len(dtype));
+  SGF_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, SGF_E_INVALID,
+              "%s: d, ldx, ldy must be multiples of 4 with ld >= d", fn);
+  const size_t esz = dtype == SGF_BF16 ? 2 : 4;
+  SGF_REQUIRE(reinterpret_cast<uintptr_t>(x) % (4 * esz) == 0 && reinterpret_cast<uintptr_t>(y) % (4 * esz) == 0,
+              SGF_E_INVALID, "%s: x / y must be aligned to 4 elements", fn);
+  SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31),
+              SGF_E_INVALID, "%s: bad long_len / long_segments", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LongQueue lq{nullptr, nullptr, 0, long_len};
+  float* partial = nullptr;
+  if (long_segments > 0) {
+    SGF_REQUIRE(workspace && workspace_bytes >= sgf_spmm_split_workspace_bytes(long_segments, d), SGF_E_WORKSPACE,
+                "%s: workspace too small", fn);
+    char* ws = static_cast<char*>(workspace);
+    lq.count = reinterpret_cast<int32_t*>(ws);
+    lq.entries = reinterpret_cast<LongEntry*>(ws + 256);
+    lq.cap = static_cast<int32_t>(long_segments);
+    partial = reinterpret_cast<float*>(ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
+    SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
+  } else {
+    lq.long_len = INT64_MAX;   // no queue: every row is walked by its wave (the plan then has LDS codes everywhere)
+  }
+  if (dtype == SGF_F32)
+    return launch_blocked<float>(rowptr, ecode, eval, nlds, sh_ptr, sh_cols, static_cast<const float*>(x), ldx,
+                                 static_cast<float*>(y), ldy, n_rows, d, rows_per_block, lds_rows, st, lq, partial);
+  return launch_blocked<uint16_t>(rowptr, ecode, eval, nlds, sh_ptr, sh_cols, static_cast<const uint16_t*>(x), ldx,
+                                  static_cast<uint16_t*>(y), ldy, n_rows, d, rows_per_block, lds_rows, st, lq, partial);
 }

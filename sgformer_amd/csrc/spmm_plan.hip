@@ -1,0 +1,347 @@
+// spmm_plan.hip — the row-block plan of the LDS-staged SpMM (k_spmm_blk in spmm.hip).
+//
+// T2, large/ours.py:34: Y[i,:] = sum_e val[e] X[colind[e],:].  The wave-per-row kernel fetches every
+// neighbour row from L2 / HBM once per stored entry.  When consecutive rows share neighbours (any graph
+// with community structure, after reorder.hip has put communities next to each other), a block of R
+// target rows can fetch each SHARED neighbour row once into LDS and serve all its uses from there.
+// Which rows are shared is a property of the graph, so it is computed once per CSR, here:
+//
+//   for every block b of R consecutive target rows
+//     unique (b, source) pairs and their multiplicity        radix sort of (block, source) keys + reduce-by-key
+//     the `cap` most-referenced sources with multiplicity >= 2  sort of (block, -count, source) keys
+//        -> sh_cols[sh_ptr[b] .. sh_ptr[b+1])  : the rows block b stages in LDS, slot = position
+//   every stored entry gets a code: 0x80000000 | slot  (served from LDS)   or   the source id (gathered)
+//   inside a row the LDS entries are moved in front of the gathered ones (stable), nlds[row] = their count,
+//   values permuted alongside.
+// Rows longer than `long_len` keep plain source ids (they go to the long-row path of spmm.hip).
+// Summation order inside a row therefore differs from the plain kernel (LDS entries first): results
+// agree to fp32 rounding, not bit for bit; the order is fixed, so the kernel stays deterministic.
+#include "common.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace sgf {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr unsigned kCountBits = 10;                 // multiplicities are clipped to 1023 for the ranking
+constexpr uint32_t kCountMax = (1u << kCountBits) - 1;
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+inline unsigned bits_for(int64_t n) {   // smallest B with 2^B - 1 >= n
+  unsigned b = 1;
+  while (((static_cast<int64_t>(1) << b) - 1) < n && b < 40) ++b;
+  return b;
+}
+
+// row of entry e: largest r with rowptr[r] <= e
+__device__ __forceinline__ int64_t row_of(const int64_t* __restrict__ rowptr, int64_t n, int64_t e) {
+  int64_t lo = 0, hi = n;   // invariant: rowptr[lo] <= e < rowptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// key1 = (block << B) | source  (all-ones sentinel for entries of long rows), value = entry index
+__global__ void k_keys1(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t n,
+                        int64_t nnz, int32_t R, int64_t long_len, unsigned B, unsigned Bb,
+                        uint64_t* __restrict__ keys, uint32_t* __restrict__ eidx, int32_t* __restrict__ rowid) {
+  int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const uint64_t sentinel = (static_cast<uint64_t>(1) << (B + Bb)) - 1;
+  for (; e < nnz; e += stride) {
+    const int64_t r = row_of(rowptr, n, e);
+    rowid[e] = static_cast<int32_t>(r);
+    const bool is_long = rowptr[r + 1] - rowptr[r] > long_len;
+    keys[e] = is_long ? sentinel
+                      : ((static_cast<uint64_t>(r / R) << B) | static_cast<uint32_t>(colind[e]));
+    eidx[e] = static_cast<uint32_t>(e);
+  }
+}
+
+// key2 = (block << (B + C)) | ((CMAX - min(count, CMAX)) << B) | source ; value = unique index j
+__global__ void k_keys2(const uint64_t* __restrict__ ukeys, const uint32_t* __restrict__ ucnt,
+                        const uint32_t* __restrict__ n_unique, int64_t m, unsigned B, unsigned Bb,
+                        uint64_t* __restrict__ keys, uint32_t* __restrict__ jidx) {
+  const int64_t u = *n_unique;
+  int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const uint64_t smask = (static_cast<uint64_t>(1) << B) - 1;
+  const uint64_t sentinel1 = (static_cast<uint64_t>(1) << (B + Bb)) - 1;
+  for (; j < m; j += stride) {
+    uint64_t k = ~static_cast<uint64_t>(0);
+    if (j < u && ukeys[j] != sentinel1) {
+      const uint64_t blk = ukeys[j] >> B, s = ukeys[j] & smask;
+      const uint32_t c = ucnt[j] < kCountMax ? ucnt[j] : kCountMax;
+      k = (blk << (B + kCountBits)) | (static_cast<uint64_t>(kCountMax - c) << B) | s;
+    }
+    keys[j] = k;
+    jidx[j] = static_cast<uint32_t>(j);
+  }
+}
+
+// first sorted position of every block
+__global__ void k_block_heads(const uint64_t* __restrict__ keys2, int64_t m, unsigned B,
+                              uint32_t* __restrict__ head) {
+  int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; p < m; p += stride) {
+    const uint64_t k = keys2[p];
+    if (k == ~static_cast<uint64_t>(0)) continue;
+    const uint64_t blk = k >> (B + kCountBits);
+    if (p == 0 || (keys2[p - 1] >> (B + kCountBits)) != blk) head[blk] = static_cast<uint32_t>(p);
+  }
+}
+
+// rank inside the block; the first `cap` uniques with count >= 2 get LDS slots
+__global__ void k_slots(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ jidx, int64_t m,
+                        unsigned B, const uint32_t* __restrict__ head, int32_t cap,
+                        int32_t* __restrict__ slot_of_unique, int32_t* __restrict__ nsh) {
+  int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; p < m; p += stride) {
+    const uint64_t k = keys2[p];
+    if (k == ~static_cast<uint64_t>(0)) continue;
+    const uint64_t blk = k >> (B + kCountBits);
+    const uint32_t cfield = static_cast<uint32_t>((k >> B) & kCountMax);   // CMAX - count
+    const int64_t rank = p - head[blk];
+    const bool ok = rank < cap && cfield <= kCountMax - 2;
+    slot_of_unique[jidx[p]] = ok ? static_cast<int32_t>(rank) : -1;
+    if (ok) atomicAdd(&nsh[blk], 1);
+  }
+}
+
+__global__ void k_sh_cols(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ jidx, int64_t m,
+                          unsigned B, const int32_t* __restrict__ slot_of_unique,
+                          const int32_t* __restrict__ sh_ptr, int32_t* __restrict__ sh_cols) {
+  int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const uint64_t smask = (static_cast<uint64_t>(1) << B) - 1;
+  for (; p < m; p += stride) {
+    const uint64_t k = keys2[p];
+    if (k == ~static_cast<uint64_t>(0)) continue;
+    const int32_t slot = slot_of_unique[jidx[p]];
+    if (slot >= 0) sh_cols[sh_ptr[k >> (B + kCountBits)] + slot] = static_cast<int32_t>(k & smask);
+  }
+}
+
+// run index of sorted position i: largest j < u with ustart[j] <= i
+__global__ void k_codes(const uint64_t* __restrict__ keys1, const uint32_t* __restrict__ eidx, int64_t nnz,
+                        const uint32_t* __restrict__ ustart, const uint32_t* __restrict__ n_unique,
+                        const int32_t* __restrict__ slot_of_unique, const int32_t* __restrict__ colind,
+                        unsigned B, unsigned Bb, int32_t* __restrict__ code_tmp, uint32_t* __restrict__ flag) {
+  const int64_t u = *n_unique;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const uint64_t sentinel = (static_cast<uint64_t>(1) << (B + Bb)) - 1;
+  for (; i < nnz; i += stride) {
+    const uint32_t e = eidx[i];
+    int32_t code = colind[e];
+    uint32_t f = 0;
+    if (keys1[i] != sentinel) {
+      int64_t lo = 0, hi = u;   // ustart[lo] <= i < ustart[hi] (ustart[u] = nnz conceptually)
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (static_cast<int64_t>(ustart[mid]) <= i) lo = mid; else hi = mid;
+      }
+      const int32_t slot = slot_of_unique[lo];
+      if (slot >= 0) {
+        code = static_cast<int32_t>(0x80000000u | static_cast<uint32_t>(slot));
+        f = 1;
+      }
+    }
+    code_tmp[e] = code;
+    flag[e] = f;
+  }
+}
+
+// stable partition inside each row: LDS entries first
+__global__ void k_partition(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ rowid,
+                            const int32_t* __restrict__ code_tmp, const uint32_t* __restrict__ flag,
+                            const uint32_t* __restrict__ fscan, const float* __restrict__ val, int64_t nnz,
+                            int32_t* __restrict__ ecode, float* __restrict__ eval, int32_t* __restrict__ nlds) {
+  int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; e < nnz; e += stride) {
+    const int32_t r = rowid[e];
+    const int64_t rs = rowptr[r], re = rowptr[r + 1];
+    const uint32_t before = fscan[e] - fscan[rs];
+    const uint32_t nl = fscan[re] - fscan[rs];          // fscan has nnz + 1 entries
+    const int64_t pos = flag[e] ? rs + before : rs + nl + (e - rs - before);
+    ecode[pos] = code_tmp[e];
+    eval[pos] = val[e];
+    if (e == rs) nlds[r] = static_cast<int32_t>(nl);
+  }
+}
+
+__global__ void k_stats(const uint32_t* __restrict__ fscan, int64_t nnz, const int32_t* __restrict__ sh_ptr,
+                        int64_t nb, const uint32_t* __restrict__ n_unique, int64_t* __restrict__ stats) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[0] = fscan[nnz];      // entries served from LDS
+    stats[1] = sh_ptr[nb];      // rows staged into LDS, summed over blocks
+    stats[2] = *n_unique;       // distinct (block, source) pairs (incl. one run for long-row entries, if any)
+    stats[3] = nnz;
+  }
+}
+
+struct Layout {
+  size_t keys_a, keys_b, idx_a, idx_b, ukeys, ucnt, ustart, slot, rowid, j2s, flag, fscan, head, nsh,
+      count, tmp, total, tmp_bytes;
+};
+
+int make_layout(int64_t nnz, int64_t nb, Layout* L) {
+  const size_t m = static_cast<size_t>(nnz);
+  size_t sort_b = 0, rbk_b = 0, scan_b = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_b, static_cast<uint64_t*>(nullptr),
+                                           static_cast<uint64_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                           static_cast<uint32_t*>(nullptr), m, 0u, 64u);
+  if (e != hipSuccess) { set_error("rocprim sort size query: %s", hipGetErrorString(e)); return SGF_E_HIP; }
+  e = rocprim::reduce_by_key(nullptr, rbk_b, static_cast<uint64_t*>(nullptr),
+                             rocprim::constant_iterator<uint32_t>(1u), m, static_cast<uint64_t*>(nullptr),
+                             static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                             rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>());
+  if (e != hipSuccess) { set_error("rocprim reduce_by_key size query: %s", hipGetErrorString(e)); return SGF_E_HIP; }
+  e = rocprim::exclusive_scan(nullptr, scan_b, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                              0u, m + 1, rocprim::plus<uint32_t>());
+  if (e != hipSuccess) { set_error("rocprim scan size query: %s", hipGetErrorString(e)); return SGF_E_HIP; }
+  size_t t = sort_b > rbk_b ? sort_b : rbk_b;
+  if (scan_b > t) t = scan_b;
+  L->tmp_bytes = align_up(t, 256) + 256;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  L->keys_a = take(m * 8);
+  L->keys_b = take(m * 8);
+  L->idx_a = take(m * 4);
+  L->idx_b = take(m * 4);
+  L->ukeys = take(m * 8);
+  L->ucnt = take((m + 1) * 4);
+  L->ustart = take((m + 1) * 4);
+  L->slot = take(m * 4);
+  L->rowid = take(m * 4);
+  L->j2s = take(m * 4);
+  L->flag = take((m + 1) * 4);
+  L->fscan = take((m + 1) * 4);
+  L->head = take(static_cast<size_t>(nb + 1) * 4);
+  L->nsh = take(static_cast<size_t>(nb + 1) * 4);
+  L->count = take(256);
+  L->tmp = take(L->tmp_bytes);
+  L->total = off;
+  return SGF_OK;
+}
+
+}  // namespace
+}  // namespace sgf
+
+using namespace sgf;
+
+extern "C" size_t sgf_spmm_plan_workspace_bytes(int64_t nnz, int64_t n, int32_t rows_per_block) {
+  if (nnz < 0 || n < 0 || rows_per_block <= 0) return 0;
+  Layout L;
+  if (make_layout(nnz, (n + rows_per_block - 1) / rows_per_block, &L) != SGF_OK) return 0;
+  return L.total;
+}
+
+extern "C" int sgf_spmm_plan(const int64_t* rowptr, const int32_t* colind, const float* val, int64_t n,
+                             int64_t nnz, int32_t rows_per_block, int32_t lds_rows, int64_t long_len,
+                             int32_t* ecode, float* eval, int32_t* nlds, int32_t* sh_ptr, int32_t* sh_cols,
+                             int64_t* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(n >= 0 && nnz >= 0 && rows_per_block > 0 && lds_rows > 0 && long_len >= 1, SGF_E_INVALID,
+              "sgf_spmm_plan: bad size argument");
+  SGF_REQUIRE(nnz < (static_cast<int64_t>(1) << 32) - 1, SGF_E_UNSUPPORTED, "sgf_spmm_plan: nnz >= 2^32");
+  SGF_REQUIRE(n < (static_cast<int64_t>(1) << 31) - 1, SGF_E_UNSUPPORTED, "sgf_spmm_plan: n too large");
+  const int64_t nb = (n + rows_per_block - 1) / rows_per_block;
+  SGF_REQUIRE(nb * static_cast<int64_t>(lds_rows) < (static_cast<int64_t>(1) << 31), SGF_E_UNSUPPORTED,
+              "sgf_spmm_plan: blocks x lds_rows overflows int32");
+  SGF_REQUIRE(rowptr && nlds && sh_ptr && stats && (nnz == 0 || (colind && val && ecode && eval && sh_cols)),
+              SGF_E_INVALID, "sgf_spmm_plan: null pointer");
+  const unsigned B = bits_for(n), Bb = bits_for(nb);
+  SGF_REQUIRE(B + Bb + kCountBits <= 63, SGF_E_UNSUPPORTED, "sgf_spmm_plan: key does not fit 64 bits");
+  Layout L;
+  int rc = make_layout(nnz, nb, &L);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(workspace && workspace_bytes >= L.total, SGF_E_WORKSPACE, "sgf_spmm_plan: workspace %zu < %zu",
+              workspace_bytes, L.total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  uint64_t* ka = reinterpret_cast<uint64_t*>(ws + L.keys_a);
+  uint64_t* kb = reinterpret_cast<uint64_t*>(ws + L.keys_b);
+  uint32_t* ia = reinterpret_cast<uint32_t*>(ws + L.idx_a);
+  uint32_t* ib = reinterpret_cast<uint32_t*>(ws + L.idx_b);
+  uint64_t* uk = reinterpret_cast<uint64_t*>(ws + L.ukeys);
+  uint32_t* uc = reinterpret_cast<uint32_t*>(ws + L.ucnt);
+  uint32_t* us = reinterpret_cast<uint32_t*>(ws + L.ustart);
+  int32_t* slot = reinterpret_cast<int32_t*>(ws + L.slot);
+  int32_t* rowid = reinterpret_cast<int32_t*>(ws + L.rowid);
+  uint32_t* j2s = reinterpret_cast<uint32_t*>(ws + L.j2s);
+  uint32_t* flag = reinterpret_cast<uint32_t*>(ws + L.flag);
+  uint32_t* fscan = reinterpret_cast<uint32_t*>(ws + L.fscan);
+  uint32_t* head = reinterpret_cast<uint32_t*>(ws + L.head);
+  int32_t* nsh = reinterpret_cast<int32_t*>(ws + L.nsh);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + L.count);
+  const size_t m = static_cast<size_t>(nnz);
+
+  if (n > 0) SGF_CHECK_HIP(hipMemsetAsync(nlds, 0, static_cast<size_t>(n) * 4, st));
+  if (nnz > 0) SGF_CHECK_HIP(hipMemsetAsync(slot, 0xff, m * 4, st));   // -1: no LDS slot
+  SGF_CHECK_HIP(hipMemsetAsync(nsh, 0, static_cast<size_t>(nb + 1) * 4, st));
+  SGF_CHECK_HIP(hipMemsetAsync(head, 0, static_cast<size_t>(nb + 1) * 4, st));
+  SGF_CHECK_HIP(hipMemsetAsync(cnt, 0, 256, st));
+  if (nnz == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(sh_ptr, 0, static_cast<size_t>(nb + 1) * 4, st));
+    SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), st));
+    return SGF_OK;
+  }
+  // 1. unique (block, source) pairs and their multiplicities
+  hipLaunchKernelGGL(k_keys1, dim3(grid_for(nnz)), dim3(kThreads), 0, st, rowptr, colind, n, nnz, rows_per_block,
+                     long_len, B, Bb, ka, ia, rowid);
+  SGF_LAUNCH_CHECK();
+  size_t bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::radix_sort_pairs(ws + L.tmp, bytes, ka, kb, ia, ib, m, 0u, B + Bb, st));
+  SGF_CHECK_HIP(hipMemsetAsync(uc, 0, (m + 1) * 4, st));
+  bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::reduce_by_key(ws + L.tmp, bytes, kb, rocprim::constant_iterator<uint32_t>(1u), m, uk, uc,
+                                       cnt, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), st));
+  bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::exclusive_scan(ws + L.tmp, bytes, uc, us, 0u, m + 1, rocprim::plus<uint32_t>(), st));
+  // 2. per block: the `lds_rows` most-referenced sources with multiplicity >= 2 get LDS slots.
+  //    Buffer reuse: keys_a / idx_a are free again (the sorted key1 / entry indices live in keys_b / idx_b);
+  //    the sorted key2 overwrites ukeys (last read by k_keys2), its values go to j2s.
+  hipLaunchKernelGGL(k_keys2, dim3(grid_for(nnz)), dim3(kThreads), 0, st, uk, uc, cnt, nnz, B, Bb, ka, ia);
+  SGF_LAUNCH_CHECK();
+  uint64_t* k2s = uk;
+  bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::radix_sort_pairs(ws + L.tmp, bytes, ka, k2s, ia, j2s, m, 0u, B + Bb + kCountBits, st));
+  hipLaunchKernelGGL(k_block_heads, dim3(grid_for(nnz)), dim3(kThreads), 0, st, k2s, nnz, B, head);
+  SGF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_slots, dim3(grid_for(nnz)), dim3(kThreads), 0, st, k2s, j2s, nnz, B, head, lds_rows, slot,
+                     nsh);
+  SGF_LAUNCH_CHECK();
+  bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::exclusive_scan(ws + L.tmp, bytes, nsh, sh_ptr, 0, static_cast<size_t>(nb + 1),
+                                        rocprim::plus<int32_t>(), st));
+  hipLaunchKernelGGL(k_sh_cols, dim3(grid_for(nnz)), dim3(kThreads), 0, st, k2s, j2s, nnz, B, slot, sh_ptr, sh_cols);
+  SGF_LAUNCH_CHECK();
+  // 3. entry codes (in CSR position; written into keys_a, free again), then the stable LDS-first partition
+  //    inside every row
+  int32_t* code_tmp = reinterpret_cast<int32_t*>(ka);
+  SGF_CHECK_HIP(hipMemsetAsync(flag, 0, (m + 1) * 4, st));
+  hipLaunchKernelGGL(k_codes, dim3(grid_for(nnz)), dim3(kThreads), 0, st, kb, ib, nnz, us, cnt, slot, colind, B, Bb,
+                     code_tmp, flag);
+  SGF_LAUNCH_CHECK();
+  bytes = L.tmp_bytes;
+  SGF_CHECK_HIP(rocprim::exclusive_scan(ws + L.tmp, bytes, flag, fscan, 0u, m + 1, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_partition, dim3(grid_for(nnz)), dim3(kThreads), 0, st, rowptr, rowid, code_tmp, flag, fscan,
+                     val, nnz, ecode, eval, nlds);
+  SGF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, st, fscan, nnz, sh_ptr, nb, cnt, stats);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}

@@ -70,6 +70,18 @@ def patch_subgraph():
     return tgu
 
 
+def patch_prologue():
+    """Serve the trainer prologue — to_undirected / remove_self_loops / add_self_loops at
+    large/main.py:75-79 and 100M/nb-sample.py:79-80 — from the GPU (sgformer_amd.batching,
+    sgf_graph_prologue_*).  The edge_index the trainer then moves `.to(device)` is
+    already there."""
+    import importlib as _il
+    tgu = _il.import_module("torch_geometric.utils")
+    b = _il.import_module("sgformer_amd.batching")
+    tgu.to_undirected, tgu.remove_self_loops, tgu.add_self_loops = b.to_undirected, b.remove_self_loops, b.add_self_loops
+    return tgu
+
+
 def _pop_option(argv, name):
     for i, a in enumerate(argv):
         if a == name and i + 1 < len(argv):
@@ -87,6 +99,7 @@ def main(argv=None):
     variant = _pop_option(argv, "--sgf-variant")
     dtype = _pop_option(argv, "--sgf-dtype")
     host_subgraph = _pop_option(argv, "--sgf-host-subgraph")   # any value: keep PyG's host subgraph
+    host_prologue = _pop_option(argv, "--sgf-host-prologue")   # any value: keep PyG's host to_undirected & co.
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -108,6 +121,8 @@ def main(argv=None):
         patch_medium_gcn()
     if host_subgraph is None and os.path.basename(trainer) == "main-batch.py":
         patch_subgraph()
+    if host_prologue is None and variant != "medium":
+        patch_prologue()
     runpy.run_path(trainer, run_name="__main__")
 
 

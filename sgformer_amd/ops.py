@@ -142,6 +142,22 @@ class HipKernels:
                       _ptr(eid), _ptr(ws), ws.numel(), _stream(dev))
         return out, eid
 
+    # ---- N2: trainer prologue (to_undirected / remove_self_loops / add_self_loops) ----
+    @staticmethod
+    def graph_prologue(ei: torch.Tensor, n: int, undirected: bool, remove_loops: bool, add_loops: bool):
+        dev, m = ei.device, int(ei.shape[1])
+        lib = _lib.load()
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(lib.sgf_graph_prologue_workspace_bytes(m, n), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_graph_prologue_plan", _ptr(ei), m, n, int(undirected), int(remove_loops), int(add_loops),
+                      _ptr(total), _ptr(ws), ws.numel(), _stream(dev))
+            k = int(total.item())              # the one host sync: the output size
+            out = torch.empty((2, k), dtype=torch.int64, device=dev)
+            _lib.call("sgf_graph_prologue_emit", m, n, int(undirected), int(add_loops), k, _ptr(out), _ptr(ws),
+                      ws.numel(), _stream(dev))
+        return out
+
     # ---- T2 ----
     @staticmethod
     def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None,
@@ -167,6 +183,75 @@ class HipKernels:
                 _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
                           _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
         return y
+
+    # ---- T2 with on-chip reuse: node order, row-block plan, LDS-staged SpMM ----
+    @staticmethod
+    def reorder(ei: torch.Tensor, n: int, iters1: int, iters2: int):
+        """perm (new position -> old id), inv (old id -> new position), community: int32 [n] each."""
+        dev, nnz = ei.device, int(ei.shape[1])
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        inv = torch.empty(n, dtype=torch.int32, device=dev)
+        comm = torch.empty(n, dtype=torch.int32, device=dev)
+        nbytes = _lib.load().sgf_reorder_workspace_bytes(nnz, n)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_reorder", _ptr(ei), nnz, n, int(iters1), int(iters2), _ptr(perm), _ptr(inv),
+                      _ptr(comm), _ptr(ws), ws.numel(), _stream(dev))
+        return perm, inv, comm
+
+    @staticmethod
+    def spmm_plan(rowptr, colind, val, n: int, rows_per_block: int, lds_rows: int, long_len: int):
+        dev, nnz = rowptr.device, int(colind.numel())
+        nb = (n + rows_per_block - 1) // rows_per_block
+        ecode = torch.empty(nnz, dtype=torch.int32, device=dev)
+        ev = torch.empty(nnz, dtype=_F32, device=dev)
+        nlds = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        sh_ptr = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+        sh_cols = torch.empty(max(nb * lds_rows, 1), dtype=torch.int32, device=dev)
+        stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        nbytes = _lib.load().sgf_spmm_plan_workspace_bytes(nnz, n, rows_per_block)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_spmm_plan", _ptr(rowptr), _ptr(colind), _ptr(val), n, nnz, int(rows_per_block),
+                      int(lds_rows), int(long_len), _ptr(ecode), _ptr(ev), _ptr(nlds), _ptr(sh_ptr),
+                      _ptr(sh_cols), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
+        st = [int(v) for v in stats.tolist()]                      # one host sync, once per plan
+        return ecode, ev, nlds, sh_ptr, sh_cols[: max(st[1], 1)].clone(), st
+
+    @staticmethod
+    def spmm_blocked(rowptr, plan, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None,
+                     long_segments: int = 0) -> torch.Tensor:
+        x = _rows(x)
+        d = x.shape[1]
+        y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device) if out is None else out
+        if n_rows == 0 or d == 0:
+            return y
+        with torch.cuda.device(x.device):
+            ws = None
+            if long_segments > 0:
+                ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(long_segments, d))
+            _lib.call("sgf_spmm_blocked", _ptr(rowptr), _ptr(plan.ecode), _ptr(plan.eval), _ptr(plan.nlds),
+                      _ptr(plan.sh_ptr), _ptr(plan.sh_cols), _ptr(x), x.stride(0), _ptr(y), y.stride(0), n_rows, d,
+                      _code(x), plan.rows_per_block, plan.lds_rows, LONG_ROW, long_segments, _ptr(ws),
+                      0 if ws is None else ws.numel(), _stream(x.device))
+        return y
+
+    @staticmethod
+    def lds_rows_max(dtype) -> int:
+        return int(_lib.load().sgf_spmm_lds_rows_len(_lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32))
+
+    @staticmethod
+    def gather_rows(src: torch.Tensor, idx: torch.Tensor, out_dtype=None) -> torch.Tensor:
+        """out[i] = src[idx[i]] (idx int32 / int64 on the GPU), optionally cast fp32 <-> bf16 on the way."""
+        if src.stride(-1) != 1:
+            src = src.contiguous()
+        n_out, d = int(idx.numel()), src.shape[1]
+        out = torch.empty((n_out, d), dtype=out_dtype or src.dtype, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.call("sgf_gather_rows", _ptr(src), src.stride(0), _code(src), src.shape[0], _ptr(idx),
+                      int(idx.dtype == torch.int64), n_out, d, _ptr(out), out.stride(0), _code(out),
+                      _stream(src.device))
+        return out
 
     # ---- T3 ----  q, k: [n, H*d] views (ld = stride(0)); v: [n, Hv*d]
     @staticmethod
@@ -481,6 +566,124 @@ class CSRGraph:
             self.t_long_segments = self.long_segments if sym else long_row_segments(t_rowptr)
         return self._t
 
+    # ---- LDS-staged row-block SpMM: one plan per (orientation, storage dtype) ----
+    blocked = False          # set by GraphView when the plan serves enough entries from LDS
+
+    def plan(self, dtype, transposed: bool = False):
+        """BlockedPlan for SpMMs with `dtype` storage on this CSR (or its transpose), or None."""
+        if not self.blocked:
+            return None
+        if not hasattr(self, "_plans"):
+            self._plans = {}
+        if transposed:
+            self.transposed()
+            if self.symmetric:
+                transposed = False
+        key = (bool(transposed), dtype)
+        if key not in self._plans:
+            rp, ci, va = self.transposed() if transposed else (self.rowptr, self.colind, self.val)
+            self._plans[key] = BlockedPlan(rp, ci, va, self.n, dtype)
+        return self._plans[key]
+
+    def view(self, now: bool = False) -> "GraphView":
+        """How the model should run on this graph: the graph itself, or a re-ordered copy + the row
+        permutation to apply at the module boundary (decided once; see GraphView).  now=True: decide
+        at this call instead of waiting for the second forward."""
+        self.forward_calls = getattr(self, "forward_calls", 0) + 1
+        v = getattr(self, "_view", None)
+        if v is None:
+            v = GraphView.decide(self, now)
+            if v is not None:
+                self._view = v
+        return v if v is not None else GraphView(self, None, None)
+
+
+# SGF_SPMM_BLOCK = "rows_per_block,lds_rows" overrides the block shape (default: 128 rows, all 144 KiB of LDS)
+def _block_shape(dtype):
+    import os
+    cap = K.lds_rows_max(dtype)
+    env = os.environ.get("SGF_SPMM_BLOCK", "")
+    if env:
+        r, c = (int(t) for t in env.split(","))
+        return r, min(c, cap)
+    return 128, cap
+
+
+class BlockedPlan:
+    """Row-block plan of one CSR (sgf_spmm_plan): which neighbour rows each block of rows stages in
+    LDS, and the entry codes / values re-ordered so that the LDS entries lead every row."""
+
+    def __init__(self, rowptr, colind, val, n: int, dtype, rows_per_block=None, lds_rows=None):
+        r, c = _block_shape(dtype)
+        self.rows_per_block = int(rows_per_block or r)
+        self.lds_rows = int(lds_rows or c)
+        (self.ecode, self.eval, self.nlds, self.sh_ptr, self.sh_cols, st) = K.spmm_plan(
+            rowptr, colind, val, n, self.rows_per_block, self.lds_rows, LONG_ROW)
+        self.lds_entries, self.staged_rows, self.unique_pairs, self.nnz = st
+        self.lds_fraction = self.lds_entries / max(self.nnz, 1)
+
+
+# When to re-order (SGF_REORDER): "auto" (default) tries once per cached graph with at least
+# REORDER_MIN_NODES nodes, at its second forward (a graph seen once is a mini-batch: planning would cost
+# more than it saves) or when prepare_graph() asks for it; "1" tries every graph at first use; "0" never.
+# The order is adopted only if the row-block plan on the re-ordered CSR then serves at least
+# REORDER_MIN_LDS_FRACTION of the stored entries from LDS — a uniform random graph is an expander, no order
+# helps it, and it keeps the plain kernel on its original CSR.
+REORDER_MIN_NODES = 100_000
+REORDER_MIN_LDS_FRACTION = 0.25
+REORDER_ITERS = (6, 6)
+_reorder_mode = None
+
+
+def set_reorder_mode(mode: Optional[str]):
+    """'auto' | 'always' | 'never' | None (= read SGF_REORDER).  Returns the previous setting."""
+    global _reorder_mode
+    prev, _reorder_mode = _reorder_mode, mode
+    return prev
+
+
+def _mode() -> str:
+    if _reorder_mode is not None:
+        return _reorder_mode
+    import os
+    return {"0": "never", "1": "always"}.get(os.environ.get("SGF_REORDER", "auto"), "auto")
+
+
+class GraphView:
+    """(graph, perm, inv): `graph` is the CSRGraph the layers multiply with; when perm is not None the
+    model's rows are in the re-ordered numbering: row p of every activation is original node perm[p],
+    and original node v sits at row inv[v]."""
+
+    def __init__(self, graph, perm, inv, stats=None):
+        self.graph, self.perm, self.inv, self.stats = graph, perm, inv, stats or {}
+
+    @staticmethod
+    def decide(g: "CSRGraph", now: bool):
+        mode = _mode()
+        if mode == "never" or K.name != "hip" or g.nnz == 0 or g.nnz >= 2 ** 32 - 1:
+            return GraphView(g, None, None, {"reordered": False, "why": "disabled"})
+        if mode == "auto":
+            if g.n < REORDER_MIN_NODES:
+                return GraphView(g, None, None, {"reordered": False, "why": "small graph"})
+            if not now and g.forward_calls < 2:
+                return None                    # undecided: wait for the second forward on this graph
+        perm, inv, _ = K.reorder(g.edge_index, g.n, *REORDER_ITERS)
+        g2 = CSRGraph(inv.long()[g.edge_index], g.n, validate=False)
+        g2.blocked = True
+        plan = g2.plan(_BF16)                  # the fraction served from LDS depends on the LDS budget: bf16 rows
+        stats = {"lds_fraction": plan.lds_fraction, "staged_rows_per_node": plan.staged_rows / max(g.n, 1),
+                 "rows_per_block": plan.rows_per_block, "lds_rows": plan.lds_rows}
+        if plan.lds_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
+            return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
+        return GraphView(g2, perm, inv, {**stats, "reordered": True})
+
+
+def prepare_graph(edge_index: torch.Tensor, num_nodes: int) -> GraphView:
+    """Build everything that is per-graph, not per-step: the CSR, and (policy above) the node order and
+    row-block plan.  The trainers need not call this — the same work happens lazily in the first two
+    forwards — bench.py does, so that it stays outside the timed region like the CSR build."""
+    return graph_cache.get(edge_index, num_nodes).view(now=True)
+
 
 class _GraphCache:
     """edge_index -> CSRGraph, keyed on tensor identity AND version: the
@@ -544,7 +747,7 @@ class _SpMM(torch.autograd.Function):
             # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
             return _sharded_spmm(graph.rowptr, graph.colind, graph.val, x, graph.n_local, shard,
                                  graph.long_segments)
-        return K.spmm(graph.rowptr, graph.colind, graph.val, x, graph.n, long_segments=graph.long_segments)
+        return spmm_on(graph, x, False)
 
     @staticmethod
     def backward(ctx, gy):
@@ -554,8 +757,18 @@ class _SpMM(torch.autograd.Function):
             rp, ci, va = graph.transposed()
             return _sharded_spmm(rp, ci, va, gy.contiguous(), graph.n_local, shard,
                                  graph.t_long_segments), None, None
-        rp, ci, va = graph.transposed()
-        return K.spmm(rp, ci, va, gy.contiguous(), graph.n, long_segments=graph.t_long_segments), None, None
+        return spmm_on(graph, gy.contiguous(), True), None, None
+
+
+def spmm_on(graph, x: torch.Tensor, transposed: bool, out=None) -> torch.Tensor:
+    """A x or A^T x on one GPU: the LDS-staged row-block kernel when the graph carries a plan for this
+    storage dtype (GraphView adopted a re-ordered CSR), else the wave-per-row kernel."""
+    rp, ci, va = graph.transposed() if transposed else (graph.rowptr, graph.colind, graph.val)
+    segs = graph.t_long_segments if transposed else graph.long_segments
+    plan = graph.plan(x.dtype, transposed) if (getattr(graph, "blocked", False) and x.shape[1] <= 256) else None
+    if plan is not None:
+        return K.spmm_blocked(rp, plan, x, graph.n, out=out, long_segments=segs)
+    return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs)
 
 
 def spmm(graph, x: torch.Tensor, shard=None) -> torch.Tensor:
@@ -897,6 +1110,35 @@ def nll_loss_rows(logits, labels, idx, denom=None):
     overrides the divisor (the GLOBAL training-row count of a node-sharded run).  fp32 math on fp32
     or bf16 logits; the gradient is written for all N rows (zeros off the training rows)."""
     return _NllRows.apply(logits, labels, idx, denom)
+
+
+# ------------------------------------------------------------------------------------------------
+# row permutation at the module boundary (re-ordered graphs) and mini-batch row gathers
+# ------------------------------------------------------------------------------------------------
+class _PermuteRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, idx_inv, out_dtype):
+        K.check(x, idx)
+        ctx.save_for_backward(idx_inv)
+        ctx.in_dtype = x.dtype
+        return K.gather_rows(x, idx, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_inv,) = ctx.saved_tensors
+        return K.gather_rows(g, idx_inv, ctx.in_dtype), None, None, None
+
+
+def permute_rows(x: torch.Tensor, idx: torch.Tensor, idx_inv: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """y[i] = x[idx[i]] for a PERMUTATION idx with inverse idx_inv (the gradient is then the gather by
+    idx_inv — no scatter, no atomics); optional storage cast on the way (fp32 features -> bf16)."""
+    return _PermuteRows.apply(x, idx, idx_inv, out_dtype)
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """x[idx] on the GPU without autograd (mini-batch feature gather, large/main-batch.py:138)."""
+    K.check(x, idx)
+    return K.gather_rows(x, idx, out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------

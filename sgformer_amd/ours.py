@@ -128,7 +128,9 @@ class GraphConvLayer(nn.Module):
 
     def forward(self, x, edge_index, x0):
         shard = self._shard
-        if shard is not None:
+        if isinstance(edge_index, ops.CSRGraph):   # SGFormer.forward resolved (and maybe re-ordered) it already
+            graph = edge_index
+        elif shard is not None:
             graph = shard.graph_for(edge_index)
         else:
             graph = ops.graph_cache.get(edge_index, x.shape[0])
@@ -206,7 +208,8 @@ class GraphConv(nn.Module):
         return _drop(x, self.dropout, self.training, res if (res is not None and not fuse_res) else None)
 
     def forward(self, x, edge_index):
-        ops._require_cuda(x, edge_index)
+        """edge_index: the int64 [2, nnz] tensor of the reference, or an ops.CSRGraph built from it."""
+        ops._require_cuda(x, None if isinstance(edge_index, ops.CSRGraph) else edge_index)
         x = _lin(x, self.fcs[0])
         x = self._stage(self.bns[0], x, None, True)
         # x0 = layer_[0] has up to 2 consumers per layer (the [. | x0] Linear and the residual) plus
@@ -420,8 +423,18 @@ class SGFormer(nn.Module):
             return self._forward_on_gpu_from_host(x, edge_index)
         ops._require_cuda(x, edge_index)
         out_dtype = x.dtype
-        if self.compute_dtype is not None and x.dtype != self.compute_dtype:
-            x = x.to(self.compute_dtype)
+        cdt = self.compute_dtype if self.compute_dtype is not None else x.dtype
+        # The graph is resolved once per forward.  If its cached view carries a locality-restoring node
+        # order (ops.GraphView), the rows of x are permuted here — fused with the storage cast — and the
+        # logits un-permuted on the way out; every op in between is permutation-equivariant.
+        view = None
+        if self.use_graph and self.graph_conv._shard is None and ops.K.name == "hip":
+            view = ops.graph_cache.get(edge_index, x.shape[0]).view()
+            edge_index = view.graph
+        if view is not None and view.perm is not None:
+            x = ops.permute_rows(x, view.perm, view.inv, cdt)
+        elif x.dtype != cdt:
+            x = x.to(cdt)
         if self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None:
             # The two branches are independent until the combine: run the attention branch on a side
             # HIP stream so that its latency-bound kernels fill the gaps of the GCN branch (autograd
@@ -446,7 +459,10 @@ class SGFormer(nn.Module):
                 x = torch.cat((x1, x2), dim=1)
         else:
             x = x1
-        return ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
+        out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
+        if view is not None and view.perm is not None:
+            out = ops.permute_rows(out, view.inv, view.perm)       # back to the caller's node order
+        return out
 
     def get_attentions(self, x):
         return self.trans_conv.get_attentions(x)

@@ -89,6 +89,56 @@ def synthetic_graph_local(n: int, avg_deg: float, locality: float = 0.9, window:
     return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
 
 
+def synthetic_graph_community(n: int, avg_deg: float, seed: int = 123, comm_size=(64, 256), comms_per_super: int = 64,
+                              p_comm: float = 0.80, p_super: float = 0.15, shuffle_ids: bool = True,
+                              device="cpu") -> torch.Tensor:
+    """Same sizes and prologue as `synthetic_graph`, but with the two-level community structure of a
+    co-purchase / social graph, and — `shuffle_ids` — with node ids that carry NO trace of it:
+
+      * nodes are split into communities of uniform random size in `comm_size`, and `comms_per_super`
+        consecutive communities form a super-community;
+      * an undirected pair starts at a uniform random node and ends, with probability `p_comm`, at a
+        uniform node of the same community; with `p_super`, of the same super-community; else anywhere;
+      * finally all node ids are renamed by a seeded random permutation.
+
+    This is SURVEY.md §8d input class (b) with the locality HIDDEN: whatever reuse an SpMM gets out of
+    this graph it must first recover from the edge list (sgf_reorder), as it would have to on ogbn ids.
+    The uniform generator stays the zero-structure worst case (an expander: nothing to recover)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mean = (comm_size[0] + comm_size[1]) / 2
+    nc = int(n / mean * 1.3) + 8
+    sizes = torch.randint(comm_size[0], comm_size[1] + 1, (nc,), generator=g)
+    bounds = torch.cumsum(sizes, 0)
+    nc = int((bounds < n).sum()) + 1
+    starts = torch.cat([torch.zeros(1, dtype=torch.long), bounds[: nc - 1]])
+    ends = torch.cat([bounds[: nc - 1], torch.tensor([n])])
+    comm = torch.repeat_interleave(torch.arange(nc), ends - starts)
+    sup_of_comm = torch.arange(nc) // comms_per_super
+    sup_start = starts[torch.arange(0, nc, comms_per_super)]
+    sup_end = torch.cat([sup_start[1:], torch.tensor([n])])
+    m = int(n * avg_deg / 2)
+    src = torch.randint(0, n, (m,), generator=g)
+    u = torch.rand(m, generator=g)
+    r = torch.rand(m, generator=g, dtype=torch.float64)
+    c = comm[src]
+    sc = sup_of_comm[c]
+    d1 = starts[c] + (r * (ends[c] - starts[c])).long()
+    d2 = sup_start[sc] + (r * (sup_end[sc] - sup_start[sc])).long()
+    d3 = (r * n).long().clamp_(max=n - 1)
+    dst = torch.where(u < p_comm, d1, torch.where(u < p_comm + p_super, d2, d3))
+    del u, r, c, sc, d1, d2, d3
+    if shuffle_ids:
+        perm = torch.randperm(n, generator=g)
+        src, dst = perm[src], perm[dst]
+    src, dst = src.to(device), dst.to(device)
+    src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
 def synthetic_graph_skewed(n: int, avg_deg: float, gamma: float = 2.0, seed: int = 123, device="cpu") -> torch.Tensor:
     """Same prologue as `synthetic_graph`, but one endpoint of every pair is drawn from a heavy-tailed
     distribution (id = floor(n * u^gamma)): a few hub nodes collect a large share of the edges — node 0

@@ -157,6 +157,13 @@ def test_full_ogbn_arxiv_shape_vs_fp64_oracle(cuda):
     loss_ref = O.nll_loss(ref, y, idx)
     loss_ref.backward()
     err = float((logits.detach().double().cpu() - ref.detach()).abs().max())
+    # gradients: Frobenius-relative 5e-4, OR no worse than 4x what the fp32 CPU oracle itself loses against
+    # fp64 on this input.  (At N = 169 343 the weight gradients in front of a BatchNorm are ill-conditioned in
+    # fp32 — dZ has an exactly zero column sum that fp32 only approximates, and that residual multiplies the
+    # large common mean of the SpMM output — so ANY fp32 implementation, the reference's included, is at ~1e-3
+    # there; the per-element absolute error stays far below BASELINE's 1e-4.)
+    p32 = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    O.nll_loss(O.sgformer_forward(p32, x, ei, cfg, training=True), y, idx).backward()
     gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
     report = {"logits_max_abs_err": err, "loss_err": abs(float(loss.detach()) - float(loss_ref.detach())),
               "logits_scale": float(ref.detach().abs().max())}
@@ -166,8 +173,11 @@ def test_full_ogbn_arxiv_shape_vs_fp64_oracle(cuda):
         if g is None:
             continue
         num = float((prm.grad.double().cpu() - g).norm())
-        report["grad/" + k] = num / max(float(g.norm()), 1e-300)
-        if num > 5e-4 * float(g.norm()) + 1e-6 * gmax:
+        num32 = float((p32[k].grad.double() - g).norm())
+        amax = float((prm.grad.double().cpu() - g).abs().max())
+        report["grad/" + k] = {"rel": num / max(float(g.norm()), 1e-300), "cpu_fp32_rel": num32 / max(float(g.norm()), 1e-300),
+                               "max_abs": amax}
+        if amax > 1e-4 or num > max(5e-4 * float(g.norm()) + 1e-6 * gmax, 4.0 * num32):
             bad.append(k)
     print("arxiv-full parity:", json.dumps(report))
     assert err <= 1e-4, report

@@ -15,11 +15,17 @@ of a (13.9 M x N)-node uniform random graph (111 M nodes at N = 8, hidden 128, 1
 rank generates only its own rows (synth.synthetic_graph_shard) and no rank ever holds the global edge list.
 
 Rank 0 prints ONE JSON line: the contract fields plus
-  roofline      — the dominant kernel (CSR SpMM, k_spmm_wave): algorithmic bytes per launch (SURVEY.md
-                  §8d: nnz*8 + (rows+1)*8 + X read once + Y written once) / mean launch time measured
-                  with HIP events on the launch stream inside the timed region, against 8 TB/s;
-                  `gather_bytes` is the no-reuse traffic of the same launch (each stored entry
-                  fetching a d-wide row), the honest bound for a uniform random graph.
+  roofline      — the dominant kernel (CSR SpMM): algorithmic bytes per launch (nnz*8 +
+                  (rows+1)*8 + X read once + Y written once) / mean launch time measured with HIP events on
+                  the launch stream inside the timed region, against 8 TB/s; `gather_bytes` is the no-reuse
+                  traffic of the same launch (each stored entry fetching a d-wide row), the bound for a
+                  uniform random graph (profiles/r02_gather_probe.md).  `traffic` = HBM bytes per launch
+                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r02_spmm_pmc.json,
+                  written by scripts/pmc_passes.sh; null when no pass has been recorded).
+  structured    — the same training step and the same SpMM roofline on a graph of the same size WITH
+                  community structure and RANDOMLY PERMUTED node ids (synth.synthetic_graph_community): the
+                  locality has to be recovered by sgf_reorder and is then exploited by the LDS-staged
+                  row-block kernel.  The uniform headline graph is an expander (nothing to recover).
   cpu_baseline  — the CPU restatement of the reference (oracle/, torch CPU kernels, all host cores) on
                   a bounded sample of the same workload, timed on this box before the GPU run.
 """
@@ -46,11 +52,20 @@ from sgformer_amd.ours import SGFormer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 
-# HBM bytes per k_spmm_wave launch from the rocprofv3 PMC passes committed under profiles/
-# (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 per the gfx950 correction of
-# MI355X_MICROARCH.md §HBM, which reproduces the gather bytes of this graph to 0.3 %).  PMC counters
-# cannot be collected from inside this process, so the figure is keyed on the exact workload.
-PMC_SPMM_TRAFFIC = {("ogbn-products", "bf16"): (67.1e9 + 1.25e9, "profiles/r01_spmm_pmc.md")}
+# HBM bytes per SpMM launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+# scripts/spmm_pmc_target.py; FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM).  PMC
+# counters cannot be collected from inside this process, so the figures live in a tracked file written
+# from those passes, keyed on graph kind / dtype / kernel.
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_spmm_pmc.json")
+
+
+def pmc_traffic(graph_kind: str, dtype: str, kernel: str):
+    try:
+        table = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    e = table.get(f"{graph_kind}/{dtype}/{kernel}")
+    return (e["hbm_bytes_per_launch"], "profiles/r02_spmm_pmc.json") if e else (None, None)
 
 
 def parse():
@@ -68,8 +83,10 @@ def parse():
     ap.add_argument("--aten-loss", action="store_true",
                     help="time the step with the trainer's own F.log_softmax + F.nll_loss (5 ATen kernels) "
                          "instead of sgformer_amd.loss.log_softmax_nll")
-    ap.add_argument("--no-locality-probe", action="store_true",
-                    help="skip the SpMM-only measurement on the locality-structured graph")
+    ap.add_argument("--no-structured", action="store_true",
+                    help="skip the second measurement on the community-structured graph with shuffled node ids")
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "community"],
+                    help="graph generator of the HEADLINE measurement (default: uniform random, the r01 workload)")
     return ap.parse_args()
 
 
@@ -125,28 +142,40 @@ class SpmmTimer:
     """HIP-event timing of every SpMM launch on the launch stream (torch's current stream)."""
 
     def __init__(self):
-        self.pairs, self.bytes_alg, self.bytes_gather, self.active, self.d = [], [], [], False, 0
-        self._orig = ops.K.spmm
+        self.pairs, self.bytes_alg, self.bytes_gather, self.active, self.kernels = [], [], [], False, []
+        self._orig = (ops.K.spmm, ops.K.spmm_blocked)
 
-    def install(self):
-        timer, orig = self, self._orig
+    def _wrap(self, orig, blocked):
+        timer = self
 
-        def timed(rowptr, colind, val, x, n_rows, **kw):
+        def timed(rowptr, b, *rest, **kw):
+            # K.spmm(rowptr, colind, val, x, n_rows, ...) / K.spmm_blocked(rowptr, plan, x, n_rows, ...)
             if not timer.active:
-                return orig(rowptr, colind, val, x, n_rows, **kw)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            y = orig(rowptr, colind, val, x, n_rows, **kw)
-            b.record()
-            s = x.element_size()
-            nnz, d = colind.numel(), x.shape[1]
-            timer.d = d
-            timer.pairs.append((a, b))
+                return orig(rowptr, b, *rest, **kw)
+            x, n_rows = (rest[0], rest[1]) if blocked else (rest[1], rest[2])
+            nnz = int(b.nnz) if blocked else b.numel()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(rowptr, b, *rest, **kw)
+            e1.record()
+            s, d = x.element_size(), x.shape[1]
+            timer.kernels.append("k_spmm_blk" if blocked else ("k_spmm_wave" if d > 128 else "k_spmm_sub"))
+            timer.pairs.append((e0, e1))
             timer.bytes_alg.append(nnz * 8 + (n_rows + 1) * 8 + x.shape[0] * d * s + n_rows * d * s)
             timer.bytes_gather.append(nnz * (8 + d * s) + (n_rows + 1) * 8 + n_rows * d * s)
             return y
 
-        ops.K.spmm = timed
+        return timed
+
+    def install(self):
+        ops.K.spmm = self._wrap(self._orig[0], False)
+        ops.K.spmm_blocked = self._wrap(self._orig[1], True)
+
+    def uninstall(self):
+        ops.K.spmm, ops.K.spmm_blocked = self._orig
+
+    def reset(self):
+        self.pairs, self.bytes_alg, self.bytes_gather, self.kernels = [], [], [], []
 
     def summary(self):
         if not self.pairs:
@@ -156,45 +185,16 @@ class SpmmTimer:
         alg = sum(self.bytes_alg) / len(self.bytes_alg)
         gat = sum(self.bytes_gather) / len(self.bytes_gather)
         achieved = alg / (mean_ms * 1e-3) / 1e9
-        kern = "k_spmm_wave" if self.d > 128 else "k_spmm_sub"
-        return {"kernel": f"{kern} (sgf_spmm)", "bound": "hbm", "achieved": round(achieved, 1),
+        kern = max(set(self.kernels), key=self.kernels.count)
+        entry = "sgf_spmm_blocked" if kern == "k_spmm_blk" else "sgf_spmm"
+        return {"kernel": f"{kern} ({entry})", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": len(ms), "mean_launch_ms": round(mean_ms, 4),
                 "algorithmic_bytes": int(alg), "gather_bytes": int(gat),
                 "gather_GBps": round(gat / (mean_ms * 1e-3) / 1e9, 1)}
 
 
-def spmm_locality_probe(n, avg_deg, d, dtype, seed, dev, reps=5, locality=0.9, window=4096):
-    """The SAME sgf_spmm kernel on a graph of the same size whose edges are mostly local in node id
-    (synth.synthetic_graph_local).  On the uniform random graph of the headline workload every
-    stored entry must fetch its 512-byte neighbour row from HBM (X is 1.25 GB: 5x the Infinity
-    Cache, 300x an XCD's L2), so the kernel is bound by GATHER bytes, 19x the algorithmic bytes;
-    this probe shows what the kernel does with the reuse a real graph offers."""
-    ei = synth.synthetic_graph_local(n, avg_deg, locality=locality, window=window, seed=seed, device=dev)
-    graph = ops.CSRGraph(ei, n, validate=False)
-    nnz = int(ei.shape[1])
-    del ei
-    x = torch.randn(n, d, device=dev).to(dtype)
-    for _ in range(2):
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=graph.long_segments)
-    evs = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        ops.K.spmm(graph.rowptr, graph.colind, graph.val, x, n, long_segments=graph.long_segments)
-        b.record()
-        evs.append((a, b))
-    torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
-    s = x.element_size()
-    alg = nnz * 8 + (n + 1) * 8 + 2 * n * d * s
-    return {"graph": f"same N / degree, {locality:.0%} of pairs within ~N(0,{window}) ids, rest uniform",
-            "nnz": nnz, "launch_ms": round(ms, 4), "algorithmic_bytes": int(alg),
-            "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-
-
-def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev):
+def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev, graph: str = "uniform"):
     """Synthetic inputs of one rank (host x / y / train_idx, edge_index on `dev`) and its ShardContext.
     Strong-scaling workloads: every rank generates the SAME global graph and task and keeps its rows.
     `*-weak`: SHAPES gives the node count PER RANK; the rank generates only its own rows of the
@@ -213,13 +213,118 @@ def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev
         if world > 1:
             ctx = ShardContext(n, local_edges=True)
     else:
-        ei = synth.synthetic_graph(n, avg_deg, seed=seed, device=dev)
+        gen = synth.synthetic_graph_community if graph == "community" else synth.synthetic_graph
+        ei = gen(n, avg_deg, seed=seed, device=dev)
         x, y, train_idx = synth.synthetic_task(n, f, c, seed=seed)
         n_train = train_idx.numel()
         if world > 1:
             ctx = ShardContext(n)
             x, y, train_idx = ctx.shard_rows(x), ctx.shard_rows(y), ctx.local_index(train_idx)
     return n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx
+
+
+def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=False):
+    """Build the synthetic inputs + model for one graph kind, run `warmup` untimed and `steps` timed training
+    steps (barrier + synchronize on both sides), return the measurements."""
+    n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx = make_inputs(args.workload, args.nodes, args.seed,
+                                                                           rank, world, dev, graph_kind)
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    x, y, train_idx = x.to(dev, dtype), y.to(dev), train_idx.to(dev)
+
+    torch.manual_seed(args.seed)
+    # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
+                     compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
+    if ctx is not None:
+        shard_model(model, ctx)
+    opt = torch.optim.Adam([{"params": model.params1, "weight_decay": 1e-5},
+                            {"params": model.params2, "weight_decay": 1e-5}], lr=0.01)
+    model.train()
+    # per-graph, not per-step: CSR, node order, row-block plan (the trainers get the same lazily in their
+    # first two epochs) — outside the timed region like every other one-off
+    view_stats, t_prep = None, None
+    if ctx is None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        view_stats = dict(ops.prepare_graph(ei, n).stats)
+        torch.cuda.synchronize()
+        t_prep = time.perf_counter() - t0
+
+    state = {"aten": args.aten_loss}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = model(x, ei)
+        if ctx is not None:
+            loss = sharded_nll_loss(logits, y, train_idx, n_train)
+        elif state["aten"]:   # the three lines of large/main.py:139-141 as the trainer writes them
+            loss = F.nll_loss(F.log_softmax(logits.float(), dim=1)[train_idx], y[train_idx])
+        else:             # the same arithmetic in one pass (sgf_nll_fwd / sgf_nll_bwd, SURVEY row N4)
+            loss = log_softmax_nll(logits, y, train_idx)
+        loss.backward()
+        if ctx is not None:
+            ctx.sync_grads(model.parameters())
+        opt.step()
+        return loss
+
+    timer = SpmmTimer()
+    timer.install()
+    try:
+        for _ in range(warmup):
+            step()
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        fence()
+        timer.active = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        timer.active = False   # (the extra ATen-loss steps below are not part of the roofline sample)
+        loss_val = float(loss.detach())
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+            lt = torch.tensor([loss_val], device=dev, dtype=torch.float64)
+            dist.all_reduce(lt)
+            loss_val = float(lt)
+        ms_aten = None
+        if with_aten and world == 1 and not state["aten"]:
+            # transparency: the same step with the trainer's own ATen loss ops
+            state["aten"] = True
+            step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(min(steps, 5)):
+                step()
+            fence()
+            ms_aten = (time.perf_counter() - t1) / min(steps, 5) * 1e3
+    finally:
+        timer.uninstall()
+    roof = timer.summary()
+    if roof is not None and world == 1 and not args.nodes:
+        kern = roof["kernel"].split(" ")[0]
+        roof["traffic"], src = pmc_traffic(f"{args.workload}:{graph_kind}", args.dtype, kern)
+        if src:
+            roof["traffic_source"] = src
+    exchanged = None
+    if ctx is not None:
+        exchanged = {"all_gather_bytes_per_step": ctx.bytes_all_gathered // max(warmup + steps, 1),
+                     "all_reduce_bytes_per_step": ctx.bytes_all_reduced // max(warmup + steps, 1)}
+    out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten,
+               roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
+               peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+    del model, opt, x, y
+    ops.graph_cache.clear()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -244,108 +349,46 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx = make_inputs(args.workload, args.nodes, args.seed,
-                                                                           rank, world, dev)
-    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    x, y, train_idx = x.to(dev, dtype), y.to(dev), train_idx.to(dev)
-
-    torch.manual_seed(args.seed)
-    # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
-    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
-                     compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
-    if ctx is not None:
-        shard_model(model, ctx)
-    opt = torch.optim.Adam([{"params": model.params1, "weight_decay": 1e-5},
-                            {"params": model.params2, "weight_decay": 1e-5}], lr=0.01)
-    model.train()
-
-    aten_loss = args.aten_loss
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        logits = model(x, ei)
-        if ctx is not None:
-            loss = sharded_nll_loss(logits, y, train_idx, n_train)
-        elif aten_loss:   # the three lines of large/main.py:139-141 as the trainer writes them
-            loss = F.nll_loss(F.log_softmax(logits.float(), dim=1)[train_idx], y[train_idx])
-        else:             # the same arithmetic in one pass (sgf_nll_fwd / sgf_nll_bwd)
-            loss = log_softmax_nll(logits, y, train_idx)
-        loss.backward()
-        if ctx is not None:
-            ctx.sync_grads(model.parameters())
-        opt.step()
-        return loss
-
-    timer = SpmmTimer()
-    timer.install()
-    for _ in range(args.warmup):
-        step()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    timer.active = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer.active = False   # (the extra ATen-loss steps below are not part of the roofline sample)
-    loss_val = float(loss.detach())
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-        lt = torch.tensor([loss_val], device=dev, dtype=torch.float64)
-        dist.all_reduce(lt)
-        loss_val = float(lt)
-
-    ms_aten = None
-    if world == 1 and not aten_loss:
-        # transparency: the same step with the trainer's own ATen loss ops
-        aten_loss = True
-        step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(min(args.steps, 5)):
-            step()
-        fence()
-        ms_aten = (time.perf_counter() - t1) / min(args.steps, 5) * 1e3
-        aten_loss = False
-    roof = timer.summary()
-    if roof is not None and world == 1 and not args.nodes and (args.workload, args.dtype) in PMC_SPMM_TRAFFIC:
-        roof["traffic"], roof["traffic_source"] = PMC_SPMM_TRAFFIC[(args.workload, args.dtype)]
-    if rank == 0 and world == 1 and roof is not None and not args.no_locality_probe and not args.nodes:
-        del model, opt, x, y, loss
-        ops.graph_cache.clear()
-        torch.cuda.empty_cache()
-        roof["locality_probe"] = spmm_locality_probe(n, synth.SHAPES[args.workload][1], d, dtype, args.seed, dev)
+    r = run_workload(args, args.graph, rank, world, dev, args.steps, args.warmup, with_aten=True)
+    structured = None
+    if (rank == 0 and world == 1 and args.graph == "uniform" and not args.no_structured
+            and not args.workload.endswith("-weak")):
+        k = max(3, min(args.steps, 5))
+        q = run_workload(args, "community", rank, world, dev, k, 2)
+        structured = {
+            "graph": "same N / degree; communities of 64-256 nodes in super-communities of 64 (80 % / 15 % / 5 % of "
+                     "the pairs inside the community / the super-community / anywhere), node ids randomly permuted",
+            "nnz": q["nnz"], "value": q["n"] * k / q["elapsed"], "unit": "nodes/s", "steps": k,
+            "ms_per_step": round(q["elapsed"] / k * 1e3, 3), "loss": q["loss"], "graph_view": q["view"],
+            "prepare_graph_s": None if q["prepare_s"] is None else round(q["prepare_s"], 3), "roofline": q["roof"]}
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
+        n, f, c, d, weak = r["n"], r["f"], r["c"], r["d"], r["weak"]
+        ms = r["elapsed"] / args.steps * 1e3
+        gname = "uniform random graph" if args.graph == "uniform" else "community graph with shuffled node ids"
         line = {
             "metric": f"SGFormer fwd+bwd nodes/sec on {args.workload} full-graph",
-            "value": n * args.steps / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
+            "value": n * args.steps / r["elapsed"], "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}-shaped uniform random graph, full-graph "
+            "config": {"workload": f"{args.workload}-shaped {gname}, full-graph "
                                    f"training step (fwd + log_softmax/NLL on the training rows + bwd + Adam), "
                                    f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout 0"
                                    + (f"; {n // world:,} nodes per rank, rows generated per rank" if weak else ""),
                        "loss": "F.log_softmax + F.nll_loss (ATen, as large/main.py:139-141 writes it)" if args.aten_loss
                                else "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
-                       "ms_per_step_with_aten_loss": None if ms_aten is None else round(ms_aten, 3),
-                       "nodes": n, ("nnz_per_rank" if weak else "nnz"): int(ei.shape[1]), "features": f, "hidden": d, "classes": c,
+                       "ms_per_step_with_aten_loss": None if r["ms_aten"] is None else round(r["ms_aten"], 3),
+                       "nodes": n, ("nnz_per_rank" if weak else "nnz"): r["nnz"], "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
+                       "graph_view": r["view"],
+                       "prepare_graph_s": None if r["prepare_s"] is None else round(r["prepare_s"], 3),
+                       "exchanged": r["exchanged"],
                        "debug_override": bool(args.nodes)},
-            "loss": loss_val,
-            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-            "roofline": roof,
+            "loss": r["loss"],
+            "peak_mem_GB": r["peak_mem"],
+            "roofline": r["roof"],
+            "structured": structured,
             "cpu_baseline": cpu,
         }
         if cpu is not None:

@@ -124,12 +124,14 @@ int sgf_graph_prologue_emit(int64_t m, int64_t n, int32_t to_undirected, int32_t
  * (third-party torch_sparse 0.6.10 spmm, reduce="sum"):  Y[i,:] = sum_e val[e] * X[colind[e],:]
  * for e in [rowptr[i], rowptr[i+1]), accumulated in fp32 in stored order.
  * Backward (dX = A^T dY) is the same call on the transposed CSR (or the same CSR if symmetric).
- *   x : [n_cols_of_A, d] dtype, leading dim ldx;  y : [n_rows, d] dtype, leading dim ldy.
+ *   x : [n_cols, d] dtype, leading dim ldx (n_cols = columns of A = rows of x; when n_cols * ldx * elsize
+ *       < 2^32 the row kernel addresses x with 32-bit buffer offsets: 8 instead of 21 instructions per
+ *       stored entry);  y : [n_rows, d] dtype, leading dim ldy.
  * d, ldx, ldy must be multiples of 4 elements; x and y aligned to 4 elements.
  * ------------------------------------------------------------------------------------------ */
 int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
-             int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
-             void* stream);
+             int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d,
+             int32_t dtype, void* stream);
 
 /* sgf_spmm with long rows split across workgroups (power-law graphs: a hub row of 17 k entries walked
  * by ONE wave is a latency-bound tail).  Rows with more than `long_len` stored entries are cut into
@@ -140,7 +142,7 @@ int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val, con
 int32_t sgf_spmm_segment_len(void);
 size_t sgf_spmm_split_workspace_bytes(int64_t long_segments, int32_t d);
 int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
-                   int64_t ldx, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
+                   int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
                    int64_t long_len, int64_t long_segments, void* workspace, size_t workspace_bytes,
                    void* stream);
 

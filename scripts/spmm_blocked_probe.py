@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--shapes", default="128x288,64x144,128x128,64x64,32x72")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--ablate", action="store_true", help="time the row-block kernel with parts switched off")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -82,6 +83,11 @@ def main():
     report("plain kernel, sgf_reorder order", timed(lambda: ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n,
                                                                          long_segments=g2.long_segments)),
            reorder_ms=round(t_re, 1), communities=ncomm, relabel_csr_ms=round(t_csr2, 1))
+    if a.ablate:
+        os.environ["SGF_SPMM_ROW_UNROLL"] = "16"
+        report("plain kernel, sgf_reorder order, 16 gathers in flight", timed(lambda: ops.K.spmm(
+            g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments)))
+        del os.environ["SGF_SPMM_ROW_UNROLL"]
     y_ref = ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments).float()
     cap = ops.K.lds_rows_max(dtype)
     for shape in a.shapes.split(","):
@@ -95,6 +101,13 @@ def main():
             g2.rowptr, plan, xp, n, long_segments=g2.long_segments)), plan_ms=round(t_plan, 1),
             lds_fraction=round(plan.lds_fraction, 4), staged_rows_per_node=round(plan.staged_rows / n, 3),
             rel_diff_vs_plain=err)
+        if a.ablate:
+            for mask, what in ((1, "no staging loads"), (2, "no LDS entries"), (4, "no gathered entries"),
+                               (6, "staging only"), (5, "LDS entries only, nothing staged"), (3, "gathered entries only")):
+                os.environ["SGF_SPMM_BLK_DEBUG"] = str(mask)
+                report(f"  ablation [{what}] {r}x{c}", timed(lambda: ops.K.spmm_blocked(
+                    g2.rowptr, plan, xp, n, long_segments=g2.long_segments)))
+            del os.environ["SGF_SPMM_BLK_DEBUG"]
         del plan
 
 

@@ -31,10 +31,10 @@ SIGNATURES = {
     "sgf_graph_prologue_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_graph_prologue_plan": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "sgf_graph_prologue_emit": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int64, _P, _P, c_size_t, _P]),
-    "sgf_spmm": (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P]),
+    "sgf_spmm": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P]),
     "sgf_spmm_segment_len": (c_int32, []),
     "sgf_spmm_split_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "sgf_spmm_split": (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int64,
+    "sgf_spmm_split": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int64,
                                  c_int64, _P, c_size_t, _P]),
     "sgf_reorder_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_reorder": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),

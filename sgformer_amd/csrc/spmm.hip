@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <climits>
+#include <cstdlib>
 
 namespace sgf {
 namespace {
@@ -129,6 +130,485 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_wave(
     }
     if (active) store4<T>(y + row * ldy + fc, acc);
   }
+}
+
+// ---- wave per row, 32-bit buffer addressing ------------------------------------------------------------
+// rocprofv3 on the community graph (profiles/r02_spmm_pmc.md) showed k_spmm_wave ISSUE-bound once its gathers
+// hit in L2: 21 wave-instructions per stored entry — 11 of them scalar ALU for the 64-bit address c * ldx —
+// at one instruction per SIMD per 4 cycles is the whole launch time.  This variant addresses X through a
+// buffer descriptor: the row offset c * pitch is ONE s_mul_i32 into the instruction's scalar offset, the
+// lane's column offset a loop-invariant VGPR, so an entry costs 1 SALU + 1 buffer_load + 4 unpack + 2 packed
+// FMA (+ 1/4 of the two s_load_dwordx8 that fetch 8 codes and 8 values).  The next batch's codes / values
+// are requested before the current batch's FMAs, so the scalar-memory latency overlaps the gathers instead
+// of following them; the row tail goes through a 4 / 2 / 1 ladder (at most 3 dependent steps, not 7).
+// Needs n_cols * ldx * sizeof(T) < 2^32 (offsets are 32-bit); larger operands keep k_spmm_wave.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct BufRow;
+template <> struct BufRow<uint16_t> {
+  using Raw = u32x2;
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, static_cast<int>(soff), 0);
+  }
+  static __device__ __forceinline__ float4 widen(const Raw& v) {
+    float4 f;
+    f.x = __uint_as_float(v.x << 16);
+    f.y = __uint_as_float(v.x & 0xffff0000u);
+    f.z = __uint_as_float(v.y << 16);
+    f.w = __uint_as_float(v.y & 0xffff0000u);
+    return f;
+  }
+};
+template <> struct BufRow<float> {
+  using Raw = u32x4;
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, static_cast<int>(soff), 0);
+  }
+  static __device__ __forceinline__ float4 widen(const Raw& v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void gather_batch(__amdgpu_buffer_rsrc_t rsrc, int voff, uint32_t pitch,
+                                             const int32_t* __restrict__ colind, const float* __restrict__ val,
+                                             int e, float4& acc) {
+  int32_t c[N];
+  float v[N];
+  typename BufRow<T>::Raw raw[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    c[u] = colind[e + u];
+    v[u] = val[e + u];
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c[u]) * pitch);
+#pragma unroll
+  for (int u = 0; u < N; ++u) fma4(acc, v[u], BufRow<T>::widen(raw[u]));
+}
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_row(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const float* __restrict__ val,
+    const T* __restrict__ x, uint32_t pitch, uint32_t x_bytes, T* __restrict__ y, int64_t ldy, int64_t n_rows,
+    int32_t d, LongQueue lq) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row = blk * kWavesPerBlock + wid;  // wave-uniform
+  if (row >= n_rows) return;
+  const int64_t e0 = rowptr[row];
+  const int64_t e1 = rowptr[row + 1];
+  if (e1 - e0 > lq.long_len) {   // wave-uniform
+    push_long_row(lq, row, e1 - e0, lane, 64);
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, x_bytes, 0x00020000);
+  const int fc = lane * 4;
+  const bool active = fc < d;
+  const int voff = active ? fc * static_cast<int>(sizeof(T)) : 0;   // idle lanes re-read column 0
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // 32-bit positions relative to the row start (scalar compares; a 64-bit induction variable costs VALU compares)
+  const int32_t* __restrict__ ci = colind + e0;
+  const float* __restrict__ va = val + e0;
+  const int len = static_cast<int>(e1 - e0);
+  int i = 0;
+  if (UNROLL <= len) {
+    // full batches, two per trip: A uses (c0, v0) and requests (c1, v1), B the other way round — the scalar
+    // loads of the NEXT batch are issued before the FMAs of the current one wait for its gathers
+    int32_t c0[UNROLL], c1[UNROLL];
+    float v0[UNROLL], v1[UNROLL];
+    typename BufRow<T>::Raw raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      c0[u] = ci[u];
+      v0[u] = va[u];
+    }
+    for (;;) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c0[u]) * pitch);
+      i += UNROLL;
+      const bool more_a = i + UNROLL <= len;
+      if (more_a) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          c1[u] = ci[i + u];
+          v1[u] = va[i + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) fma4(acc, v0[u], BufRow<T>::widen(raw[u]));
+      if (!more_a) break;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c1[u]) * pitch);
+      i += UNROLL;
+      const bool more_b = i + UNROLL <= len;
+      if (more_b) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          c0[u] = ci[i + u];
+          v0[u] = va[i + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) fma4(acc, v1[u], BufRow<T>::widen(raw[u]));
+      if (!more_b) break;
+    }
+  }
+  if (i + 4 <= len) { gather_batch<T, 4>(rsrc, voff, pitch, ci, va, i, acc); i += 4; }
+  if (i + 2 <= len) { gather_batch<T, 2>(rsrc, voff, pitch, ci, va, i, acc); i += 2; }
+  if (i < len) gather_batch<T, 1>(rsrc, voff, pitch, ci, va, i, acc);
+  if (active) store4<T>(y + row * ldy + fc, acc);
+}
+
+// ---- flattened (segmented) wave kernel --------------------------------------------------------------------
+// Why: with ~46 stored entries per row, a wave-per-row kernel spends its life in a chain of DEPENDENT memory
+// latencies — kernel arguments, rowptr, then per 8-entry batch (codes/values -> gathers), then a tail ladder —
+// about ten of them, ~12 us per row (measured: 2.45 M waves in 3.6 ms at 32 waves per CU).  Once the gathers
+// hit in L2 that chain, not bandwidth and not instruction issue, is the launch time.  Here a wave owns
+// kSegRows CONSECUTIVE rows and walks their stored entries as ONE stream in groups of G: the gathers of a
+// group are all in flight together, the codes / values of the NEXT group are requested before the current
+// group's FMAs, and a row boundary inside a group costs one scalar compare per entry plus a store when it
+// is hit.  Per row there is no dependent latency left at all; per group there is one.
+// Rows longer than lq.long_len go to the long-row queue as in the other kernels: a wave that owns one (or
+// whose entry count does not fit the 32-bit stream positions) takes the per-row fallback below.
+constexpr int kSegRows = 8;
+
+template <typename T, int G>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_seg(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const float* __restrict__ val,
+    const T* __restrict__ x, uint32_t pitch, uint32_t x_bytes, T* __restrict__ y, int64_t ldy, int64_t n_rows,
+    int32_t d, int32_t chunk_blocks, LongQueue lq) {
+  using Raw = typename BufRow<T>::Raw;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t blk = xcd_remap(blockIdx.x, gridDim.x, chunk_blocks);
+  const int64_t r_first = (blk * kWavesPerBlock + wid) * kSegRows;
+  if (r_first >= n_rows) return;
+  const int nr = n_rows - r_first < kSegRows ? static_cast<int>(n_rows - r_first) : kSegRows;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, x_bytes, 0x00020000);
+  const int fc = lane * 4;
+  const bool active = fc < d;
+  const int voff = active ? fc * static_cast<int>(sizeof(T)) : 0;
+  T* __restrict__ yl = y + r_first * ldy + (active ? fc : 0);
+
+  // lane i (< nr) holds the END of row r_first + i relative to the wave's first entry
+  const int64_t e_first = rowptr[r_first];
+  const int64_t end_abs = rowptr[r_first + 1 + (lane < nr ? lane : nr - 1)];
+  const int64_t begin_abs = __shfl_up(end_abs, 1, 64);
+  const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);
+  const bool long_i = lane < nr && len_i > lq.long_len;
+  // (readlane results are wave-uniform AND known to be so to the compiler: scalar loads / branches downstream)
+  auto lane64 = [&](int64_t v, int i) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffff), i);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), i);
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+  };
+  const int64_t total64 = lane64(end_abs, nr - 1) - e_first;
+  const int32_t* __restrict__ ci = colind + e_first;
+  const float* __restrict__ va = val + e_first;
+
+  if (__ballot(long_i) != 0 || total64 >= (static_cast<int64_t>(1) << 31)) {
+    // fallback: row by row (rare: a hub row among this wave's rows)
+    for (int r = 0; r < nr; ++r) {
+      const int64_t re = lane64(end_abs, r);
+      const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
+      if (re - rb > lq.long_len) {
+        push_long_row(lq, r_first + r, re - rb, lane, 64);
+        continue;
+      }
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t e = rb; e < re; ++e)
+        fma4(acc, val[e], BufRow<T>::widen(BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(colind[e]) * pitch)));
+      if (active) store4<T>(yl + r * ldy, acc);
+    }
+    return;
+  }
+
+  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
+  const int total = static_cast<int>(total64);
+  int row = 0;
+  int row_end = __builtin_amdgcn_readlane(rel_v, 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // a row ends at stream position p: write it, start the next (empty rows fall through the loop and store zeros)
+  auto boundary = [&](int p) {
+    while (p == row_end && row < nr) {
+      if (active) store4<T>(yl + row * ldy, acc);
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      ++row;
+      row_end = row < nr ? __builtin_amdgcn_readlane(rel_v, row < kSegRows ? row : kSegRows - 1) : 0x7fffffff;
+    }
+  };
+
+  int pos = 0;
+  int32_t c0[G], c1[G];
+  float v0[G], v1[G];
+  Raw raw[G];
+  if (G <= total) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      c0[u] = ci[u];
+      v0[u] = va[u];
+    }
+    for (;;) {
+      // ---- body A: (c0, v0) current, (c1, v1) requested
+#pragma unroll
+      for (int u = 0; u < G; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c0[u]) * pitch);
+      const bool more_a = pos + 2 * G <= total;
+      if (more_a) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          c1[u] = ci[pos + G + u];
+          v1[u] = va[pos + G + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (pos + u == row_end) boundary(pos + u);
+        fma4(acc, v0[u], BufRow<T>::widen(raw[u]));
+      }
+      pos += G;
+      if (!more_a) break;
+      // ---- body B: roles swapped
+#pragma unroll
+      for (int u = 0; u < G; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c1[u]) * pitch);
+      const bool more_b = pos + 2 * G <= total;
+      if (more_b) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          c0[u] = ci[pos + G + u];
+          v0[u] = va[pos + G + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (pos + u == row_end) boundary(pos + u);
+        fma4(acc, v1[u], BufRow<T>::widen(raw[u]));
+      }
+      pos += G;
+      if (!more_b) break;
+    }
+  }
+  // the stream's tail (< G entries): gathers clamped to the last entry, each FMA behind a uniform test
+  if (pos < total) {
+    const int g = total - pos;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int p = pos + (u < g ? u : g - 1);
+      c0[u] = ci[p];
+      v0[u] = va[p];
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) raw[u] = BufRow<T>::load(rsrc, voff, static_cast<uint32_t>(c0[u]) * pitch);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (u < g) {
+        if (pos + u == row_end) boundary(pos + u);
+        fma4(acc, v0[u], BufRow<T>::widen(raw[u]));
+      }
+    }
+    pos = total;
+  }
+  boundary(total);   // closes the last non-empty row and any trailing empty rows (row_end == total for all of them)
+}
+
+// ---- the same stream, bf16 rows fetched TWO PER INSTRUCTION ---------------------------------------------------
+// Four differently built kernels (wave per row with 64-bit and with buffer addressing, the flattened stream above,
+// the LDS-staged row blocks) all ran the re-ordered community graph in 3.6-4.1 ms = 15 TB/s of L2-served
+// gathers: the limit is the vector memory pipe's address rate, which is per LANE — an 8-byte-per-lane load
+// (one 512-byte bf16 row per wave instruction) moves half the bytes of a 16-byte-per-lane load for the same
+// lane work (MI355X_MICROARCH.md: 8-B accesses run at 0.54-0.70x the 16-B rate).  So: lanes 0-31 fetch the
+// row of stream entry 2j (16 B = 8 bf16 each), lanes 32-63 the row of entry 2j+1, in ONE dwordx4 buffer load;
+// each half accumulates its own partial sums of the current row (even / odd stream positions) and the two
+// halves are added when the row ends.  A row boundary between the two entries of a pair takes a slow path
+// (the two halves are applied one after the other under exec masks).  Deterministic: a row's summation order
+// depends only on where its entries sit in the wave's stream.
+template <int G>   // stored entries per group (even): G/2 pair loads in flight per wave
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_seg_bf16x2(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const float* __restrict__ val,
+    const uint16_t* __restrict__ x, uint32_t pitch, uint32_t x_bytes, uint16_t* __restrict__ y, int64_t ldy,
+    int64_t n_rows, int32_t d, int32_t chunk_blocks, LongQueue lq) {
+  constexpr int P = G / 2;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t blk = xcd_remap(blockIdx.x, gridDim.x, chunk_blocks);
+  const int64_t r_first = (blk * kWavesPerBlock + wid) * kSegRows;
+  if (r_first >= n_rows) return;
+  const int nr = n_rows - r_first < kSegRows ? static_cast<int>(n_rows - r_first) : kSegRows;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+  const int q = lane & 31;
+  const bool hi = lane >= 32;
+  const uint32_t hmask = hi ? 0xffffffffu : 0u;
+  const int fc = q * 8;
+  const bool active = fc < d;                      // d % 8 == 0 (checked by the launcher)
+  const uint32_t lanebase = active ? static_cast<uint32_t>(fc) * 2u : 0u;
+  uint16_t* __restrict__ yl = y + r_first * ldy + (active ? fc : 0);
+
+  auto lane64 = [&](int64_t v, int i) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffff), i);
+    const uint32_t hi32 = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), i);
+    return static_cast<int64_t>((static_cast<uint64_t>(hi32) << 32) | lo);
+  };
+  const int64_t e_first = rowptr[r_first];
+  const int64_t end_abs = rowptr[r_first + 1 + (lane < nr ? lane : nr - 1)];
+  const int64_t begin_abs = __shfl_up(end_abs, 1, 64);
+  const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);
+  const bool long_i = lane < nr && len_i > lq.long_len;
+  const int64_t total64 = lane64(end_abs, nr - 1) - e_first;
+  const int32_t* __restrict__ ci = colind + e_first;
+  const float* __restrict__ va = val + e_first;
+
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  auto fma8 = [&](float v, const u32x4& r) {
+    acc[0] = fmaf(v, __uint_as_float(r.x << 16), acc[0]);
+    acc[1] = fmaf(v, __uint_as_float(r.x & 0xffff0000u), acc[1]);
+    acc[2] = fmaf(v, __uint_as_float(r.y << 16), acc[2]);
+    acc[3] = fmaf(v, __uint_as_float(r.y & 0xffff0000u), acc[3]);
+    acc[4] = fmaf(v, __uint_as_float(r.z << 16), acc[4]);
+    acc[5] = fmaf(v, __uint_as_float(r.z & 0xffff0000u), acc[5]);
+    acc[6] = fmaf(v, __uint_as_float(r.w << 16), acc[6]);
+    acc[7] = fmaf(v, __uint_as_float(r.w & 0xffff0000u), acc[7]);
+  };
+  // row finished: add the two halves, lanes 0-31 write 8 bf16 each, both halves start the next row at zero
+  auto flush_row = [&](int local_row) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = acc[k] + __shfl_xor(acc[k], 32, 64);
+    if (active && !hi) {
+      uint4 o;
+      o.x = static_cast<uint32_t>(f32_to_bf16(t[0])) | (static_cast<uint32_t>(f32_to_bf16(t[1])) << 16);
+      o.y = static_cast<uint32_t>(f32_to_bf16(t[2])) | (static_cast<uint32_t>(f32_to_bf16(t[3])) << 16);
+      o.z = static_cast<uint32_t>(f32_to_bf16(t[4])) | (static_cast<uint32_t>(f32_to_bf16(t[5])) << 16);
+      o.w = static_cast<uint32_t>(f32_to_bf16(t[6])) | (static_cast<uint32_t>(f32_to_bf16(t[7])) << 16);
+      *reinterpret_cast<uint4*>(yl + local_row * ldy) = o;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  };
+  auto pair_load = [&](int32_t ca, int32_t cb) -> u32x4 {
+    // offsets are added as unsigned numbers (no wrap): select, do not subtract (cb may be smaller than ca
+    // when the pair straddles a row boundary)
+    const uint32_t sa = static_cast<uint32_t>(ca) * pitch, sb = static_cast<uint32_t>(cb) * pitch;
+    const uint32_t voff = lanebase + (sa ^ ((sa ^ sb) & hmask));
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(voff), 0, 0);
+  };
+  auto pick = [&](float a, float b) -> float {   // lanes 0-31: a, lanes 32-63: b
+    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    return __uint_as_float(ua ^ ((ua ^ ub) & hmask));
+  };
+
+  if (__ballot(long_i) != 0 || total64 >= (static_cast<int64_t>(1) << 31)) {
+    // fallback: row by row, one entry per instruction (rare: a hub row among this wave's rows)
+    for (int r = 0; r < nr; ++r) {
+      const int64_t re = lane64(end_abs, r);
+      const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
+      if (re - rb > lq.long_len) {
+        push_long_row(lq, r_first + r, re - rb, lane, 64);
+        continue;
+      }
+      for (int64_t e = rb; e < re; ++e) {
+        const u32x4 raw = pair_load(colind[e], colind[e]);
+        if (!hi) fma8(val[e], raw);
+      }
+      flush_row(r);
+    }
+    return;
+  }
+
+  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
+  const int total = static_cast<int>(total64);
+  int row = 0;
+  int row_end = __builtin_amdgcn_readlane(rel_v, 0);
+  auto boundary = [&](int p) {     // rows ending at stream position p (empty rows store zeros)
+    while (p == row_end && row < nr) {
+      flush_row(row);
+      ++row;
+      row_end = row < nr ? __builtin_amdgcn_readlane(rel_v, row < kSegRows ? row : kSegRows - 1) : 0x7fffffff;
+    }
+  };
+  // one pair at stream positions (p, p + 1): fast unless a row ends exactly between them
+  auto apply_pair = [&](int p, float v_a, float v_b, const u32x4& raw) {
+    if (p == row_end) boundary(p);
+    if (p + 1 == row_end) {
+      if (!hi) fma8(v_a, raw);
+      boundary(p + 1);
+      if (hi) fma8(v_b, raw);
+    } else {
+      fma8(pick(v_a, v_b), raw);
+    }
+  };
+
+  int pos = 0;
+  int32_t c0[G], c1[G];
+  float v0[G], v1[G];
+  u32x4 raw[P];
+  if (G <= total) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      c0[u] = ci[u];
+      v0[u] = va[u];
+    }
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) raw[j] = pair_load(c0[2 * j], c0[2 * j + 1]);
+      const bool more_a = pos + 2 * G <= total;
+      if (more_a) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          c1[u] = ci[pos + G + u];
+          v1[u] = va[pos + G + u];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < P; ++j) apply_pair(pos + 2 * j, v0[2 * j], v0[2 * j + 1], raw[j]);
+      pos += G;
+      if (!more_a) break;
+#pragma unroll
+      for (int j = 0; j < P; ++j) raw[j] = pair_load(c1[2 * j], c1[2 * j + 1]);
+      const bool more_b = pos + 2 * G <= total;
+      if (more_b) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          c0[u] = ci[pos + G + u];
+          v0[u] = va[pos + G + u];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < P; ++j) apply_pair(pos + 2 * j, v1[2 * j], v1[2 * j + 1], raw[j]);
+      pos += G;
+      if (!more_b) break;
+    }
+  }
+  // the stream's tail (< G entries): indices clamped to the last entry, values of the padding are zero
+  if (pos < total) {
+    const int g = total - pos;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int p = pos + (u < g ? u : g - 1);
+      c0[u] = ci[p];
+      v0[u] = u < g ? va[p] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) raw[j] = pair_load(c0[2 * j], c0[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      if (2 * j < g) {
+        const int p = pos + 2 * j;
+        if (p == row_end) boundary(p);
+        if (2 * j + 1 < g) {
+          apply_pair(p, v0[2 * j], v0[2 * j + 1], raw[j]);
+        } else if (!hi) {
+          fma8(v0[2 * j], raw[j]);                       // last entry of the stream: lanes 0-31 only
+        }
+      }
+    }
+    pos = total;
+  }
+  boundary(total);   // closes the last non-empty row and any trailing empty rows
 }
 
 // LPR lanes per row (power of two, < 64); 64/LPR rows per wave.  d <= 4*LPR.
@@ -290,7 +770,7 @@ __global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ ecode, const float* __restrict__ eval,
     const int32_t* __restrict__ nlds, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_cols,
     const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t n_rows, int32_t d,
-    int32_t rows_per_block, int32_t lds_rows, int32_t chunk_blocks, LongQueue lq) {
+    int32_t rows_per_block, int32_t lds_rows, int32_t chunk_blocks, LongQueue lq, int32_t dbg) {
   using V = typename Stored<T>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   V* tile = reinterpret_cast<V*>(smem_raw);           // [slot][64 lanes]
@@ -309,7 +789,7 @@ __global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
   const int s0 = sh_ptr[blk];
   const int ns = sh_ptr[blk + 1] - s0;
   constexpr int kStage = 9;
-  for (int u0 = wid; u0 < ns; u0 += nw * kStage) {
+  for (int u0 = wid; u0 < ns && !(dbg & 1); u0 += nw * kStage) {
     V r[kStage];
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
@@ -386,8 +866,9 @@ __global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
     const int64_t el = e0 + __builtin_amdgcn_readlane(nl_v, ci);
     const int len = ce1 - cp < kPiece ? static_cast<int>(ce1 - cp) : kPiece;
     const int l0 = 0;                                   // piece-local [l0, l1) = LDS entries, [d0, len) = gathered
-    const int l1 = el > cp ? (el - cp < len ? static_cast<int>(el - cp) : len) : 0;
-    const int d0 = l1;
+    const int l1x = el > cp ? (el - cp < len ? static_cast<int>(el - cp) : len) : 0;
+    const int d0 = l1x;
+    const int l1 = (dbg & 2) ? 0 : l1x;
     if (cp == e0) {
       acc_l = make_float4(0.f, 0.f, 0.f, 0.f);
       acc_d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -396,7 +877,7 @@ __global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
     // first group of gathers: issue now, consume after the LDS entries
     uint2 cv[DG];
     V xv[DG];
-    const int dg0 = len - d0 < DG ? len - d0 : DG;
+    const int dg0 = (dbg & 4) ? 0 : (len - d0 < DG ? len - d0 : DG);
     if (dg0 > 0) {
 #pragma unroll
       for (int u = 0; u < DG; ++u) cv[u] = sc[d0 + (u < dg0 ? u : dg0 - 1)];
@@ -466,6 +947,10 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
   if (chunk < 1) chunk = 1;
   // Two register budgets: "deep" keeps 4 KiB of gathers + 8 LDS entries in flight per wave (<= 128 VGPRs, 16 waves
   // per CU); "lean" halves both and fits 64 VGPRs, for block shapes of which the LDS admits 32 waves per CU.
+  // SGF_SPMM_BLK_DEBUG (timing experiments only, results are then wrong): 1 = skip the staging loads,
+  // 2 = skip the LDS entries, 4 = skip the gathered entries
+  const char* dbg_env = getenv("SGF_SPMM_BLK_DEBUG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   const size_t per_cu = 160 * 1024;
   const bool lean = (per_cu / lds_bytes) * static_cast<size_t>(threads / 64) > 16;
   constexpr int DGd = sizeof(T) == 4 ? 4 : 8, DGl = sizeof(T) == 4 ? 2 : 4;
@@ -480,10 +965,10 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
   }
   if (lean)
     hipLaunchKernelGGL(lean_fn, dim3(static_cast<unsigned>(nb)), dim3(threads), lds_bytes, st, rowptr, ecode, eval,
-                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq);
+                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq, dbg);
   else
     hipLaunchKernelGGL(deep_fn, dim3(static_cast<unsigned>(nb)), dim3(threads), lds_bytes, st, rowptr, ecode, eval,
-                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq);
+                       nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq, dbg);
   SGF_LAUNCH_CHECK();
   if (lq.cap > 0) {
     const dim3 block(kWavesPerBlock * 64);
@@ -498,15 +983,40 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
 }
 
 template <typename T>
-int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const T* x, int64_t ldx,
+int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const T* x, int64_t ldx, int64_t n_cols,
            T* y, int64_t ldy, int64_t n_rows, int32_t d, hipStream_t st, const LongQueue& lq,
            float* partial) {
   constexpr int UNROLL = 8;
   const dim3 block(kWavesPerBlock * 64);
   if (d > 128) {
     const int64_t nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL((k_spmm_wave<T, UNROLL>), dim3(static_cast<unsigned>(nb)), block, 0, st,
-                       rowptr, colind, val, x, ldx, y, ldy, n_rows, d, lq);
+    const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T);
+    const char* un_env = getenv("SGF_SPMM_ROW_UNROLL");      // timing experiments: 16 gathers in flight per wave
+    if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32) && un_env && atoi(un_env) == 16)
+      hipLaunchKernelGGL((k_spmm_row<T, 16>), dim3(static_cast<unsigned>(nb)), block, 0, st, rowptr, colind,
+                         val, x, static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy,
+                         n_rows, d, lq);
+    else if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32) && !getenv("SGF_SPMM_NO_SEG")) {
+      // flattened stream over kSegRows rows per wave; XCD chunk = 4096 rows as in xcd_remap
+      constexpr int G = sizeof(T) == 4 ? 8 : 16;
+      const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
+      if (sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+          reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("SGF_SPMM_NO_PAIR"))
+        hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
+                           reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
+                           static_cast<uint32_t>(x_bytes), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d,
+                           4096 / (kWavesPerBlock * kSegRows), lq);
+      else
+      hipLaunchKernelGGL((k_spmm_seg<T, G>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val, x,
+                         static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy, n_rows, d,
+                         4096 / (kWavesPerBlock * kSegRows), lq);
+    } else if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32))   // 32-bit offsets reach all of X
+      hipLaunchKernelGGL((k_spmm_row<T, UNROLL>), dim3(static_cast<unsigned>(nb)), block, 0, st, rowptr, colind,
+                         val, x, static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy,
+                         n_rows, d, lq);
+    else
+      hipLaunchKernelGGL((k_spmm_wave<T, UNROLL>), dim3(static_cast<unsigned>(nb)), block, 0, st,
+                         rowptr, colind, val, x, ldx, y, ldy, n_rows, d, lq);
   } else {
 #define SGF_SUB(LPR_)                                                                         \
   {                                                                                           \
@@ -542,9 +1052,9 @@ using namespace sgf;
 
 namespace {
 int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x, int64_t ldx,
-                void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, const LongQueue& lq,
+                int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, const LongQueue& lq,
                 float* partial, hipStream_t st, const char* fn) {
-  SGF_REQUIRE(n_rows >= 0 && d >= 0, SGF_E_INVALID, "%s: negative size", fn);
+  SGF_REQUIRE(n_rows >= 0 && d >= 0 && n_cols >= 0, SGF_E_INVALID, "%s: negative size", fn);
   if (n_rows == 0 || d == 0) return SGF_OK;
   SGF_REQUIRE(rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
   SGF_REQUIRE(n_rows < (static_cast<int64_t>(1) << 31) * kWavesPerBlock, SGF_E_UNSUPPORTED,
@@ -557,10 +1067,10 @@ int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, 
                   reinterpret_cast<uintptr_t>(y) % (4 * esz) == 0,
               SGF_E_INVALID, "%s: x / y must be aligned to 4 elements", fn);
   if (dtype == SGF_F32)
-    return launch<float>(rowptr, colind, val, static_cast<const float*>(x), ldx, static_cast<float*>(y), ldy,
+    return launch<float>(rowptr, colind, val, static_cast<const float*>(x), ldx, n_cols, static_cast<float*>(y), ldy,
                          n_rows, d, st, lq, partial);
   if (dtype == SGF_BF16)
-    return launch<uint16_t>(rowptr, colind, val, static_cast<const uint16_t*>(x), ldx,
+    return launch<uint16_t>(rowptr, colind, val, static_cast<const uint16_t*>(x), ldx, n_cols,
                             static_cast<uint16_t*>(y), ldy, n_rows, d, st, lq, partial);
   set_error("%s: unknown dtype %d", fn, dtype);
   return SGF_E_INVALID;
@@ -568,10 +1078,10 @@ int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, 
 }  // namespace
 
 extern "C" int sgf_spmm(const int64_t* rowptr, const int32_t* colind, const float* val,
-                        const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows,
+                        const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows,
                         int32_t d, int32_t dtype, void* stream) {
   const LongQueue none{nullptr, nullptr, 0, INT64_MAX};
-  return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, none, nullptr,
+  return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, none, nullptr,
                      static_cast<hipStream_t>(stream), "sgf_spmm");
 }
 
@@ -584,7 +1094,7 @@ extern "C" size_t sgf_spmm_split_workspace_bytes(int64_t long_segments, int32_t 
 }
 
 extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val,
-                              const void* x, int64_t ldx, void* y, int64_t ldy, int64_t n_rows,
+                              const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows,
                               int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
                               void* workspace, size_t workspace_bytes, void* stream) {
   SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31),
@@ -592,7 +1102,7 @@ extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (long_segments == 0) {
     const LongQueue none{nullptr, nullptr, 0, INT64_MAX};
-    return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, none, nullptr, st,
+    return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, none, nullptr, st,
                        "sgf_spmm_split");
   }
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_spmm_split_workspace_bytes(long_segments, d),
@@ -606,7 +1116,7 @@ extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, cons
   float* partial = reinterpret_cast<float*>(
       ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
   SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
-  return spmm_common(rowptr, colind, val, x, ldx, y, ldy, n_rows, d, dtype, lq, partial, st,
+  return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, lq, partial, st,
                      "sgf_spmm_split");
 }
 

@@ -176,11 +176,11 @@ class HipKernels:
         with torch.cuda.device(x.device):
             if long_segments > 0:
                 ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(long_segments, d))
-                _lib.call("sgf_spmm_split", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
+                _lib.call("sgf_spmm_split", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), x.shape[0],
                           _ptr(y), y.stride(0), n_rows, d, _code(x), LONG_ROW, long_segments, _ptr(ws),
                           ws.numel(), _stream(x.device))
             else:
-                _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0),
+                _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), x.shape[0],
                           _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
         return y
 

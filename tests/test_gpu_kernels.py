@@ -114,7 +114,10 @@ def test_spmm_into_column_slice(cuda):
         for c in range(4):
             ops.K.spmm(g.rowptr, g.colind, g.val, xg[:, 64 * c:64 * (c + 1)].contiguous(), n,
                        out=y[:, 64 * c:64 * (c + 1)])
-        assert torch.equal(y, full)                      # same per-feature accumulation order
+        if dtype == torch.float32:
+            assert torch.equal(y, full)                  # same per-feature accumulation order
+        else:   # bf16 d = 256 pairs even / odd stream entries (k_spmm_seg_bf16x2): another fp32 summation order,
+            assert _rel(y.float(), full.float()) <= 2e-3     # so the rounded bf16 results differ by at most an ulp
         assert _rel(y.float(), ref) <= (1e-6 if dtype == torch.float32 else 4e-3)
     with pytest.raises(ValueError):
         ops.K.spmm(g.rowptr, g.colind, g.val, x.to(cuda), n, out=torch.empty(n, d + 4, device=cuda))

@@ -61,7 +61,7 @@ def test_argument_errors_are_reported_per_thread():
     if not _lib.available():
         pytest.skip("libsgf.so not built (run `make`)")
     lib = _lib.load()
-    assert lib.sgf_spmm(None, None, None, None, 0, None, 0, 10, 256, 0, None) == -1      # null pointers
+    assert lib.sgf_spmm(None, None, None, None, 0, 10, None, 0, 10, 256, 0, None) == -1      # null pointers
     main_msg = lib.sgf_last_error()
     assert b"sgf_spmm" in main_msg
     seen = {}

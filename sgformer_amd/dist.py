@@ -7,13 +7,19 @@ four exchange points, all designed into the kernels' partial-sum layouts:
 
   attention fwd/bwd   one all-reduce each of [K^T V | sum K | ||Q||^2 | ||K||^2] (H(d^2+d)+2 fp32)
                       and [dS0 | dz0 | .] (H(d^2+d)+1 fp32): <= 257 KB at d = 256 — latency bound
-  SpMM fwd/bwd        all-gather of the operand rows (X forward, dY backward), in up to 4 column
-                      chunks whose gathers are pipelined against the chunk SpMMs (ops._sharded_spmm).  With the equal
-                      contiguous partition the gathered buffer is indexed by GLOBAL node id, so the
-                      local CSR keeps global column ids and needs no relabelling.  (A uniform random
-                      graph cuts (P-1)/P of its edges, so a halo list would be the whole matrix
-                      anyway; xGMI is point-to-point, each GPU ingests (P-1)/P * N*d*s bytes over
-                      its 7 links.)
+  SpMM fwd/bwd        HALO exchange of the operand rows (X forward, dY backward): at graph build every
+                      rank lists the distinct remote columns its row block references, grouped by owner
+                      (HaloPlan; the owners learn what to send by one all-to-all of index lists); per
+                      SpMM each rank packs the rows its peers need (sgf_gather_rows), ONE
+                      all_to_all_single moves them, and the product runs on [own rows ; halo rows] with
+                      the block's columns relabelled once.  Bytes per SpMM = distinct cut-edge sources
+                      x d x s instead of (P-1)/P x N x d x s.  When the halo would be more than
+                      SGF_HALO_MAX (default 0.5) of the remote rows on any rank — a uniform random graph
+                      cuts (P-1)/P of its edges, its halo IS the whole matrix — every rank falls back to
+                      the all-gather of the operand in up to 4 column chunks whose gathers are pipelined
+                      against the chunk SpMMs (ops._sharded_spmm), indexed by GLOBAL node id.  Directed
+                      graphs: the backward multiplies with the row block of A^T, which carries its own
+                      halo plan (the distinct remote TARGETS of local sources).
   BatchNorm1d         all-reduce of [sum | sumsq] (2 x d fp32, two passes) forward and of
                       [sum dz | sum dz*xhat] backward — required for parity with full-graph BN
   parameter grads     ONE flat all-reduce (SUM) per step: each rank's autograd already produces the
@@ -48,6 +54,45 @@ def _mix64(x: torch.Tensor, stream: int) -> torch.Tensor:
     z = (z ^ shr(z, 30)) * c(0xBF58476D1CE4E5B9)
     z = (z ^ shr(z, 27)) * c(0x94D049BB133111EB)
     return z ^ shr(z, 31)
+
+
+class HaloPlan:
+    """Who needs which rows of a node-sharded operand, for one CSR row block with GLOBAL column ids.
+
+    need     : sorted distinct remote columns of the block, i.e. grouped by owner rank (contiguous ranges)
+    recv_counts[q] / send_counts[q] : rows this rank receives from / sends to rank q per exchange
+    send_idx : LOCAL row numbers to pack, grouped by destination rank (what the peers asked for)
+    colind   : the block's columns relabelled into [own rows (0..n_local) ; halo rows (n_local + position in need)]
+    Built with three collectives (fraction all-reduce, counts all-to-all, index all-to-all), once per graph."""
+
+    def __init__(self, colind: torch.Tensor, ctx: "ShardContext"):
+        dev = colind.device
+        cols = torch.unique(colind.long())                      # sorted
+        remote = cols[(cols < ctx.r0) | (cols >= ctx.r1)]
+        self.n_halo = int(remote.numel())
+        n_remote_rows = max(ctx.n_global - ctx.n_local, 1)
+        frac = torch.tensor([self.n_halo / n_remote_rows], dtype=torch.float64, device=dev)
+        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=ctx.group)   # one decision for all ranks
+        self.max_fraction = float(frac)
+        self.enabled = self.max_fraction <= ctx.halo_max
+        if not self.enabled:
+            return
+        owner = torch.div(remote, ctx.n_max, rounding_mode="floor")
+        need_counts = torch.bincount(owner, minlength=ctx.world)[: ctx.world]
+        send_counts = torch.empty_like(need_counts)
+        dist.all_to_all_single(send_counts, need_counts, group=ctx.group)
+        self.recv_counts = [int(v) for v in need_counts.tolist()]
+        self.send_counts = [int(v) for v in send_counts.tolist()]
+        asked = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(asked, remote.contiguous(), self.send_counts, self.recv_counts, group=ctx.group)
+        if asked.numel() and (int(asked.min()) < ctx.r0 or int(asked.max()) >= ctx.r1):
+            raise RuntimeError("halo plan: a peer asked for a row this rank does not own")
+        self.send_idx = (asked - ctx.r0).to(torch.int32)
+        c = colind.long()
+        is_local = (c >= ctx.r0) & (c < ctx.r1)
+        pos = torch.searchsorted(remote, c.clamp(max=max(ctx.n_global - 1, 0)))
+        self.colind = torch.where(is_local, c - ctx.r0, ctx.n_local + pos).to(torch.int32)
+        self.n_ext = ctx.n_local + self.n_halo
 
 
 class ShardedGraph:
@@ -130,6 +175,17 @@ class ShardedGraph:
     def transposed(self):
         return self._t
 
+    def halo(self, ctx: "ShardContext", transposed: bool):
+        """HaloPlan of the forward block (or of the A^T block the backward multiplies with); the same plan
+        when A is symmetric.  Built on first use — by every rank at the same point of the step."""
+        if not hasattr(self, "_halo"):
+            self._halo = {}
+        key = bool(transposed) and not self.symmetric
+        if key not in self._halo:
+            colind = self._t[1] if key else self.colind
+            self._halo[key] = HaloPlan(colind, ctx)
+        return self._halo[key]
+
 
 class ShardContext:
     """Partition + collectives of one rank.  `group=None` uses the default process group."""
@@ -148,8 +204,10 @@ class ShardContext:
         self.r1 = min(self.r0 + self.n_max, self.n_global)
         self.n_local = self.r1 - self.r0
         self.local_edges = bool(local_edges)
+        self.halo_max = float(os.environ.get("SGF_HALO_MAX", "0.5"))   # largest halo / remote-rows ratio served by the halo path
         self.bytes_all_reduced = 0
         self.bytes_all_gathered = 0
+        self.bytes_halo_sent = 0
 
     # ---- partition helpers ----
     def shard_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -186,6 +244,17 @@ class ShardContext:
         work = dist.all_gather_into_tensor(out, x.contiguous(), group=self.group, async_op=async_op)
         self.bytes_all_gathered += out.numel() * out.element_size()
         return (out, work) if async_op else out
+
+    def halo_exchange(self, x: torch.Tensor, plan: "HaloPlan") -> torch.Tensor:
+        """[n_local, d] -> [n_local + n_halo, d]: own rows, then the rows of the peers this rank's block
+        references (in `plan.need` order).  One pack kernel + one all_to_all_single."""
+        d = x.shape[1]
+        send = ops.gather_rows(x, plan.send_idx) if plan.send_idx.numel() else x.new_empty((0, d))
+        ext = torch.empty((plan.n_ext, d), dtype=x.dtype, device=x.device)
+        ext[: self.n_local] = x
+        dist.all_to_all_single(ext[self.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
+        self.bytes_halo_sent += send.numel() * send.element_size()
+        return ext
 
     def gather_chunks(self, d: int) -> int:
         """Column chunks the SpMM operand is gathered in (ops._sharded_spmm): up to 4, each at least

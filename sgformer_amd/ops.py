@@ -669,12 +669,22 @@ class GraphView:
                 return None                    # undecided: wait for the second forward on this graph
         perm, inv, _ = K.reorder(g.edge_index, g.n, *REORDER_ITERS)
         g2 = CSRGraph(inv.long()[g.edge_index], g.n, validate=False)
+        # how much neighbour sharing the new order exposes: the share of stored entries a row-block plan could
+        # serve from LDS (bf16 rows, the full LDS budget) — the adoption criterion, whichever kernel then runs
         g2.blocked = True
-        plan = g2.plan(_BF16)                  # the fraction served from LDS depends on the LDS budget: bf16 rows
+        plan = g2.plan(_BF16)
         stats = {"lds_fraction": plan.lds_fraction, "staged_rows_per_node": plan.staged_rows / max(g.n, 1),
                  "rows_per_block": plan.rows_per_block, "lds_rows": plan.lds_rows}
         if plan.lds_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
             return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
+        # Which kernel multiplies with the re-ordered CSR: the flattened stream kernels (k_spmm_seg*) by default —
+        # on MI355X they beat the LDS-staged row blocks even at 76 % LDS-served entries (3.3 vs 4.1 ms at
+        # ogbn-products scale, profiles/r02_spmm_structured.md); SGF_SPMM_BLOCKED=1 selects the row-block kernel.
+        import os
+        g2.blocked = os.environ.get("SGF_SPMM_BLOCKED", "0") == "1"
+        if not g2.blocked:
+            g2._plans.clear()
+        stats["kernel"] = "row-block (LDS-staged)" if g2.blocked else "stream"
         return GraphView(g2, perm, inv, {**stats, "reordered": True})
 
 
@@ -718,13 +728,21 @@ graph_cache = _GraphCache()
 # ------------------------------------------------------------------------------------------------
 # T2: SpMM (large/ours.py:34)
 # ------------------------------------------------------------------------------------------------
-def _sharded_spmm(rowptr, colind, val, x, n_local: int, shard, long_segments: int = 0):
-    """Local rows of A times the all-gathered operand, with the gather PIPELINED against the
-    product: the operand is split into column chunks, every chunk's all-gather is issued up front
-    (asynchronously, on the collective's own stream), and the SpMM of chunk c starts as soon as chunk
-    c has arrived while chunks c+1.. are still on the xGMI links.  The all-gather is the one
-    bandwidth-bound exchange of the path (N*d*s bytes per SpMM into every GPU), the SpMM the one
-    HBM-bound kernel: they use different resources, so overlapping them hides the shorter of the two."""
+def _sharded_spmm(graph, x, shard, transposed: bool):
+    """Local rows of A (or of A^T) times the node-sharded operand.
+
+    Halo path (graph.halo(...).enabled): pack the rows the peers need, one all_to_all_single, product on
+    [own rows ; halo rows] with the block's relabelled columns — bytes on the links = the distinct cut-edge
+    sources only.  Fallback when the cut is (nearly) everything: all-gather of the operand PIPELINED against
+    the product — the operand is split into column chunks, every chunk's all-gather is issued up front
+    (asynchronously, on the collective's own stream), and the SpMM of chunk c starts as soon as chunk c has
+    arrived while chunks c+1.. are still on the xGMI links."""
+    rowptr, colind, val = graph.transposed() if transposed else (graph.rowptr, graph.colind, graph.val)
+    long_segments = graph.t_long_segments if transposed else graph.long_segments
+    n_local = graph.n_local
+    plan = graph.halo(shard, transposed) if hasattr(graph, "halo") else None
+    if plan is not None and plan.enabled:
+        return K.spmm(rowptr, plan.colind, val, shard.halo_exchange(x, plan), n_local, long_segments=long_segments)
     d = x.shape[1]
     chunks = shard.gather_chunks(d)
     if chunks <= 1:
@@ -745,18 +763,15 @@ class _SpMM(torch.autograd.Function):
         ctx.graph, ctx.shard = graph, shard
         if shard is not None:
             # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
-            return _sharded_spmm(graph.rowptr, graph.colind, graph.val, x, graph.n_local, shard,
-                                 graph.long_segments)
+            return _sharded_spmm(graph, x, shard, False)
         return spmm_on(graph, x, False)
 
     @staticmethod
     def backward(ctx, gy):
         graph, shard = ctx.graph, ctx.shard
         if shard is not None:
-            # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the gathered dY
-            rp, ci, va = graph.transposed()
-            return _sharded_spmm(rp, ci, va, gy.contiguous(), graph.n_local, shard,
-                                 graph.t_long_segments), None, None
+            # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the sharded dY
+            return _sharded_spmm(graph, gy.contiguous(), shard, True), None, None
         return spmm_on(graph, gy.contiguous(), True), None, None
 
 

@@ -46,6 +46,38 @@ class CpuKernels:
             out = idx[out]
         return out, (keep.nonzero().view(-1) if want_eid else None)
 
+    # ---- graph-side planning (oracle/graph_oracle.py) ----
+    @staticmethod
+    def graph_prologue(ei, n, undirected, remove_loops, add_loops):
+        from oracle import graph_oracle as G
+        e = ei.cpu().numpy()
+        if undirected and remove_loops and add_loops:
+            return torch.from_numpy(G.graph_prologue(e, n, undirected=True))
+        src, dst = e[0], e[1]
+        if undirected:
+            key = np.unique(np.concatenate([src, dst]) * n + np.concatenate([dst, src]))
+            src, dst = key // n, key % n
+        if remove_loops:
+            keep = src != dst
+            src, dst = src[keep], dst[keep]
+        if add_loops:
+            loops = np.arange(n, dtype=np.int64)
+            src, dst = np.concatenate([src, loops]), np.concatenate([dst, loops])
+        return torch.from_numpy(np.stack([src, dst]))
+
+    @staticmethod
+    def reorder(ei, n, iters1, iters2):
+        from oracle import graph_oracle as G
+        return tuple(torch.from_numpy(a) for a in G.reorder(ei.cpu().numpy(), n, iters1, iters2))
+
+    @staticmethod
+    def gather_rows(src, idx, out_dtype=None):
+        return src[idx.long()].to(out_dtype or src.dtype)
+
+    @staticmethod
+    def lds_rows_max(dtype):
+        return 288 if dtype == torch.bfloat16 else 144
+
     # ---- T2 ----
     @staticmethod
     def spmm(rowptr, colind, val, x, n_rows, out=None, long_segments=0):

@@ -106,6 +106,76 @@ def test_sharded_step_matches_full_graph(world, cfg_name, directed, chunk_cols):
         assert e["gathered"] > 0 and e["reduced"] > 0
 
 
+def _worker_halo(rank, world, port, directed, ret):
+    """A graph whose contiguous node ranges cut few edges (planted communities, ids NOT shuffled): the
+    SpMM exchange must take the halo path (no all-gather at all) and match the full-graph oracle."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import sgformer_oracle as O
+        from sgformer_amd import ops, synth
+        from sgformer_amd.dist import ShardContext, shard_model, sharded_nll_loss
+        from sgformer_amd.ours import SGFormer
+        from tests.cpu_kernels import CpuKernels
+        from tests.test_host import CONFIGS
+
+        ops.set_kernels(CpuKernels())
+        cfg = CONFIGS["products"]
+        n, f, d, c = 601, 10, 16, 4
+        torch.manual_seed(5)
+        x = torch.randn(n, f)
+        ei = synth.synthetic_graph_community(n, 8.0, seed=3, comm_size=(20, 40), comms_per_super=4, p_comm=0.9,
+                                             p_super=0.09, shuffle_ids=False)
+        if directed:   # drop one direction of a third of the pairs: A != A^T, the backward needs its own halo
+            keep = (ei[0] <= ei[1]) | (torch.arange(ei.shape[1]) % 3 != 0)
+            ei = ei[:, keep]
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: n // 2]
+        p = O.init_params(cfg, f, d, c, seed=6)
+        ctx = ShardContext(n)
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        shard_model(m, ctx)
+        m.train()
+        logits = m(ctx.shard_rows(x), ei)
+        loss = sharded_nll_loss(logits, ctx.shard_rows(y), ctx.local_index(idx), idx.numel())
+        loss.backward()
+        ctx.sync_grads(m.parameters())
+        p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+        ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True)
+        O.nll_loss(ref, y, idx).backward()
+        gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+        gerr = 0.0
+        for k, prm in m.named_parameters():
+            if p64[k].grad is not None:
+                e = float((prm.grad.double() - p64[k].grad).norm())
+                gerr = max(gerr, e / (float(p64[k].grad.norm()) + 1e-3 * gmax))
+        g = ctx.graph_for(ei)
+        ret[rank] = {"logits": float((logits.detach().double() - ref.detach()[ctx.r0:ctx.r1]).abs().max()),
+                     "grad": gerr, "halo_sent": ctx.bytes_halo_sent, "gathered": ctx.bytes_all_gathered,
+                     "n_halo": g.halo(ctx, False).n_halo, "fraction": g.halo(ctx, False).max_fraction,
+                     "symmetric": bool(g.symmetric), "plans": len(g._halo)}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,directed", [(2, False), (3, False), (2, True)])
+def test_halo_exchange_matches_full_graph(world, directed):
+    """halo all-gather for cut-edge neighbour features (large/ours.py:34 sharded by rows)."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_halo, args=(world, port, directed, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        e = ret[rank]
+        assert e["logits"] < 5e-5 and e["grad"] < 2e-3, e
+        assert e["gathered"] == 0 and e["halo_sent"] > 0, e          # halo path only: no all-gather of X
+        assert e["fraction"] <= 0.5 and 0 < e["n_halo"] < 601 // world, e
+        assert e["symmetric"] != directed and e["plans"] == (2 if directed else 1), e
+
+
 def _worker_local_edges(rank, world, port, ret):
     """Weak-scaling mode: every rank generates ONLY its own rows of the graph (synthetic_graph_shard) and
     hands `model` those local edges; the union over ranks is the reference graph."""

@@ -152,13 +152,15 @@ def test_gather_rows(cuda, idx_dtype, d, src_dtype, dst_dtype):
     assert torch.equal(y.detach().cpu(), src.float()[perm]) and torch.equal(xg.grad.cpu(), w[inv])
 
 
+@pytest.mark.parametrize("blocked", ["0", "1"])
 @pytest.mark.parametrize("name,dtype", [("community", torch.float32), ("directed", torch.float32),
                                         ("community", torch.bfloat16)])
-def test_module_on_reordered_graph_matches_oracle(cuda, name, dtype):
+def test_module_on_reordered_graph_matches_oracle(cuda, name, dtype, blocked, monkeypatch):
     """The whole module with the node order + row-block plan ADOPTED (mode 'always') against the fp64
     oracle in the caller's node order: logits 1e-4, gradients relative (large/ours.py:265-276)."""
     from sgformer_amd import ops
     from sgformer_amd.ours import SGFormer
+    monkeypatch.setenv("SGF_SPMM_BLOCKED", blocked)      # the stream kernels / the LDS-staged row blocks
     cfg = dict(trans_num_layers=1, trans_num_heads=1, trans_use_act=False, gnn_num_layers=2, gnn_use_init=True,
                graph_weight=0.5)
     ei = _graphs()[name]
@@ -178,7 +180,7 @@ def test_module_on_reordered_graph_matches_oracle(cuda, name, dtype):
         eig = ei.to(cuda)
         logits = m(x.to(cuda), eig)
         view = ops.graph_cache.get(eig, n).view()
-        assert view.perm is not None and view.graph.blocked and view.stats["reordered"]
+        assert view.perm is not None and view.stats["reordered"]
         loss = O.nll_loss(logits, y.to(cuda), idx.to(cuda))
         loss.backward()
     finally:

@@ -110,18 +110,44 @@ class ShardedGraph:
         if ctx.local_edges:
             self._init_from_local_edges(edge_index, ctx)
             return
-        full = ops.CSRGraph(edge_index, ctx.n_global)
-        self.device = full.device
-        self.rowptr, self.colind, self.val = self._slice(full.rowptr, full.colind, full.val, ctx)
+        # Replicated edge list: only the edges this rank multiplies with are SORTED here (those whose target it
+        # owns; for a directed graph also those whose source it owns, for the A^T block) — 1/P of the radix sort
+        # of the full list; the in-degrees every value needs come from one O(E) histogram of all targets.
+        n_g, dev = ctx.n_global, edge_index.device
+        self.device = dev
+        src, dst = edge_index[0], edge_index[1]
+        deg = torch.bincount(dst, minlength=n_g).to(torch.int32)
+        fwd, bwd = src * n_g + dst, dst * n_g + src
+        self.symmetric = bool(_mix64(fwd, 0).sum() == _mix64(bwd, 0).sum()) and \
+            bool(_mix64(fwd, 1).sum() == _mix64(bwd, 1).sum())
+        del fwd, bwd
+        own_t = (dst >= ctx.r0) & (dst < ctx.r1)
+        self.rowptr, self.colind, self.val = self._block(edge_index[:, own_t], deg, ctx, transposed=False)
         self.long_segments = ops.long_row_segments(self.rowptr)
-        t_rowptr, t_colind, t_val = full.transposed()
-        self.symmetric = full.symmetric
-        if full.symmetric:
+        if self.symmetric:
             self._t = (self.rowptr, self.colind, self.val)
             self.t_long_segments = self.long_segments
         else:
-            self._t = self._slice(t_rowptr, t_colind, t_val, ctx)
+            own_s = (src >= ctx.r0) & (src < ctx.r1)
+            self._t = self._block(edge_index[:, own_s].flip(0), deg, ctx, transposed=True)
             self.t_long_segments = ops.long_row_segments(self._t[0])
+
+    @staticmethod
+    def _block(local_edges: torch.Tensor, deg: torch.Tensor, ctx: "ShardContext", transposed: bool):
+        """CSR of the rows [r0, r1) from the edges that land in them (row = edge[1]), values from the GLOBAL
+        in-degree vector with k_finalize's arithmetic (csr.hip): sqrt(1/d_target) * sqrt(1/d_source) in fp32,
+        non-finite -> 0.  For the A^T block the rows are SOURCES, so (row, col) = (source, target)."""
+        part = ops.CSRGraph(local_edges.contiguous(), ctx.n_global, validate=False)   # foreign rows come out empty
+        lo = int(part.rowptr[ctx.r0])
+        rowptr = (part.rowptr[ctx.r0:ctx.r1 + 1] - lo).contiguous()
+        colind = part.colind
+        dinv = (1.0 / deg.to(torch.float32)).sqrt()
+        counts = rowptr[1:] - rowptr[:-1]
+        row_of = torch.repeat_interleave(torch.arange(ctx.r0, ctx.r1, device=colind.device), counts,
+                                         output_size=int(colind.numel()))
+        tgt, srcn = (colind.long(), row_of) if transposed else (row_of, colind.long())
+        val = dinv[tgt] * dinv[srcn]
+        return rowptr, colind, torch.nan_to_num(val, nan=0.0, posinf=0.0, neginf=0.0)
 
     def _init_from_local_edges(self, edge_index: torch.Tensor, ctx: "ShardContext"):
         """edge_index = exactly the edges whose target (edge_index[1]) this rank owns, GLOBAL ids.

@@ -365,7 +365,28 @@ int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
                      int32_t dtype, void* dx, int64_t lddx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * T7 — branch combine.   Replaces large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.
+ * T7 — branch combine + output layer, fused (the "residual + MLP" kernel).   Replaces
+ * large/ours.py:269-270,275 (aggregate == 'add'):
+ *     x = graph_weight * x2 + (1 - graph_weight) * x1;   logits = fc(x) = x W^T + bias
+ *   sgf_combine_fc_fwd : logits[n, classes] (fp32, leading dim ldl) = (a x1 + b x2) W^T + bias in ONE pass
+ *                        over x1, x2 — the combined activations are rounded to the storage dtype once (where
+ *                        the unfused axpby rounds them) and fed to the bf16 matrix cores, never written.
+ *   sgf_combine_fc_bwd : dx1 = a (dlogits W), dx2 = b (dlogits W), storage dtype, one pass over dlogits
+ *                        (fp32 [n, classes], leading dim lddl; rounded to the storage dtype in registers).
+ *   dW = a dlogits^T x1 + b dlogits^T x2 and db are node reductions: sgf_gram.
+ * W: fp32 [classes, d] row-major, bias fp32 [classes].  Implemented for bf16 storage, d % 32 == 0,
+ * d <= 256, classes <= 64 (sgf_combine_fc_supported); anything else: sgf_axpby + a library GEMM.
+ * ------------------------------------------------------------------------------------------ */
+int32_t sgf_combine_fc_supported(int32_t d, int32_t classes, int32_t dtype);
+int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                       const float* w, const float* bias, int64_t n, int32_t d, int32_t classes,
+                       int32_t dtype, float* logits, int64_t ldl, void* stream);
+int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
+                       int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2,
+                       int64_t ld2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T7 — branch combine alone.   large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.
  * (generic axpby: y = a * x1 + b * x2; the 'cat' aggregate is a plain copy done by the caller.)
  * ------------------------------------------------------------------------------------------ */
 int sgf_axpby(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,

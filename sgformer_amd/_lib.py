@@ -90,6 +90,11 @@ SIGNATURES = {
     "sgf_sum_n": (c_int32, [_P, _P, c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
     "sgf_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_colsum": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_combine_fc_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "sgf_combine_fc_fwd": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_int32, c_int32,
+                                     c_int32, _P, c_int64, _P]),
+    "sgf_combine_fc_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P,
+                                     c_int64, _P, c_int64, _P]),
     "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
                             c_int64, _P]),
 }

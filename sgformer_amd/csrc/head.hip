@@ -1,0 +1,248 @@
+// head.hip — T7: the two branches fused into ONE residual + MLP kernel.
+//
+// Reference (large/ours.py:265-276, `aggregate == 'add'`):
+//     x = graph_weight * x2 + (1 - graph_weight) * x1          # [N, d] elementwise
+//     x = self.fc(x)                                           # [N, d] -> [N, C], C = 7 ... 47 classes
+// As separate ops that is an axpby pass (read 2, write 1 [N, d] tensors), a GEMM that reads the result
+// again, and — under autograd — the same again backwards plus two scaled copies of the [N, d] gradient.
+//
+//   sgf_combine_fc_fwd : logits = (a x1 + b x2) W^T + bias        one pass over x1, x2; fp32 logits
+//   sgf_combine_fc_bwd : dX = dlogits W;  dx1 = a dX, dx2 = b dX  one pass over dlogits, two stores
+// (dW = a dlogits^T x1 + b dlogits^T x2 and db are reductions over all nodes: sgf_gram, as for every
+// other Linear of the path.)
+//
+// gfx950 mapping (bf16 activations — BASELINE.json config 3; fp32 runs keep sgf_axpby + the library GEMM):
+//   * [N, d] x [d, C] with C <= 64 is GEMM-shaped but skinny: v_mfma_f32_32x32x16_bf16, a wave owns 32 rows
+//     and both 32-class tiles, so one A fragment feeds two MFMAs; W (bf16, <= 64 x 256 = 32 KiB) lives in LDS
+//     for the whole block, rows padded by 16 B so the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
+//   * the A operand needs, per lane, 8 consecutive k of ONE row (lane l: row l & 31, k = 8 (l >> 5) ...):
+//     16 contiguous bytes of x1 and of x2 — read straight from global memory (each 128-byte line of a row is
+//     consumed by 4 consecutive k-steps of the same wave), combined in fp32 and rounded to bf16 ONCE — the same
+//     rounding point as the unfused axpby.  No LDS staging of activations, no barrier in the row loop.
+//   * backward: A = dlogits (fp32 in memory, rounded to bf16 in registers: the rounding the unfused path
+//     applies when it casts the logits gradient to the activation dtype), B = W^T fragments from a transposed
+//     LDS copy; a wave keeps the 32 x 256 result in 8 accumulator tiles and stores both scaled copies.
+// HBM-bound: forward 2 d s + 4 C bytes per node, backward 4 C + 2 d s.
+#include "common.h"
+
+namespace sgf {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kHeadThreads = 256;                 // 4 waves, 32 rows each per trip
+constexpr int kMaxClasses = 64;                   // two 32-class tiles
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
+}
+__device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+union Frag {
+  bf16x8 v;
+  uint4 u;
+};
+
+// logits[N, C] = (a x1 + b x2)[N, d] W[C, d]^T + bias.   d % 16 == 0, d <= 256, C <= 64.
+template <int DP>   // d rounded up to 64 / 128 / 256 (LDS pitch, k-steps)
+__global__ __launch_bounds__(kHeadThreads) void k_head_fwd_bf16(
+    const uint16_t* __restrict__ x1, int64_t ld1, float a, const uint16_t* __restrict__ x2, int64_t ld2, float b,
+    const float* __restrict__ w, const float* __restrict__ bias, int64_t n, int d, int c,
+    float* __restrict__ logits, int64_t ldl) {
+  constexpr int PITCH = DP + 8;                    // bf16 elements per LDS row of W (+16 B)
+  __shared__ __align__(16) uint16_t wl[kMaxClasses * PITCH];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  // W -> bf16 in LDS, classes >= c and columns >= d zero
+  for (int i = threadIdx.x; i < kMaxClasses * (DP / 4); i += kHeadThreads) {
+    const int row = i / (DP / 4), col = (i % (DP / 4)) * 4;
+    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < c && col < d) f = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(row) * d + col);
+    uint2 pk;
+    pk.x = pack2(f.x, f.y);
+    pk.y = pack2(f.z, f.w);
+    *reinterpret_cast<uint2*>(&wl[row * PITCH + col]) = pk;
+  }
+  __syncthreads();
+  const int i31 = lane & 31, hi = lane >> 5;
+  const int ks = d / 16;
+  const float bias0 = i31 < c ? bias[i31] : 0.f;
+  const float bias1 = 32 + i31 < c ? bias[32 + i31] : 0.f;
+  const int64_t ntiles = (n + 31) / 32;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wid; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+    int64_t row = tile * 32 + i31;
+    if (row >= n) row = n - 1;                     // clamp: loads stay in bounds, stores are masked
+    const uint16_t* p1 = x1 + row * ld1 + 8 * hi;
+    const uint16_t* p2 = x2 + row * ld2 + 8 * hi;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    for (int s0 = 0; s0 < ks; s0 += 4) {
+      uint4 r1[4], r2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u < ks ? s0 + u : ks - 1;
+        r1[u] = *reinterpret_cast<const uint4*>(p1 + 16 * s);
+        r2[u] = *reinterpret_cast<const uint4*>(p2 + 16 * s);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (s0 + u < ks) {
+          Frag fa;
+          fa.u.x = pack2(a * lo16(r1[u].x) + b * lo16(r2[u].x), a * hi16(r1[u].x) + b * hi16(r2[u].x));
+          fa.u.y = pack2(a * lo16(r1[u].y) + b * lo16(r2[u].y), a * hi16(r1[u].y) + b * hi16(r2[u].y));
+          fa.u.z = pack2(a * lo16(r1[u].z) + b * lo16(r2[u].z), a * hi16(r1[u].z) + b * hi16(r2[u].z));
+          fa.u.w = pack2(a * lo16(r1[u].w) + b * lo16(r2[u].w), a * hi16(r1[u].w) + b * hi16(r2[u].w));
+          const int k0 = 16 * (s0 + u) + 8 * hi;
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wl[i31 * PITCH + k0]);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&wl[(32 + i31) * PITCH + k0]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b1, acc1, 0, 0, 0);
+        }
+      }
+    }
+    // C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t orow = tile * 32 + mfma32_row(r, lane);
+      if (orow < n) {
+        if (i31 < c) logits[orow * ldl + i31] = acc0[r] + bias0;
+        if (32 + i31 < c) logits[orow * ldl + 32 + i31] = acc1[r] + bias1;
+      }
+    }
+  }
+}
+
+// dx1 = a (dlogits W), dx2 = b (dlogits W).   d % 32 == 0, d <= 256, C <= 64.
+template <int DP>
+__global__ __launch_bounds__(kHeadThreads) void k_head_bwd_bf16(
+    const float* __restrict__ dl, int64_t lddl, const float* __restrict__ w, int64_t n, int d, int c, float a, float b,
+    uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2) {
+  constexpr int PITCH = kMaxClasses + 8;           // bf16 elements per LDS row of W^T (+16 B)
+  constexpr int NT = DP / 32;
+  __shared__ __align__(16) uint16_t wt[DP * PITCH];   // wt[feature][class]
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < DP * kMaxClasses; i += kHeadThreads) {
+    const int f = i % DP, cl = i / DP;             // consecutive threads read consecutive features of one class
+    const float v = (cl < c && f < d) ? w[static_cast<int64_t>(cl) * d + f] : 0.f;
+    wt[f * PITCH + cl] = f32_to_bf16(v);
+  }
+  __syncthreads();
+  const int i31 = lane & 31, hi = lane >> 5;
+  const int ks = (c + 15) / 16;
+  const int64_t ntiles = (n + 31) / 32;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wid; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+    int64_t row = tile * 32 + i31;
+    if (row >= n) row = n - 1;
+    const float* pg = dl + row * lddl;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int s = 0; s < ks; ++s) {
+      const int k0 = 16 * s + 8 * hi;
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = k0 + j < c ? pg[k0 + j] : 0.f;   // rows of dlogits are C floats: unaligned
+      Frag fa;
+      fa.u.x = pack2(g[0], g[1]);
+      fa.u.y = pack2(g[2], g[3]);
+      fa.u.z = pack2(g[4], g[5]);
+      fa.u.w = pack2(g[6], g[7]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (32 * t < d) {
+          const bf16x8 bt = *reinterpret_cast<const bf16x8*>(&wt[(32 * t + i31) * PITCH + k0]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bt, acc[t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (32 * t < d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t orow = tile * 32 + mfma32_row(r, lane);
+          if (orow < n) {
+            dx1[orow * ld1 + 32 * t + i31] = f32_to_bf16(a * acc[t][r]);
+            dx2[orow * ld2 + 32 * t + i31] = f32_to_bf16(b * acc[t][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+inline int head_grid(int64_t n) {
+  int64_t b = (n + 127) / 128;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 4;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+int check_head(const char* fn, int64_t n, int d, int c, int dtype) {
+  SGF_REQUIRE(n >= 0 && d > 0 && c > 0, SGF_E_INVALID, "%s: bad size", fn);
+  SGF_REQUIRE(dtype == SGF_BF16, SGF_E_UNSUPPORTED,
+              "%s: bf16 activations only (fp32 runs use sgf_axpby + the library GEMM)", fn);
+  SGF_REQUIRE(d % 32 == 0 && d <= 256 && c <= kMaxClasses, SGF_E_UNSUPPORTED,
+              "%s: needs d %% 32 == 0, d <= 256, classes <= %d (d=%d, classes=%d)", fn, kMaxClasses, d, c);
+  return SGF_OK;
+}
+
+}  // namespace
+}  // namespace sgf
+
+using namespace sgf;
+
+extern "C" int32_t sgf_combine_fc_supported(int32_t d, int32_t classes, int32_t dtype) {
+  return dtype == SGF_BF16 && d > 0 && d % 32 == 0 && d <= 256 && classes > 0 && classes <= kMaxClasses;
+}
+
+extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                                  const float* w, const float* bias, int64_t n, int32_t d, int32_t classes,
+                                  int32_t dtype, float* logits, int64_t ldl, void* stream) {
+  int rc = check_head("sgf_combine_fc_fwd", n, d, classes, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(x1 && x2 && w && bias && logits && ld1 % 8 == 0 && ld2 % 8 == 0 && ld1 >= d && ld2 >= d && ldl >= classes,
+              SGF_E_INVALID, "sgf_combine_fc_fwd: bad pointer / ld");
+  SGF_REQUIRE(reinterpret_cast<uintptr_t>(x1) % 16 == 0 && reinterpret_cast<uintptr_t>(x2) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(w) % 16 == 0,
+              SGF_E_INVALID, "sgf_combine_fc_fwd: x1 / x2 / w must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(head_grid(n)), block(kHeadThreads);
+#define SGF_HEAD_FWD(DP_)                                                                                        \
+  hipLaunchKernelGGL((k_head_fwd_bf16<DP_>), grid, block, 0, st, static_cast<const uint16_t*>(x1), ld1, a,       \
+                     static_cast<const uint16_t*>(x2), ld2, b, w, bias, n, d, classes, logits, ldl)
+  if (d <= 64) SGF_HEAD_FWD(64);
+  else if (d <= 128) SGF_HEAD_FWD(128);
+  else SGF_HEAD_FWD(256);
+#undef SGF_HEAD_FWD
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
+                                  int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1,
+                                  void* dx2, int64_t ld2, void* stream) {
+  int rc = check_head("sgf_combine_fc_bwd", n, d, classes, dtype);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
+              "sgf_combine_fc_bwd: bad pointer / ld");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(head_grid(n)), block(kHeadThreads);
+#define SGF_HEAD_BWD(DP_)                                                                                   \
+  hipLaunchKernelGGL((k_head_bwd_bf16<DP_>), grid, block, 0, st, dlogits, lddl, w, n, d, classes, a, b,       \
+                     static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2)
+  if (d <= 64) SGF_HEAD_BWD(64);
+  else if (d <= 128) SGF_HEAD_BWD(128);
+  else SGF_HEAD_BWD(256);
+#undef SGF_HEAD_BWD
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}

@@ -485,6 +485,33 @@ class HipKernels:
             _lib.call("sgf_sum_n", ptrs, lds, k, n, d, _code(y), _ptr(y), y.stride(0), _stream(y.device))
         return y
 
+    # ---- T7 fused: logits = (a x1 + b x2) W^T + bias ----
+    @staticmethod
+    def combine_fc_supported(d: int, classes: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_combine_fc_supported(d, classes, _lib.SGF_BF16))
+
+    @staticmethod
+    def combine_fc_fwd(x1, a: float, x2, b: float, w, bias) -> torch.Tensor:
+        n, d = x1.shape
+        c = w.shape[0]
+        logits = torch.empty((n, c), dtype=_F32, device=x1.device)
+        with torch.cuda.device(x1.device):
+            _lib.call("sgf_combine_fc_fwd", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), _ptr(w),
+                      _ptr(bias), n, d, c, _code(x1), _ptr(logits), logits.stride(0), _stream(x1.device))
+        return logits
+
+    @staticmethod
+    def combine_fc_bwd(g, w, a: float, b: float, dtype):
+        n, c = g.shape
+        d = w.shape[1]
+        dx1 = torch.empty((n, d), dtype=dtype, device=g.device)
+        dx2 = torch.empty((n, d), dtype=dtype, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("sgf_combine_fc_bwd", _ptr(g), g.stride(0), _ptr(w), n, d, c, float(a), float(b),
+                      _lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32, _ptr(dx1), dx1.stride(0), _ptr(dx2),
+                      dx2.stride(0), _stream(g.device))
+        return dx1, dx2
+
     # ---- T7 ----
     @staticmethod
     def axpby(x1, a: float, x2, b: float) -> torch.Tensor:
@@ -1206,6 +1233,48 @@ class _Axpby(torch.autograd.Function):
 
 def axpby(x1, x2, a, b):
     return _Axpby.apply(x1, x2, a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# T7 fused: logits = (a x1 + b x2) W^T + bias   (large/ours.py:269-270 + :275 in one kernel)
+# ------------------------------------------------------------------------------------------------
+class _CombineFC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias, a: float, b: float):
+        K.check(x1, x2)
+        x1, x2 = _rows(x1), _rows(x2)
+        w32 = w.detach().float().contiguous()
+        b32 = bias.detach().float().contiguous()
+        ctx.save_for_backward(x1, x2, w32)
+        ctx.meta = (float(a), float(b), w.dtype, bias.dtype)
+        return K.combine_fc_fwd(x1, a, x2, b, w32, b32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, w32 = ctx.saved_tensors
+        a, b, wdtype, bdtype = ctx.meta
+        g = g.float().contiguous()
+        dx1, dx2 = K.combine_fc_bwd(g, w32, a, b, x1.dtype)
+        # dW = a g^T x1 + b g^T x2, db = colsum(g): node reductions on sgf_gram (g in the activation dtype, its
+        # width padded to a multiple of 4 — the same rounding the unfused path applies to the logits gradient)
+        c = g.shape[1]
+        gp = g.to(x1.dtype)
+        if c % 4 != 0:
+            gp = torch.nn.functional.pad(gp, (0, 4 - c % 4))
+        gp = _rows(gp)
+        dw1, db = K.gram(gp, x1, want_colsum=True)
+        dw2, _ = K.gram(gp, x2, want_colsum=False)
+        dw = (a * dw1 + b * dw2)[:c]
+        return dx1, dx2, dw.to(wdtype), db[:c].to(bdtype), None, None
+
+
+def combine_fc(x1, x2, w, bias, a: float, b: float) -> torch.Tensor:
+    """fp32 logits = (a x1 + b x2) W^T + bias without materialising the combination (sgf_combine_fc_*)."""
+    return _CombineFC.apply(x1, x2, w, bias, a, b)
+
+
+def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:
+    return x.dim() == 2 and K.combine_fc_supported(x.shape[1], classes, x.dtype)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ backward run on the hand-written gfx950 kernels behind include/sgf.h.
     large/ours.py:198-216 LN / relu / residual  ops.ln_res_act      (k_ln_fwd / k_ln_bwd)
     large/ours.py:77-93  BN / relu / residual   ops.batch_stats + ops.bn_act_res
     large/ours.py:83-93  x0 used 7 times        ops.fan_out         (one fused gradient sum)
-    large/ours.py:269-270 weighted add          ops.axpby
+    large/ours.py:269-275 weighted add + fc     ops.combine_fc (one kernel, bf16) / ops.axpby + ops.out_linear
 
 GPU only: a CPU tensor raises (no eager fallback by design).
 """
@@ -451,15 +451,21 @@ class SGFormer(nn.Module):
         else:
             x1 = self.trans_conv(x)
             x2 = self.graph_conv(x, edge_index) if self.use_graph else None
-        if self.use_graph:
-            if self.aggregate == 'add':
-                gw = float(self.graph_weight)
-                x = ops.axpby(x2, x1, gw, 1.0 - gw)
-            else:
-                x = torch.cat((x1, x2), dim=1)
+        if self.use_graph and self.aggregate == 'add' and ops.combine_fc_supported(x1, self.fc.out_features):
+            # gw * x2 + (1 - gw) * x1 -> fc in ONE kernel (large/ours.py:269-270,275): the combined
+            # activations are never written, the logits come out in fp32
+            gw = float(self.graph_weight)
+            out = ops.combine_fc(x2, x1, self.fc.weight, self.fc.bias, gw, 1.0 - gw).to(out_dtype)
         else:
-            x = x1
-        out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
+            if self.use_graph:
+                if self.aggregate == 'add':
+                    gw = float(self.graph_weight)
+                    x = ops.axpby(x2, x1, gw, 1.0 - gw)
+                else:
+                    x = torch.cat((x1, x2), dim=1)
+            else:
+                x = x1
+            out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
         if view is not None and view.perm is not None:
             out = ops.permute_rows(out, view.inv, view.perm)       # back to the caller's node order
         return out

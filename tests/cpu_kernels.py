@@ -46,6 +46,21 @@ class CpuKernels:
             out = idx[out]
         return out, (keep.nonzero().view(-1) if want_eid else None)
 
+    # ---- T7 fused ----
+    @staticmethod
+    def combine_fc_supported(d, classes, dtype):
+        return dtype == torch.bfloat16 and d % 32 == 0 and d <= 256 and classes <= 64
+
+    @staticmethod
+    def combine_fc_fwd(x1, a, x2, b, w, bias):
+        xc = (a * x1.float() + b * x2.float()).to(x1.dtype)          # rounded once, as the kernel does
+        return xc.float() @ w.to(x1.dtype).float().t() + bias
+
+    @staticmethod
+    def combine_fc_bwd(g, w, a, b, dtype):
+        dx = g.to(dtype).float() @ w.to(dtype).float()
+        return (a * dx).to(dtype), (b * dx).to(dtype)
+
     # ---- graph-side planning (oracle/graph_oracle.py) ----
     @staticmethod
     def graph_prologue(ei, n, undirected, remove_loops, add_loops):

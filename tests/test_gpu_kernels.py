@@ -661,3 +661,47 @@ def test_colsum_any_width(cuda, d):
     got = ops.K.colsum(x.to(cuda))
     assert _rel(got, x.double().sum(0)) <= 1e-6
     assert float(ops.K.colsum(torch.zeros(0, d, device=cuda)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,d,c", [(1000, 256, 47), (777, 64, 7), (3001, 128, 40), (33, 256, 64), (500, 256, 2)])
+def test_combine_fc_fused(cuda, n, d, c):
+    """T7, large/ours.py:269-270,275: logits = fc(gw * x2 + (1 - gw) * x1) in one kernel (bf16 activations),
+    forward and all four gradients against fp64 ON THE HOST of the same arithmetic applied to the same
+    bf16-rounded inputs (combined activations rounded to bf16 once, weights rounded to bf16)."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d + c)
+    x1 = torch.randn(n, d, generator=g).bfloat16()
+    x2 = torch.randn(n, d, generator=g).bfloat16()
+    w = (torch.randn(c, d, generator=g) / d ** 0.5)
+    b = torch.randn(c, generator=g) * 0.1
+    go = torch.randn(n, c, generator=g)
+    gw = 0.8
+    assert ops.combine_fc_supported(x1.to(cuda), c)
+    x1g, x2g = x1.to(cuda).requires_grad_(True), x2.to(cuda).requires_grad_(True)
+    wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    out = ops.combine_fc(x2g, x1g, wg, bg, gw, 1.0 - gw)          # the module's argument order
+    assert out.dtype == torch.float32 and out.shape == (n, c)
+    (out * go.to(cuda)).sum().backward()
+    # reference arithmetic on the host: the combination is formed in fp32 (as sgf_axpby forms it) and rounded to
+    # bf16 once, everything after that in fp64.  Forming it in fp64 instead flips the bf16 rounding of ~0.25 % of
+    # the elements (bf16 inputs times 0.8 / 0.2 land near rounding boundaries), the kernel's fused multiply-add a
+    # handful more: so the MEAN error is the criterion (exact rows dominate), the max is bounded by one bf16 ulp
+    # of one element times a weight.
+    xc = (gw * x2.double() + (1.0 - gw) * x1.double())
+    xc_r = (torch.tensor(gw, dtype=torch.float32) * x2.float()
+            + torch.tensor(1.0 - gw, dtype=torch.float32) * x1.float()).bfloat16().double()
+    w_r = w.bfloat16().double()
+    ref = xc_r @ w_r.t() + b.double()
+    err = (out.double().cpu() - ref).abs()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(err.mean()) <= 1e-4 * scale and float(err.max()) <= 4e-3 * scale, (float(err.mean()), float(err.max()))
+    go_r = go.bfloat16().double()                                  # logits gradient rounded to the activation dtype
+    dx = go_r @ w_r
+    assert _rel(x2g.grad.float(), gw * dx) <= 4e-3 and _rel(x1g.grad.float(), (1.0 - gw) * dx) <= 4e-3
+    assert x1g.grad.dtype == torch.bfloat16
+    dw = go_r.t() @ xc                                             # fp32-exact products of bf16 values
+    assert _rel(wg.grad, dw) <= 2e-5
+    assert _rel(bg.grad, go_r.sum(0)) <= 2e-5
+    # and the unfused path (sgf_axpby + library GEMM) agrees to bf16 rounding of the logits
+    unf = ops.out_linear(ops.axpby(x2.to(cuda), x1.to(cuda), gw, 1.0 - gw), w.to(cuda), b.to(cuda)).float()
+    assert float((unf.cpu() - out.detach().cpu()).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))

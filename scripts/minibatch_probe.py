@@ -23,11 +23,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--batch", type=int, default=100000)
+    ap.add_argument("--host-features", action="store_true",
+                    help="keep node features on the host (the reference trainer as written; default = what "
+                         "sgformer_amd.launch sets up: features resident on the GPU, 16 host threads)")
     args = ap.parse_args()
+    if not args.host_features:
+        from sgformer_amd import launch
+        launch.limit_host_threads()
     dev = torch.device("cuda:0")
     n, avg_deg, f, c, d = synth.SHAPES["ogbn-products"]
     ei = synth.synthetic_graph(n, avg_deg, seed=123, device=dev).cpu()     # data stays on the HOST (main-batch.py:43-99)
     x, y, train_idx = synth.synthetic_task(n, f, c, seed=123)
+    if not args.host_features:
+        x = x.to(dev)                      # launch.patch_resident_features
     train_mask = torch.zeros(n, dtype=torch.bool)
     train_mask[train_idx] = True
     dt = None if args.dtype == "f32" else torch.bfloat16
@@ -65,6 +73,7 @@ def main():
     tg, ts, loss = epoch()
     dt_epoch = time.perf_counter() - t0
     print(json.dumps({"workload": "ogbn-products-shaped, amazon2m recipe, random-partition mini-batches",
+                      "features": "host" if args.host_features else "resident on the GPU", "host_threads": torch.get_num_threads(),
                       "dtype": args.dtype, "batch_nodes": args.batch, "batches": num_batch,
                       "epoch_s": round(dt_epoch, 3), "nodes_per_s": round(n / dt_epoch),
                       "host_gather_h2d_s": round(tg, 3), "gpu_subgraph_s": round(ts, 3),

@@ -57,6 +57,8 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
         subset = subset.nonzero().view(-1)
     ei = _on_gpu(edge_index, device) if ops.K.name == "hip" else edge_index
     out, eid = ops.K.subgraph(ei, n, subset.contiguous().long(), bool(relabel_nodes), edge_attr is not None)
+    if relabel_nodes:
+        out._sgf_trusted = True       # ids are positions in `subset`: CSRGraph skips its range check (a host sync)
     if edge_attr is not None:
         edge_attr = edge_attr.to(device)[eid]
     return out, edge_attr

@@ -82,6 +82,36 @@ def patch_prologue():
     return tgu
 
 
+def patch_resident_features():
+    """Keep the node features of the mini-batch trainer on the GPU: wrap the trainer's own
+    `dataset.load_dataset` so that `dataset.graph['node_feat']` is a device tensor.  The per-batch
+    `x[idx_i].to(device)` of large/main-batch.py:138 is then a device gather + a no-op instead of an 88 ms
+    host gather + H2D copy per 100 k-node batch (profiles/r01_minibatch_probe.md: 2.1 s of a 6.3 s epoch).
+    Labels and splits stay on the host (the trainer indexes host masks with them)."""
+    import importlib as _il
+    import torch
+    ds_mod = _il.import_module("dataset")
+    orig = ds_mod.load_dataset
+
+    def load_dataset(*args, **kwargs):
+        ds = orig(*args, **kwargs)
+        if torch.cuda.is_available() and torch.is_tensor(ds.graph.get("node_feat")):
+            ds.graph["node_feat"] = ds.graph["node_feat"].to(torch.device("cuda", torch.cuda.current_device()))
+        return ds
+
+    ds_mod.load_dataset = load_dataset
+    return ds_mod
+
+
+def limit_host_threads():
+    """torch's CPU kernels (the trainer's host-side index / mask ops) slow DOWN beyond ~16 threads on the
+    256-thread hosts of MI355X boxes and their OpenMP team then competes with the launch thread (the 75 ms
+    stalls of profiles/r01_minibatch_probe.md).  Respect OMP_NUM_THREADS if the user set it."""
+    import torch
+    if "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
+
 def _pop_option(argv, name):
     for i, a in enumerate(argv):
         if a == name and i + 1 < len(argv):
@@ -100,6 +130,7 @@ def main(argv=None):
     dtype = _pop_option(argv, "--sgf-dtype")
     host_subgraph = _pop_option(argv, "--sgf-host-subgraph")   # any value: keep PyG's host subgraph
     host_prologue = _pop_option(argv, "--sgf-host-prologue")   # any value: keep PyG's host to_undirected & co.
+    host_features = _pop_option(argv, "--sgf-host-features")   # any value: keep node features on the host
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -123,6 +154,10 @@ def main(argv=None):
         patch_subgraph()
     if host_prologue is None and variant != "medium":
         patch_prologue()
+    if os.path.basename(trainer) == "main-batch.py":
+        limit_host_threads()
+        if host_features is None:
+            patch_resident_features()
     runpy.run_path(trainer, run_name="__main__")
 
 

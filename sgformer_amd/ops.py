@@ -531,11 +531,20 @@ LONG_ROW = 1024
 _SEGMENT = 1024   # = sgf_spmm_segment_len()
 
 
-def long_row_segments(rowptr: torch.Tensor) -> int:
+# Graphs with fewer stored entries than this are per-batch graphs (mini-batch trainers build one per step): their
+# long-row segment count is not read back from the device (a host sync per batch) but bounded from nnz alone.
+SMALL_GRAPH_NNZ = 1 << 23
+
+
+def long_row_segments(rowptr: torch.Tensor, nnz: Optional[int] = None) -> int:
     """sum over rows longer than LONG_ROW of ceil(len / segment): the `long_segments` argument of
-    sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built)."""
+    sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built) — or, for
+    small graphs whose nnz is known on the host, the bound  sum ceil(len/seg) <= nnz/seg + nnz/(LONG_ROW+1)
+    without any device read (0 when no row can be long at all)."""
     if rowptr.numel() <= 1:
         return 0
+    if nnz is not None and nnz < SMALL_GRAPH_NNZ:
+        return 0 if nnz <= LONG_ROW else nnz // _SEGMENT + nnz // (LONG_ROW + 1) + 1
     lens = rowptr[1:] - rowptr[:-1]
     segs = torch.where(lens > LONG_ROW, (lens + (_SEGMENT - 1)) // _SEGMENT, torch.zeros_like(lens))
     return int(segs.sum())
@@ -571,6 +580,8 @@ class CSRGraph:
             raise ValueError("num_nodes must be < 2^31 (int32 column indices)")
         ei = edge_index.contiguous()
         n = int(num_nodes)
+        if getattr(edge_index, "_sgf_trusted", False):
+            validate = False      # produced by batching.subgraph / graph_prologue: ids are in range by construction
         if validate and ei.shape[1] > 0:
             lo, hi = torch.aminmax(ei)
             if int(lo) < 0 or int(hi) >= n:
@@ -578,7 +589,7 @@ class CSRGraph:
         self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
         self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
-        self.long_segments = long_row_segments(self.rowptr)
+        self.long_segments = long_row_segments(self.rowptr, self.nnz)
         self.t_long_segments = 0
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None
@@ -590,7 +601,7 @@ class CSRGraph:
                                                              self.rowptr, self.colind)
             self.symmetric = sym
             self._t = (self.rowptr, self.colind, self.val) if sym else (t_rowptr, t_colind, t_val)
-            self.t_long_segments = self.long_segments if sym else long_row_segments(t_rowptr)
+            self.t_long_segments = self.long_segments if sym else long_row_segments(t_rowptr, self.nnz)
         return self._t
 
     # ---- LDS-staged row-block SpMM: one plan per (orientation, storage dtype) ----

@@ -25,12 +25,20 @@ def _graph(edge_index, n):
     return ops.graph_cache.get(edge_index, n)
 
 
+def _difformer_values(ei, w, n):
+    """medium/difformer.py:66-74: value = edge_weight * (1/d[col]).sqrt() * (1/d[row]).sqrt() with d the
+    UNWEIGHTED in-degree, non-finite -> 0."""
+    row, col = ei[0], ei[1]
+    d = torch.bincount(col, minlength=n).float()
+    v = w.detach().float() * (1.0 / d[col]).sqrt() * (1.0 / d[row]).sqrt()
+    return ei, torch.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)
+
+
 def gcn_conv(x, edge_index, edge_weight=None):
     """medium/difformer.py:63-79: per head, D^-1/2 A D^-1/2 x.  x: [N, H, D] -> [N, H, D]."""
-    if edge_weight is not None:
-        raise NotImplementedError("sgformer_amd gcn_conv: edge weights are not supported")
     n, h, d = x.shape
-    g = _graph(edge_index, n)
+    g = _graph(edge_index, n) if edge_weight is None else ops.weighted_graph(edge_index, edge_weight, n,
+                                                                             _difformer_values, "difformer_w")
     x2 = x.reshape(n, h * d)
     return torch.stack([ops.spmm(g, x2[:, i * d:(i + 1) * d]) for i in range(h)], dim=1)
 

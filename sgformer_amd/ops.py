@@ -636,6 +636,57 @@ class CSRGraph:
         return v if v is not None else GraphView(self, None, None)
 
 
+class WeightedCSRGraph:
+    """CSR of A[target, source] = value_e with EXPLICIT per-edge values — the edge-weighted variants of the
+    medium recipes: GCNConv(x, edge_index, edge_weight) (medium/models.py:55-62, gcn_norm with weights) and
+    DIFFormer's gcn_conv (medium/difformer.py:63-79, value = edge_weight * d_in * d_out).  The caller computes
+    the values (one elementwise expression); entries are ordered by (target, source) like sgf_csr_build's, the
+    transpose by (source, target).  No gradient flows to the values (edge weights are data, not parameters).
+    Same interface as CSRGraph towards ops.spmm."""
+
+    blocked = False
+
+    def __init__(self, edge_index: torch.Tensor, values: torch.Tensor, num_nodes: int):
+        K.check(edge_index, values)
+        n = int(num_nodes)
+        self.n, self.nnz, self.device = n, int(edge_index.shape[1]), edge_index.device
+        self._src, self._tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
+        self._values = values.detach().to(_F32).contiguous()
+        self.rowptr, self.colind, self.val = self._sorted(self._tgt, self._src)
+        self.long_segments = long_row_segments(self.rowptr, self.nnz)
+        self._t, self.t_long_segments, self.symmetric = None, 0, False
+
+    def _sorted(self, rows, cols):
+        perm = torch.argsort(rows * self.n + cols, stable=True)
+        counts = torch.bincount(rows, minlength=self.n)
+        rowptr = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        return rowptr, cols[perm].to(torch.int32), self._values[perm]
+
+    def transposed(self):
+        if self._t is None:
+            self._t = self._sorted(self._src, self._tgt)
+            self.t_long_segments = long_row_segments(self._t[0], self.nnz)
+        return self._t
+
+    def plan(self, dtype, transposed=False):
+        return None
+
+
+def weighted_graph(edge_index: torch.Tensor, edge_weight: torch.Tensor, num_nodes: int, value_fn, tag: str):
+    """Cached WeightedCSRGraph; `value_fn(edge_index, edge_weight, n)` -> (edge_index', values) builds the
+    normalised values once per (edge_index, edge_weight) pair."""
+    key_tag = (tag, edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape))
+
+    def build(ei, n):
+        ei2, vals = value_fn(ei, edge_weight, n)
+        g = WeightedCSRGraph(ei2, vals, n)
+        g.edge_weight_ref = edge_weight          # pins the key tensor, like graph_cache pins edge_index
+        return g
+
+    return graph_cache.get(edge_index, num_nodes, factory=build, tag=key_tag)
+
+
 # SGF_SPMM_BLOCK = "rows_per_block,lds_rows" overrides the block shape (default: 128 rows, all 144 KiB of LDS)
 def _block_shape(dtype):
     import os

@@ -88,8 +88,22 @@ def full_attention_conv(qs, ks, vs, output_attn=False, shard=None):
     """
     n, h, d = qs.shape
     if h != 1:
-        raise NotImplementedError("full_attention_conv: per-head outputs for H > 1 are not exposed; "
-                                  "call TransConvLayer (which returns the head mean, as the reference does)")
+        # per-head outputs [N, H, D] (medium/ours.py:14-46 returns them; every caller in the reference takes the
+        # head mean next, :98): served from the kernels' per-head buffer, forward only — the backward kernels
+        # take the gradient of the head MEAN, which is what TransConvLayer differentiates
+        if torch.is_grad_enabled() and (qs.requires_grad or ks.requires_grad or vs.requires_grad):
+            raise NotImplementedError("full_attention_conv: per-head outputs for H > 1 are forward-only; under "
+                                      "autograd call TransConvLayer (the head mean, as the reference takes next)")
+        if output_attn:
+            raise NotImplementedError("full_attention_conv: output_attn with H > 1: use TransConvLayer")
+        q2, k2 = ops._rows(qs.reshape(n, h * d)), ops._rows(ks.reshape(n, h * d))
+        vh = vs.shape[1]
+        v2 = ops._rows(vs.reshape(n, vh * d))
+        stats = ops.K.attn_fwd_reduce(q2, k2, v2, h, vh, d)
+        if shard is not None:
+            shard.all_reduce(stats)
+        _, _, o_heads = ops.K.attn_fwd_apply(q2, v2, stats, float(n if shard is None else shard.n_global), h, vh, d)
+        return o_heads.reshape(n, h, d)
     qk = torch.cat([qs.reshape(n, h * d), ks.reshape(n, h * d)], dim=1)
     if vs.shape[1] == h:
         qkv = torch.cat([qk, vs.reshape(n, h * d)], dim=1)

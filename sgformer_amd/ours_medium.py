@@ -43,6 +43,23 @@ def _gcn_graph(edge_index: torch.Tensor, n: int):
     return ops.graph_cache.get(edge_index, n, factory=build, tag="gcn_norm")
 
 
+def _gcn_norm_weighted(ei, w, n):
+    """torch_geometric 1.7.2 gcn_norm with edge weights: add_remaining_self_loops (an existing self-loop
+    keeps its weight, the others get 1), deg = scatter_add(w, target), norm = deg^-1/2[src] w deg^-1/2[tgt]."""
+    row, col = ei[0], ei[1]
+    w = w.detach().float()
+    keep = row != col
+    loop_w = torch.ones(n, dtype=w.dtype, device=w.device)
+    loop_w[row[~keep]] = w[~keep]
+    loops = torch.arange(n, dtype=ei.dtype, device=ei.device)
+    row, col = torch.cat([row[keep], loops]), torch.cat([col[keep], loops])
+    w = torch.cat([w[keep], loop_w])
+    deg = torch.zeros(n, dtype=w.dtype, device=w.device).scatter_add_(0, col, w)
+    dis = deg.pow(-0.5)
+    dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+    return torch.stack([row, col]), dis[row] * w * dis[col]
+
+
 class GCNConv(nn.Module):
     """out = A_norm (x @ weight) + bias   (torch_geometric 1.7.2 GCNConv with its defaults)."""
 
@@ -59,8 +76,6 @@ class GCNConv(nn.Module):
         self.bias.data.fill_(0)
 
     def forward(self, x, edge_index, edge_weight=None):
-        if edge_weight is not None:
-            raise NotImplementedError("sgformer_amd GCNConv: edge weights are not on the sgformer recipes' path")
         ops._require_cuda(x, edge_index)
         w_t = self.weight.t()
         pad = -self.out_channels % 4
@@ -70,7 +85,9 @@ class GCNConv(nn.Module):
             # class count (7 on Cora, medium/parse.py:19-23)
             w_t = F.pad(w_t, (0, 0, 0, pad))
         xw = ops.linear(x, w_t, None)
-        y = ops.spmm(_gcn_graph(edge_index, x.shape[0]), xw)
+        graph = (_gcn_graph(edge_index, x.shape[0]) if edge_weight is None else
+                 ops.weighted_graph(edge_index, edge_weight, x.shape[0], _gcn_norm_weighted, "gcn_norm_w"))
+        y = ops.spmm(graph, xw)
         if pad:
             y = y[:, :self.out_channels]
         return y + self.bias.to(y.dtype)
@@ -112,7 +129,7 @@ class GCN(nn.Module):
             else:
                 x = torch.relu(x)
             x = _large._drop(x, self.dropout, self.training)
-        return self.convs[-1](x, edge_index, edge_weight)
+        return self.convs[-1](x, edge_index)     # as the reference: the last conv gets NO edge weights (models.py:62)
 
 
 class TransConvLayer(_large.TransConvLayer):

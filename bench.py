@@ -159,7 +159,8 @@ class SpmmTimer:
             y = orig(rowptr, b, *rest, **kw)
             e1.record()
             s, d = x.element_size(), x.shape[1]
-            timer.kernels.append("k_spmm_blk" if blocked else ("k_spmm_wave" if d > 128 else "k_spmm_sub"))
+            timer.kernels.append("k_spmm_blk" if blocked else ("k_spmm_sub" if d <= 128 else (
+                "k_spmm_seg_bf16x2" if kw.get("stream_hint") and x.dtype == torch.bfloat16 else "k_spmm_row")))
             timer.pairs.append((e0, e1))
             timer.bytes_alg.append(nnz * 8 + (n_rows + 1) * 8 + x.shape[0] * d * s + n_rows * d * s)
             timer.bytes_gather.append(nnz * (8 + d * s) + (n_rows + 1) * 8 + n_rows * d * s)
@@ -186,7 +187,7 @@ class SpmmTimer:
         gat = sum(self.bytes_gather) / len(self.bytes_gather)
         achieved = alg / (mean_ms * 1e-3) / 1e9
         kern = max(set(self.kernels), key=self.kernels.count)
-        entry = "sgf_spmm_blocked" if kern == "k_spmm_blk" else "sgf_spmm"
+        entry = {"k_spmm_blk": "sgf_spmm_blocked", "k_spmm_seg_bf16x2": "sgf_spmm_stream"}.get(kern, "sgf_spmm")
         return {"kernel": f"{kern} ({entry})", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": len(ms), "mean_launch_ms": round(mean_ms, 4),

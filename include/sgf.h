@@ -146,6 +146,18 @@ int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* va
                    int64_t long_len, int64_t long_segments, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* sgf_spmm_split for a CSR whose gathers mostly hit in L2 (a locality-restoring node order, sgf_reorder
+ * below).  The vector memory pipe's address rate is per LANE, so bf16 rows (512 B) are then fetched TWO per
+ * 16-byte-per-lane load: lanes 0-31 take the row of stream entry 2j, lanes 32-63 the row of entry 2j+1; a
+ * wave walks the stored entries of 8 consecutive rows as one stream, the two half-waves keep partial sums of
+ * the even / odd positions and are added when a row ends (k_spmm_seg_bf16x2).  Equal to sgf_spmm up to fp32
+ * summation order, deterministic.  fp32 storage (already 16 B per lane) and operands beyond 4 GiB run the
+ * sgf_spmm kernels.  long_segments = 0: no row is split. */
+int sgf_spmm_stream(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
+                    int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype,
+                    int64_t long_len, int64_t long_segments, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * T2 with on-chip reuse: a locality-restoring node order + an LDS-staged row-block SpMM.
  * Same arithmetic as sgf_spmm (large/ours.py:34, torch_sparse.matmul, sum-reduce) — what changes is

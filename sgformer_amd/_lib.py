@@ -36,6 +36,8 @@ SIGNATURES = {
     "sgf_spmm_split_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_spmm_split": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int64,
                                  c_int64, _P, c_size_t, _P]),
+    "sgf_spmm_stream": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int64,
+                                  c_int64, _P, c_size_t, _P]),
     "sgf_reorder_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_reorder": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_spmm_plan_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),

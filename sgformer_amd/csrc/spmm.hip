@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <climits>
+#include <string>
 #include <cstdlib>
 
 namespace sgf {
@@ -985,32 +986,33 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
 template <typename T>
 int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const T* x, int64_t ldx, int64_t n_cols,
            T* y, int64_t ldy, int64_t n_rows, int32_t d, hipStream_t st, const LongQueue& lq,
-           float* partial) {
+           float* partial, bool stream) {
   constexpr int UNROLL = 8;
   const dim3 block(kWavesPerBlock * 64);
   if (d > 128) {
     const int64_t nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T);
-    const char* un_env = getenv("SGF_SPMM_ROW_UNROLL");      // timing experiments: 16 gathers in flight per wave
-    if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32) && un_env && atoi(un_env) == 16)
-      hipLaunchKernelGGL((k_spmm_row<T, 16>), dim3(static_cast<unsigned>(nb)), block, 0, st, rowptr, colind,
-                         val, x, static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy,
-                         n_rows, d, lq);
-    else if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32) && !getenv("SGF_SPMM_NO_SEG")) {
-      // flattened stream over kSegRows rows per wave; XCD chunk = 4096 rows as in xcd_remap
-      constexpr int G = sizeof(T) == 4 ? 8 : 16;
-      const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
-      if (sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
-          reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("SGF_SPMM_NO_PAIR"))
-        hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
-                           reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
-                           static_cast<uint32_t>(x_bytes), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d,
-                           4096 / (kWavesPerBlock * kSegRows), lq);
-      else
-      hipLaunchKernelGGL((k_spmm_seg<T, G>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val, x,
-                         static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy, n_rows, d,
-                         4096 / (kWavesPerBlock * kSegRows), lq);
-    } else if (d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32))   // 32-bit offsets reach all of X
+    const bool fits32 = d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32);   // 32-bit offsets reach all of X
+    // Kernel choice (A/B on one MI355X, ogbn-products scale, profiles/r02_spmm_structured.md):
+    //   gathers out of HBM (uniform graph)      wave 10.46  row 10.49  seg 10.65  seg_bf16x2 10.66 ms  -> row
+    //   gathers out of L2 (re-ordered, bf16)    wave  3.94  row  3.84  seg  3.96  seg_bf16x2  3.31 ms  -> seg_bf16x2
+    //   gathers out of L2 (re-ordered, fp32)    wave  6.00  row  5.97  seg  7.37                       -> row
+    // `stream` is the caller's statement that the CSR's gathers mostly hit in L2 (sgf_spmm_stream).
+    const char* force = getenv("SGF_SPMM_KERNEL");          // timing experiments: wave | row | seg | seg2
+    const std::string fk = force ? force : "";
+    const bool pair_ok = sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                         reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
+    const int chunk = 4096 / (kWavesPerBlock * kSegRows);   // one XCD walks ~4096 consecutive rows at a time
+    if (fits32 && pair_ok && ((stream && fk.empty()) || fk == "seg2"))
+      hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
+                         reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
+                         static_cast<uint32_t>(x_bytes), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d, chunk, lq);
+    else if (fits32 && fk == "seg")
+      hipLaunchKernelGGL((k_spmm_seg<T, (sizeof(T) == 4 ? 8 : 16)>), dim3(static_cast<unsigned>(nbs)), block, 0, st,
+                         rowptr, colind, val, x, static_cast<uint32_t>(ldx * sizeof(T)),
+                         static_cast<uint32_t>(x_bytes), y, ldy, n_rows, d, chunk, lq);
+    else if (fits32 && fk != "wave")
       hipLaunchKernelGGL((k_spmm_row<T, UNROLL>), dim3(static_cast<unsigned>(nb)), block, 0, st, rowptr, colind,
                          val, x, static_cast<uint32_t>(ldx * sizeof(T)), static_cast<uint32_t>(x_bytes), y, ldy,
                          n_rows, d, lq);
@@ -1053,7 +1055,7 @@ using namespace sgf;
 namespace {
 int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x, int64_t ldx,
                 int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, const LongQueue& lq,
-                float* partial, hipStream_t st, const char* fn) {
+                float* partial, hipStream_t st, const char* fn, bool stream = false) {
   SGF_REQUIRE(n_rows >= 0 && d >= 0 && n_cols >= 0, SGF_E_INVALID, "%s: negative size", fn);
   if (n_rows == 0 || d == 0) return SGF_OK;
   SGF_REQUIRE(rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
@@ -1068,10 +1070,10 @@ int spmm_common(const int64_t* rowptr, const int32_t* colind, const float* val, 
               SGF_E_INVALID, "%s: x / y must be aligned to 4 elements", fn);
   if (dtype == SGF_F32)
     return launch<float>(rowptr, colind, val, static_cast<const float*>(x), ldx, n_cols, static_cast<float*>(y), ldy,
-                         n_rows, d, st, lq, partial);
+                         n_rows, d, st, lq, partial, stream);
   if (dtype == SGF_BF16)
     return launch<uint16_t>(rowptr, colind, val, static_cast<const uint16_t*>(x), ldx, n_cols,
-                            static_cast<uint16_t*>(y), ldy, n_rows, d, st, lq, partial);
+                            static_cast<uint16_t*>(y), ldy, n_rows, d, st, lq, partial, stream);
   set_error("%s: unknown dtype %d", fn, dtype);
   return SGF_E_INVALID;
 }
@@ -1093,20 +1095,20 @@ extern "C" size_t sgf_spmm_split_workspace_bytes(int64_t long_segments, int32_t 
          static_cast<size_t>(long_segments) * static_cast<size_t>(d) * sizeof(float);
 }
 
-extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val,
+static int spmm_split_impl(bool stream_hint, const char* fn, const int64_t* rowptr, const int32_t* colind, const float* val,
                               const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows,
                               int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
                               void* workspace, size_t workspace_bytes, void* stream) {
   SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31),
-              SGF_E_INVALID, "sgf_spmm_split: bad long_len / long_segments");
+              SGF_E_INVALID, "%s: bad long_len / long_segments", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (long_segments == 0) {
     const LongQueue none{nullptr, nullptr, 0, INT64_MAX};
-    return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, none, nullptr, st,
-                       "sgf_spmm_split");
+    return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, none, nullptr, st, fn,
+                       stream_hint);
   }
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_spmm_split_workspace_bytes(long_segments, d),
-              SGF_E_WORKSPACE, "sgf_spmm_split: workspace too small");
+              SGF_E_WORKSPACE, "%s: workspace too small", fn);
   char* ws = static_cast<char*>(workspace);
   LongQueue lq;
   lq.count = reinterpret_cast<int32_t*>(ws);
@@ -1116,8 +1118,25 @@ extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, cons
   float* partial = reinterpret_cast<float*>(
       ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
   SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
-  return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, lq, partial, st,
-                     "sgf_spmm_split");
+  return spmm_common(rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype, lq, partial, st, fn, stream_hint);
+}
+
+extern "C" int sgf_spmm_split(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
+                              int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d,
+                              int32_t dtype, int64_t long_len, int64_t long_segments, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return spmm_split_impl(false, "sgf_spmm_split", rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype,
+                         long_len, long_segments, workspace, workspace_bytes, stream);
+}
+
+// sgf_spmm_split for a CSR whose gathers mostly hit in L2 (a locality-restoring node order, sgf_reorder): bf16 rows
+// are then fetched two per 16-byte-per-lane load by the flattened stream kernel (k_spmm_seg_bf16x2)
+extern "C" int sgf_spmm_stream(const int64_t* rowptr, const int32_t* colind, const float* val, const void* x,
+                               int64_t ldx, int64_t n_cols, void* y, int64_t ldy, int64_t n_rows, int32_t d,
+                               int32_t dtype, int64_t long_len, int64_t long_segments, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return spmm_split_impl(true, "sgf_spmm_stream", rowptr, colind, val, x, ldx, n_cols, y, ldy, n_rows, d, dtype,
+                         long_len, long_segments, workspace, workspace_bytes, stream);
 }
 
 // ---- LDS-staged row-block SpMM (plan from sgf_spmm_plan) ------------------------------------------------

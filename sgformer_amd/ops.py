@@ -161,10 +161,11 @@ class HipKernels:
     # ---- T2 ----
     @staticmethod
     def spmm(rowptr, colind, val, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None,
-             long_segments: int = 0) -> torch.Tensor:
+             long_segments: int = 0, stream_hint: bool = False) -> torch.Tensor:
         """`out`: optional [n_rows, d] destination, possibly a column slice of a wider buffer.
         `long_segments` > 0 (see long_row_segments): rows longer than LONG_ROW are split across
-        workgroups (sgf_spmm_split)."""
+        workgroups (sgf_spmm_split).  `stream_hint`: the CSR's gathers mostly hit in L2 (re-ordered graph):
+        sgf_spmm_stream."""
         x = _rows(x)
         d = x.shape[1]
         y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device) if out is None else out
@@ -174,11 +175,12 @@ class HipKernels:
         if n_rows == 0 or d == 0:
             return y
         with torch.cuda.device(x.device):
-            if long_segments > 0:
-                ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(long_segments, d))
-                _lib.call("sgf_spmm_split", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), x.shape[0],
+            if long_segments > 0 or stream_hint:
+                ws = (_workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(long_segments, d))
+                      if long_segments > 0 else None)
+                _lib.call("sgf_spmm_stream" if stream_hint else "sgf_spmm_split", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), x.shape[0],
                           _ptr(y), y.stride(0), n_rows, d, _code(x), LONG_ROW, long_segments, _ptr(ws),
-                          ws.numel(), _stream(x.device))
+                          0 if ws is None else ws.numel(), _stream(x.device))
             else:
                 _lib.call("sgf_spmm", _ptr(rowptr), _ptr(colind), _ptr(val), _ptr(x), x.stride(0), x.shape[0],
                           _ptr(y), y.stride(0), n_rows, d, _code(x), _stream(x.device))
@@ -770,6 +772,7 @@ class GraphView:
         # on MI355X they beat the LDS-staged row blocks even at 76 % LDS-served entries (3.3 vs 4.1 ms at
         # ogbn-products scale, profiles/r02_spmm_structured.md); SGF_SPMM_BLOCKED=1 selects the row-block kernel.
         import os
+        g2.locality = True        # its gathers mostly hit in L2: ops.spmm_on picks sgf_spmm_stream
         g2.blocked = os.environ.get("SGF_SPMM_BLOCKED", "0") == "1"
         if not g2.blocked:
             g2._plans.clear()
@@ -872,6 +875,8 @@ def spmm_on(graph, x: torch.Tensor, transposed: bool, out=None) -> torch.Tensor:
     plan = graph.plan(x.dtype, transposed) if (getattr(graph, "blocked", False) and x.shape[1] <= 256) else None
     if plan is not None:
         return K.spmm_blocked(rp, plan, x, graph.n, out=out, long_segments=segs)
+    if getattr(graph, "locality", False):
+        return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs, stream_hint=True)
     return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs)
 
 

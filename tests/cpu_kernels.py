@@ -95,7 +95,7 @@ class CpuKernels:
 
     # ---- T2 ----
     @staticmethod
-    def spmm(rowptr, colind, val, x, n_rows, out=None, long_segments=0):
+    def spmm(rowptr, colind, val, x, n_rows, out=None, long_segments=0, stream_hint=False):
         y = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
         if n_rows > 0 and colind.numel() > 0:
             counts = (rowptr[1:] - rowptr[:-1])

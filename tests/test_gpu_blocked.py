@@ -230,3 +230,25 @@ def test_uniform_graph_keeps_the_plain_kernel(cuda):
     v2 = ops.prepare_graph(ei2, n)
     assert v2.perm is not None and v2.stats["lds_fraction"] > 0.5
     ops.graph_cache.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,d", [("community", 256), ("hub_dups_isolated", 256), ("directed", 136), ("uniform", 200),
+                                    ("community", 64)])
+def test_spmm_stream_vs_oracle(cuda, dtype, name, d):
+    """sgf_spmm_stream (flattened stream; bf16: two rows per 16-byte-per-lane load, k_spmm_seg_bf16x2) vs the
+    fp64 oracle SpMM of large/ours.py:34 — long rows, empty rows, odd row boundaries inside a pair included."""
+    from sgformer_amd import ops
+    ei = _graphs()[name]
+    n = 2500 if name == "hub_dups_isolated" else int(ei.max()) + 1
+    g = ops.CSRGraph(ei.to(cuda), n)
+    torch.manual_seed(2)
+    xs = torch.randn(n, d).to(dtype)
+    y = ops.K.spmm(g.rowptr, g.colind, g.val, xs.to(cuda), n, long_segments=g.long_segments, stream_hint=True)
+    rowptr, colind, val, _ = O.csr_build(ei.numpy(), n)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    ref = np.zeros((n, d))
+    np.add.at(ref, rows, val[:, None].astype(np.float64) * xs.double().numpy()[colind])
+    assert _rel(y.float(), torch.from_numpy(ref)) <= (1e-6 if dtype == torch.float32 else 3e-3)
+    y2 = ops.K.spmm(g.rowptr, g.colind, g.val, xs.to(cuda), n, long_segments=g.long_segments, stream_hint=True)
+    assert torch.equal(y, y2)                                # deterministic

@@ -198,24 +198,34 @@ __global__ __launch_bounds__(kThreads) void k_ln_bwd(
   }
 }
 
-// out[j] = sum_b part[b][j], j < width.  Fixed summation order (deterministic): 8 interleaved
-// partial chains per column (b = g, g+8, ...) combined in order g = 0..7 through LDS.
+// out[j] = sum_b part[b][j], j < width.  Fixed summation order (deterministic): 32 interleaved partial
+// chains per column (b = g, g+32, ...) combined in order g = 0..31 through LDS.  8 columns per block so that a
+// 512-wide statistics vector spreads over 64 CUs (16 blocks of 32 columns ran 64 us on 4 MiB of partials:
+// latency-bound; this is a per-BatchNorm-layer, per-LayerNorm kernel, 14 launches per step).
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nblk,
                                                       int width, float* __restrict__ out0,
                                                       float* __restrict__ out1, int split) {
   __shared__ float red[256];
-  const int c = threadIdx.x & 31;
-  const int g = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + c;
-  float s = 0.f;
-  if (j < width)
-    for (int b = g; b < nblk; b += 8) s += part[static_cast<int64_t>(b) * width + j];
-  red[threadIdx.x] = s;
+  const int c = threadIdx.x & 7;
+  const int g = threadIdx.x >> 3;
+  const int j = blockIdx.x * 8 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 independent loads in flight per thread
+  if (j < width) {
+    int b = g;
+    for (; b + 96 < nblk; b += 128) {
+      s0 += part[static_cast<int64_t>(b) * width + j];
+      s1 += part[static_cast<int64_t>(b + 32) * width + j];
+      s2 += part[static_cast<int64_t>(b + 64) * width + j];
+      s3 += part[static_cast<int64_t>(b + 96) * width + j];
+    }
+    for (; b < nblk; b += 32) s0 += part[static_cast<int64_t>(b) * width + j];
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && j < width) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k * 32 + c];
+    for (int k = 0; k < 32; ++k) t += red[k * 8 + c];
     if (j < split) {
       if (out0) out0[j] = t;
     } else {
@@ -773,7 +783,7 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const voi
                             static_cast<T*>(dx), lddx, static_cast<T*>(dres), lddres, part);
   if (rc != SGF_OK) return rc;
   if (gamma != nullptr && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, nblk,
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 7) / 8), dim3(256), 0, st, part, nblk,
                        2 * d, dgamma, dbeta, d);
     SGF_LAUNCH_CHECK();
   }
@@ -786,7 +796,7 @@ int colreduce(F f, int64_t n, int d, float* stats, void* ws, hipStream_t st) {
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL((k_colreduce<F>), dim3(nblk), dim3(kThreads), 0, st, f, n, d, part);
   SGF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, nblk, 2 * d,
+  hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 7) / 8), dim3(256), 0, st, part, nblk, 2 * d,
                      stats, stats + d, d);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -1137,7 +1147,7 @@ extern "C" int sgf_colsum(const void* x, int64_t ldx, int64_t n, int32_t d, int3
     hipLaunchKernelGGL((k_colsum_any<uint16_t>), dim3(nblk), dim3(kThreads), 0, st,
                        static_cast<const uint16_t*>(x), ldx, n, d, part);
   SGF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3((d + 31) / 32), dim3(256), 0, st, part, nblk, d, out,
+  hipLaunchKernelGGL(k_sum_partials, dim3((d + 7) / 8), dim3(256), 0, st, part, nblk, d, out,
                      static_cast<float*>(nullptr), d);
   SGF_LAUNCH_CHECK();
   return SGF_OK;

@@ -147,28 +147,39 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_bf16(
       float g[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) g[j] = k0 + j < c ? pg[k0 + j] : 0.f;   // rows of dlogits are C floats: unaligned
-      Frag fa;
-      fa.u.x = pack2(g[0], g[1]);
-      fa.u.y = pack2(g[2], g[3]);
-      fa.u.z = pack2(g[4], g[5]);
-      fa.u.w = pack2(g[6], g[7]);
+      Frag fb;
+      fb.u.x = pack2(g[0], g[1]);
+      fb.u.y = pack2(g[2], g[3]);
+      fb.u.z = pack2(g[4], g[5]);
+      fb.u.w = pack2(g[6], g[7]);
+      // TRANSPOSED product: D[feature][node] = W^T[feature][class] dlogits^T[class][node].  The W^T fragment is the
+      // A operand (lane: feature 32 t + i31, 8 classes), the dlogits fragment the B operand (lane: node i31, the
+      // same 8 classes), so in the result a lane holds 16 FEATURES of ITS node in four runs of 4 consecutive
+      // ones: 8-byte stores, 16 contiguous bytes per node row and instruction (a lane-per-feature result would
+      // store 2 bytes per lane)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (32 * t < d) {
-          const bf16x8 bt = *reinterpret_cast<const bf16x8*>(&wt[(32 * t + i31) * PITCH + k0]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bt, acc[t], 0, 0, 0);
+          const bf16x8 at = *reinterpret_cast<const bf16x8*>(&wt[(32 * t + i31) * PITCH + k0]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, fb.v, acc[t], 0, 0, 0);
         }
       }
     }
+    const int64_t orow = tile * 32 + i31;
+    if (orow < n) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (32 * t < d) {
+      for (int t = 0; t < NT; ++t) {
+        if (32 * t < d) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t orow = tile * 32 + mfma32_row(r, lane);
-          if (orow < n) {
-            dx1[orow * ld1 + 32 * t + i31] = f32_to_bf16(a * acc[t][r]);
-            dx2[orow * ld2 + 32 * t + i31] = f32_to_bf16(b * acc[t][r]);
+          for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * t + 8 * q + 4 * hi;          // C layout: row index = (r & 3) + 8 (r >> 2) + 4 hi
+            uint2 o1, o2;
+            o1.x = pack2(a * acc[t][4 * q + 0], a * acc[t][4 * q + 1]);
+            o1.y = pack2(a * acc[t][4 * q + 2], a * acc[t][4 * q + 3]);
+            o2.x = pack2(b * acc[t][4 * q + 0], b * acc[t][4 * q + 1]);
+            o2.y = pack2(b * acc[t][4 * q + 2], b * acc[t][4 * q + 3]);
+            *reinterpret_cast<uint2*>(dx1 + orow * ld1 + f0) = o1;
+            *reinterpret_cast<uint2*>(dx2 + orow * ld2 + f0) = o2;
           }
         }
       }
@@ -232,8 +243,9 @@ extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const floa
   int rc = check_head("sgf_combine_fc_bwd", n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
-  SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
-              "sgf_combine_fc_bwd: bad pointer / ld");
+  SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d && ld1 % 4 == 0 && ld2 % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(dx1) % 8 == 0 && reinterpret_cast<uintptr_t>(dx2) % 8 == 0,
+              SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 8-byte aligned, ld %% 4 == 0)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(head_grid(n)), block(kHeadThreads);
 #define SGF_HEAD_BWD(DP_)                                                                                   \

@@ -59,12 +59,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_spmm_pmc.json")
 
 
-def pmc_traffic(graph_kind: str, dtype: str, kernel: str):
+def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
     try:
         table = json.load(open(PMC_FILE))
     except (OSError, ValueError):
         return None, None
-    e = table.get(f"{graph_kind}/{dtype}/{kernel}")
+    e = table.get(f"{graph_kind}/{dtype}/{kernel}/{'reordered' if reordered else 'given'}")
     return (e["hbm_bytes_per_launch"], "profiles/r02_spmm_pmc.json") if e else (None, None)
 
 
@@ -312,7 +312,8 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     roof = timer.summary()
     if roof is not None and world == 1 and not args.nodes:
         kern = roof["kernel"].split(" ")[0]
-        roof["traffic"], src = pmc_traffic(f"{args.workload}:{graph_kind}", args.dtype, kern)
+        roof["traffic"], src = pmc_traffic(f"{args.workload}:{graph_kind}", args.dtype, kern,
+                                           bool(view_stats and view_stats.get("reordered")))
         if src:
             roof["traffic_source"] = src
     exchanged = None

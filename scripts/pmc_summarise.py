@@ -1,48 +1,90 @@
 #!/usr/bin/env python
-"""Summarise the rocprofv3 passes written by scripts/pmc_passes.sh: per kernel name, the mean of every
-counter over its dispatches and the mean duration from the kernel trace.  Prints a markdown table."""
-import csv
+"""Summarise the rocprofv3 passes written by scripts/pmc_passes.sh for scripts/spmm_pmc_target.py.
+
+Dispatches of one SpMM kernel are grouped by launch order (the target launches each variant `reps` times in a
+row), counters are averaged per group, durations come from the kernel-trace pass.  Prints a markdown table and,
+with --json, the entries of profiles/r02_spmm_pmc.json: HBM bytes per launch = 2 x FETCH_SIZE (KiB; the gfx950
+correction of MI355X_MICROARCH.md §HBM: wide coalesced reads are tallied at half their bytes) + WRITE_SIZE (KiB)."""
 import glob
+import json
 import os
 import sys
-from collections import defaultdict
+
+import pandas as pd
+
+LABELS = {"k_spmm_row": ["given node order", "sgf_reorder order"], "k_spmm_seg_bf16x2": ["sgf_reorder order"],
+          "k_spmm_blk": ["sgf_reorder order, LDS-staged row blocks"]}
 
 
-def short(name):
-    for key in ("k_spmm_blk", "k_spmm_wave", "k_spmm_sub", "k_spmm_long_seg", "k_spmm_long_fin"):
-        if key in name:
-            return key + ("<bf16>" if "It" in name.split(key)[1][:4] else "<f32>")
-    return None
+def groups(df):
+    out = {}
+    for k, sub in df.groupby("k"):
+        ids = sorted(sub.Dispatch_Id.unique())
+        grp, cur = [], [ids[0]]
+        for a, b in zip(ids, ids[1:]):
+            if b - a > 3:
+                grp.append(cur)
+                cur = [b]
+            else:
+                cur.append(b)
+        grp.append(cur)
+        for i, g in enumerate(grp):
+            lab = LABELS.get(k, [])
+            out[f"{k} [{lab[i] if i < len(lab) else i}]"] = (k, set(g))
+    return out
 
 
-def main(out):
-    counters = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> values
-    for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            k = short(row.get("Kernel_Name", ""))
-            if k:
-                # LDS size distinguishes block shapes of the row-block kernel
-                k = f"{k} lds={row.get('LDS_Block_Size', '?')}" if "blk" in k else k
-                counters[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    dur = defaultdict(list)
-    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            k = short(row.get("Kernel_Name", ""))
-            if k:
-                k = f"{k} lds={row.get('LDS_Block_Size', '?')}" if "blk" in k else k
-                dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
-    names = sorted({c for k in counters for c in counters[k]})
-    print("| kernel | launches | mean ms | " + " | ".join(names) + " |")
-    print("|---|---:|---:|" + "---:|" * len(names))
-    for k in sorted(set(counters) | set(dur)):
-        d = dur.get(k, [])
-        cells = []
-        for c in names:
-            v = counters[k].get(c, [])
-            cells.append(f"{sum(v) / len(v):.4g}" if v else "")
-        print(f"| {k} | {len(d)} | {sum(d) / len(d):.3f} | " + " | ".join(cells) + " |" if d else
-              f"| {k} | 0 | | " + " | ".join(cells) + " |")
+def main(out, as_json=None, key_prefix=""):
+    frames = [pd.read_csv(f) for f in glob.glob(os.path.join(out, "p*", "*counter_collection.csv"))]
+    df = pd.concat(frames)
+    df = df[df.Kernel_Name.str.contains("k_spmm")]
+    df["k"] = df.Kernel_Name.str.extract(r"(k_spmm_[a-z0-9_]+?)(?:I|<)")[0]
+    # every pass re-runs the program: dispatch ids repeat, so group inside ONE pass and reuse the id sets
+    first = frames[0]
+    first = first[first.Kernel_Name.str.contains("k_spmm")].copy()
+    first["k"] = first.Kernel_Name.str.extract(r"(k_spmm_[a-z0-9_]+?)(?:I|<)")[0]
+    gs = groups(first)
+    rows = {}
+    for name, (k, ids) in gs.items():
+        sub = df[(df.k == k) & df.Dispatch_Id.isin(ids)]
+        rows[name] = sub.groupby("Counter_Name").Counter_Value.mean()
+    t = pd.concat([pd.read_csv(f) for f in glob.glob(os.path.join(out, "trace", "*kernel_trace.csv"))])
+    t = t[t.Kernel_Name.str.contains("k_spmm")].copy()
+    t["k"] = t.Kernel_Name.str.extract(r"(k_spmm_[a-z0-9_]+?)(?:I|<)")[0]
+    t["ms"] = (t.End_Timestamp - t.Start_Timestamp) / 1e6
+    tg = {}
+    for k, sub in t.groupby("k"):
+        sub = sub.sort_values("Start_Timestamp")
+        ms = sub.ms.tolist()
+        names = [n for n in gs if gs[n][0] == k]
+        per = max(1, len(ms) // max(1, len(names)))
+        for i, n in enumerate(names):
+            chunk = ms[i * per:(i + 1) * per]
+            tg[n] = sum(chunk) / max(1, len(chunk))
+    res = pd.DataFrame(rows)
+    res.loc["launch_ms (kernel trace)"] = pd.Series(tg)
+    if "FETCH_SIZE" in res.index:
+        res.loc["HBM_read_GB (2 x FETCH_SIZE)"] = 2 * res.loc["FETCH_SIZE"] * 1024 / 1e9
+        res.loc["HBM_write_GB (WRITE_SIZE)"] = res.loc["WRITE_SIZE"] * 1024 / 1e9
+    if "TCC_HIT_sum" in res.index:
+        res.loc["L2_hit_rate"] = res.loc["TCC_HIT_sum"] / (res.loc["TCC_HIT_sum"] + res.loc["TCC_MISS_sum"])
+    print(res.to_markdown(floatfmt=".4g"))
+    if as_json:
+        table = {}
+        if os.path.exists(as_json):
+            table = json.load(open(as_json))
+        for n in rows:
+            if "HBM_read_GB (2 x FETCH_SIZE)" in res.index:
+                k = gs[n][0]
+                tag = "reordered" if "sgf_reorder" in n else "given"
+                table[f"{key_prefix}/{k}/{tag}"] = {
+                    "hbm_bytes_per_launch": float((res.loc["HBM_read_GB (2 x FETCH_SIZE)", n] +
+                                                   res.loc["HBM_write_GB (WRITE_SIZE)", n]) * 1e9),
+                    "fetch_size_kib": float(res.loc["FETCH_SIZE", n]), "write_size_kib": float(res.loc["WRITE_SIZE", n]),
+                    "l2_hit_rate": float(res.loc["L2_hit_rate", n]) if "L2_hit_rate" in res.index else None,
+                    "launch_ms": float(tg.get(n, float("nan")))}
+        json.dump(table, open(as_json, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else "")

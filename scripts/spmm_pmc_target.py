@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--deg", type=float, default=50.5)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--shapes", default="128x288,64x144")
+    ap.add_argument("--shapes", default="128x288")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -34,7 +34,11 @@ def main():
     n = a.n
     x = torch.randn(n, a.d, device=dev).to(dtype)
     g = ops.CSRGraph(ei, n, validate=False)
-    for _ in range(a.reps):
+    # phase markers in the kernel trace: a tiny named fill between the groups of launches
+    def mark(k):
+        torch.full((k,), 1.0, device=dev)
+    mark(1)
+    for _ in range(a.reps):          # group 0: given node order, row kernel (sgf_spmm)
         ops.K.spmm(g.rowptr, g.colind, g.val, x, n, long_segments=g.long_segments)
     if a.graph == "community":
         perm, inv, _ = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
@@ -42,12 +46,16 @@ def main():
         del ei
         xp = ops.gather_rows(x, perm)
         torch.cuda.synchronize()
-        for _ in range(a.reps):
+        for _ in range(a.reps):      # group 1: sgf_reorder order, row kernel
             ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments)
+        for _ in range(a.reps):      # group 2: sgf_reorder order, stream kernel (sgf_spmm_stream)
+            ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments, stream_hint=True)
         for shape in a.shapes.split(","):
+            if not shape:
+                continue
             r, c = (int(t) for t in shape.split("x"))
             plan = ops.BlockedPlan(g2.rowptr, g2.colind, g2.val, n, dtype, rows_per_block=r, lds_rows=c)
-            for _ in range(a.reps):
+            for _ in range(a.reps):  # group 3+: LDS-staged row blocks
                 ops.K.spmm_blocked(g2.rowptr, plan, xp, n, long_segments=g2.long_segments)
             del plan
     torch.cuda.synchronize()

@@ -612,6 +612,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_seg_bf16x2(
   boundary(total);   // closes the last non-empty row and any trailing empty rows
 }
 
+// Tried and dropped (r02): a second version of this kernel that parks the stream's {code, value} pairs in a per-wave
+// LDS window (one coalesced load per 64 entries, one ds_read_b64 + one v_mad_u32_u24 per pair, no row-end test inside
+// 16-entry groups).  Bit-identical results, a much shorter front end — and 3.38 ms against 3.28 ms for the kernel above
+// on the same box (community graph, sgf_reorder order).  The kernel is not bound by its instruction count but by the
+// gathers themselves: scripts/l2_gather_probe.hip puts the ceiling for 512-byte rows that HIT in L2 at 25-27 TB/s
+// (16 B per lane; 14.7 TB/s at 8 B per lane), this launch moves 58 GB of rows with a 70 % L2 hit rate, the rest at the
+// 7-8 TB/s fabric rate.
+
 // LPR lanes per row (power of two, < 64); 64/LPR rows per wave.  d <= 4*LPR.
 template <typename T, int LPR, int UNROLL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_sub(
@@ -1004,7 +1012,7 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
                          reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
     const int chunk = 4096 / (kWavesPerBlock * kSegRows);   // one XCD walks ~4096 consecutive rows at a time
-    if (fits32 && pair_ok && ((stream && fk.empty()) || fk == "seg2"))
+    if (fits32 && pair_ok && (stream || fk == "seg2"))
       hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
                          reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
                          static_cast<uint32_t>(x_bytes), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d, chunk, lq);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 200 /* 0.2.0 */
+#define SGF_VERSION 210 /* 0.2.1 */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -396,6 +396,32 @@ int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int
 int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
                        int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2,
                        int64_t ld2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T6 / K8 — the dense half of a GCN layer as one streaming pass.   Replaces, for large/ours.py:36-40,87-88
+ *     x = self.W(gcn_conv(...));  x = self.bns[i](x)        (the Linear and BatchNorm1d's batch statistics)
+ *   sgf_gcn_epilogue_stats : y[n, d_out] = a[n, d_in] W^T + bias, W [d_out, d_in] row-major in the storage
+ *                            dtype, bias fp32 or null; fp32 accumulation on the matrix cores, y rounded to the
+ *                            storage dtype.  With stats != null also, in the same pass,
+ *                              stats[j] = sum_i (y_ij - shift_j),  stats[d_out + j] = sum_i (y_ij - shift_j)^2
+ *                            of the ROUNDED y (what sgf_colstats(y, shift) returns, without re-reading y);
+ *                            shift fp32 [d_out] or null.  workspace: sgf_gcn_epilogue_workspace_bytes (only
+ *                            used with stats).  The normalise / ReLU / dropout / residual half of the layer
+ *                            is sgf_bn_apply (+ sgf_dropout_*).
+ *   sgf_gcn_epilogue_dx    : dx[n, d_in] = dy[n, d_out] W   (the Linear's input gradient; dW, db: sgf_gram).
+ * W stays resident in LDS (one 8-wave block per CU), every wave streams 32-row tiles on its own; see
+ * csrc/rowgemm.hip.  Implemented for bf16 storage and d_in == d_out in {64, 128, 256}
+ * (sgf_gcn_epilogue_supported); rows of a / y / dy / dx / W must be 16-byte aligned.  Anything else: a
+ * library GEMM + sgf_colstats.
+ * ------------------------------------------------------------------------------------------ */
+int32_t sgf_gcn_epilogue_supported(int32_t d_in, int32_t d_out, int32_t dtype);
+size_t sgf_gcn_epilogue_workspace_bytes(int64_t n, int32_t d_out);
+int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                           int64_t n, int32_t d_in, int32_t d_out, int32_t dtype, void* y, int64_t ldy,
+                           const float* shift, float* stats, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw, int64_t n, int32_t d_in,
+                        int32_t d_out, int32_t dtype, void* dx, int64_t lddx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T7 — branch combine alone.   large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.

@@ -97,6 +97,11 @@ SIGNATURES = {
                                      c_int32, _P, c_int64, _P]),
     "sgf_combine_fc_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P,
                                      c_int64, _P, c_int64, _P]),
+    "sgf_gcn_epilogue_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "sgf_gcn_epilogue_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "sgf_gcn_epilogue_stats": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, _P, c_int64,
+                                         _P, _P, _P, c_size_t, _P]),
+    "sgf_gcn_epilogue_dx": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
                             c_int64, _P]),
 }

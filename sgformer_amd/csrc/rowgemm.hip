@@ -1,0 +1,356 @@
+// rowgemm.hip — K8: the GCN layer's dense half as ONE streaming pass.
+//
+// Reference (large/ours.py:36-40, 87-93):   x = gcn_conv(...)            # SpMM, csrc/spmm.hip
+//                                           x = self.W(x)                # Linear d -> d        <- here
+//                                           x = self.bns[i](x)           # needs column mean / var of THAT   <- Σ, Σ² here
+//                                           x = relu(x); x = x + layer_[i]        # sgf_bn_apply
+//
+//   sgf_gcn_epilogue_stats : y = a W^T + b (bf16 out, fp32 accumulate) and, in the same pass, the shifted column sums
+//                            Σ_i (y_ij - shift_j), Σ_i (y_ij - shift_j)² that BatchNorm needs (of the ROUNDED y, the
+//                            tensor sgf_bn_apply normalises afterwards) — one read of a, one write of y, nothing else.
+//   sgf_gcn_epilogue_dx    : dx = dy W, the same kernel with W loaded transposed.
+//
+// Replaces hipBLASLt's [N, d] x [d, d] GEMM (0.61-0.63 ms at N = 2.45 M, d = 256: 4.0 TB/s of the 2.5 GB it must move)
+// plus the separate sgf_colstats pass over y (0.33 ms).  Shape of the problem: 2 N d² flop = 0.13 ms of bf16 MFMA
+// against 0.40 ms of HBM time — a copy with a matrix product attached, so the kernel is organised as a copy:
+//
+//   * W (d x d bf16 = 128 KiB) is loaded ONCE per block into LDS, laid out so that a matrix-core B fragment
+//     (8 consecutive k of one output column) is one conflict-free ds_read_b128.  One 8-wave block per CU, persistent.
+//   * every wave works ALONE on 32-row tiles — no block barrier after the W fill.  It loads its tile straight into
+//     MFMA A-fragment registers (lane l: row l & 31, 16 bytes at k = 16 s + 8 (l >> 5); four consecutive loads cover
+//     the same 128-byte lines), and requests the NEXT tile before computing the current one: 8 waves x 16 KiB x 2 in
+//     flight per CU.
+//   * per 32-column strip: 16 x v_mfma_f32_32x32x16_bf16; the accumulator layout (lane = output column, registers =
+//     16 rows) makes the column statistics register-local adds; bias add, rounding, then the strip goes through a
+//     2.5 KiB per-wave LDS patch to come back row-major for 64-byte-per-row coalesced stores.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace sgf {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRgWaves = 8;
+constexpr int kRgThreads = kRgWaves * 64;
+constexpr int kStageStride = 144;                      // bytes per staged row (64 bf16 + pad: the two half-waves' rows
+                                                       // land 16 banks apart)
+constexpr int kStageBytes = 16 * kStageStride;         // per wave: 16 rows x two column strips
+
+struct RowGemmArgs {
+  const uint16_t* a; int64_t lda;
+  const uint16_t* w; int64_t ldw; int trans;           // trans = 0: B^T[j][k] = w[j ldw + k];  1: = w[k ldw + j]
+  const float* bias;                                   // [d_out] or null
+  const float* shift;                                  // [d_out] or null (statistics only)
+  float* part;                                         // [gridDim.x][2][d_out] statistics partials, or null
+  uint16_t* y; int64_t ldy;
+  int64_t n;
+};
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  const f32x2 v = {lo, hi};
+  const bf16x2 b = __builtin_convertvector(v, bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
+
+// Writes of one lane read back by another lane of the same wave: LDS executes a wave's instructions in order, the
+// compiler only has to be kept from re-ordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// D = d_in = d_out (64 / 128 / 256); KS = D / 16 k-steps, NS = D / 32 column strips, processed in pairs so that a row
+// leaves in 128-byte pieces (full cache lines: 64-byte pieces measured 0.71 ms against 0.55 ms at N = 2.45 M).
+template <int D, bool STATS, int DBG = 0>   // DBG: timing ablations only (SGF_ROWGEMM_DEBUG): 2 no stores, 4 no re-loads
+__global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
+  constexpr int KS = D / 16, NS = D / 32;
+  constexpr int BT = D * 2 + 16;                       // bytes per row of B^T in LDS (16-byte slots rotate by one per row)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[D * BT + kRgWaves * kStageBytes + 2 * D * 4];
+  unsigned char* const ldsB = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const stg = lds + D * BT + wave * kStageBytes;
+  float* const cvec = reinterpret_cast<float*>(lds + D * BT + kRgWaves * kStageBytes);   // [bias | shift]
+
+  // ---- W -> LDS, once ----
+  if (!p.trans) {
+    constexpr int CH = D / 8;                          // 16-byte chunks per row
+    for (int c = tid; c < D * CH; c += kRgThreads) {
+      const int j = c / CH, q = c % CH;
+      *reinterpret_cast<uint4*>(ldsB + j * BT + 16 * q) = *reinterpret_cast<const uint4*>(p.w + j * p.ldw + 8 * q);
+    }
+  } else {
+    constexpr int CH = D / 8;
+    for (int c = tid; c < D * CH; c += kRgThreads) {
+      const int k = c / CH, q = c % CH;                // 8 output columns j = 8 q .. 8 q + 7 of contraction index k
+      const uint4 v = *reinterpret_cast<const uint4*>(p.w + k * p.ldw + 8 * q);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<uint16_t*>(ldsB + (8 * q + t) * BT + 2 * k) =
+            static_cast<uint16_t>(t & 1 ? u[t >> 1] >> 16 : u[t >> 1] & 0xffffu);
+    }
+  }
+  for (int c = tid; c < D; c += kRgThreads) {
+    cvec[c] = p.bias ? p.bias[c] : 0.f;
+    cvec[D + c] = (STATS && p.shift) ? p.shift[c] : 0.f;
+  }
+  __syncthreads();
+
+  float s1[NS], s2[NS];
+#pragma unroll
+  for (int w = 0; w < NS; ++w) {
+    s1[w] = 0.f;
+    s2[w] = 0.f;
+  }
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kRgWaves;
+  auto load_tile = [&](int64_t t, bf16x8 (&dst)[KS]) {
+    int64_t row = t * 32 + i31;
+    if (row >= p.n) row = p.n - 1;                     // ragged end: any valid row; its results are masked
+    const uint16_t* src = p.a + row * p.lda + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+  };
+
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  // staging patch: 16 rows x 64 columns (two strips).  write: value (row, column 32 c + i31) at
+  // row * stride + 64 c + 2 i31.  read back: lane -> row lane >> 3 (+8), 16-byte chunk lane & 7.
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+
+  bf16x8 cur[KS], nxt[KS];
+  int64_t t = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+  if (t < ntiles) load_tile(t, cur);
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    if (tn < ntiles && !(DBG & 4)) load_tile(tn, nxt);
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    uint16_t* const yrow = p.y + (row0 + (lane >> 3)) * p.ldy + 8 * (lane & 7);
+#pragma unroll
+    for (int u = 0; u < NS / 2; ++u) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[0][r] = 0.f;
+        acc[1][r] = 0.f;
+      }
+      const unsigned char* const bu = bfrag0 + 64 * u * BT;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bu + 32 * s);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bu + 32 * BT + 32 * s);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b1, acc[1], 0, 0, 0);
+      }
+      // accumulator register r of lane (i31, hi): row (r & 3) + 8 (r >> 2) + 4 hi, column 32 w + i31.
+      // Rows 0-15 are registers 0-7, rows 16-31 registers 8-15: two passes through the 16-row patch.
+      float bias_c[2], shift_c[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bias_c[c] = cvec[32 * (2 * u + c) + i31];
+        shift_c[c] = STATS ? cvec[D + 32 * (2 * u + c) + i31] : 0.f;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        uint32_t pk[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+            const uint32_t v = cvt_pk_bf16(acc[c][r] + bias_c[c], acc[c][r + 1] + bias_c[c]);
+            const int rl = (r & 3) + 8 * ((r >> 2) & 1);                 // row inside the patch (+ 4 hi in st_w)
+            *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+            pk[c][(r >> 1) & 3] = v;
+          }
+        }
+        if (STATS) {
+          if (!tail) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float v0 = __uint_as_float(pk[c][q] << 16) - shift_c[c];
+                const float v1 = __uint_as_float(pk[c][q] & 0xffff0000u) - shift_c[c];
+                s1[2 * u + c] += v0 + v1;
+                s2[2 * u + c] = fmaf(v0, v0, fmaf(v1, v1, s2[2 * u + c]));
+              }
+          } else {                                     // the one ragged tile of the launch: rows >= n do not count
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int64_t ra = row0 + 16 * hh + ((2 * q) & 3) + 8 * (q >> 1) + 4 * hi;
+                const float v0 = ra < p.n ? __uint_as_float(pk[c][q] << 16) - shift_c[c] : 0.f;
+                const float v1 = ra + 1 < p.n ? __uint_as_float(pk[c][q] & 0xffff0000u) - shift_c[c] : 0.f;
+                s1[2 * u + c] += v0 + v1;
+                s2[2 * u + c] = fmaf(v0, v0, fmaf(v1, v1, s2[2 * u + c]));
+              }
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          if ((!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n) && !(DBG & 2))
+            *reinterpret_cast<uint4*>(yrow + (16 * hh + 8 * q) * p.ldy + 64 * u) = v;
+        }
+        wave_lds_sync();
+      }
+    }
+    if (!(DBG & 4)) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+    }
+  }
+
+  if (STATS) {
+    // hi = 0 / 1 hold the same columns, different rows; then the 8 waves of the block
+    __syncthreads();                                   // every wave is done with its staging patch
+    static_assert(kRgWaves * 2 * D * 4 <= kRgWaves * kStageBytes, "reduction scratch must fit the staging patches");
+    float* const redb = reinterpret_cast<float*>(lds + D * BT);   // [wave][2][D]
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      const float a1s = s1[w] + __shfl_xor(s1[w], 32, 64);
+      const float a2s = s2[w] + __shfl_xor(s2[w], 32, 64);
+      if (hi == 0) {
+        redb[(wave * 2 + 0) * D + 32 * w + i31] = a1s;
+        redb[(wave * 2 + 1) * D + 32 * w + i31] = a2s;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * D; c += kRgThreads) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < kRgWaves; ++v) s += redb[v * 2 * D + c];
+      p.part[static_cast<int64_t>(blockIdx.x) * 2 * D + c] = s;
+    }
+  }
+}
+
+// stats[c] = Σ_blocks part[b][c], fixed order (deterministic).  One block per 64 entries, 4 block-groups per entry.
+__global__ __launch_bounds__(256) void k_rowgemm_stats(const float* __restrict__ part, int nblk, int len,
+                                                       float* __restrict__ stats) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < len)
+    for (int b = g; b < nblk; b += 4) s += part[static_cast<int64_t>(b) * len + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && c < len) stats[c] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+}
+
+int grid_blocks(int64_t n) {
+  const int64_t tiles = (n + 31) / 32;
+  int64_t b = (tiles + kRgWaves - 1) / kRgWaves;
+  if (b > kNumCU) b = kNumCU;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+template <bool STATS>
+int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
+  switch (d) {
+    case 64: hipLaunchKernelGGL((k_rowgemm_bf16<64, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((k_rowgemm_bf16<128, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 256: {
+      const char* e = getenv("SGF_ROWGEMM_DEBUG");
+      const int dbg = e ? atoi(e) : 0;
+      switch (dbg) {
+#define SGF_RG_DBG(X) case X: hipLaunchKernelGGL((k_rowgemm_bf16<256, false, X>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+        SGF_RG_DBG(2) SGF_RG_DBG(4) SGF_RG_DBG(6)
+#undef SGF_RG_DBG
+        default: hipLaunchKernelGGL((k_rowgemm_bf16<256, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+      }
+      break;
+    }
+    default: set_error("sgf_gcn_epilogue: width %d not in {64, 128, 256}", d); return SGF_E_UNSUPPORTED;
+  }
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+bool supported(int32_t d_in, int32_t d_out, int32_t dtype) {
+  return dtype == SGF_BF16 && d_in == d_out && (d_in == 64 || d_in == 128 || d_in == 256);
+}
+
+int check_common(const char* who, const void* a, int64_t lda, const void* w, int64_t ldw, int64_t n, int32_t d_in,
+                 int32_t d_out, int32_t dtype, const void* y, int64_t ldy) {
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", who);
+  SGF_REQUIRE(supported(d_in, d_out, dtype), SGF_E_UNSUPPORTED,
+              "%s: only bf16 storage with d_in == d_out in {64, 128, 256} (got %d -> %d, dtype %d)", who, d_in, d_out,
+              dtype);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(a && w && y, SGF_E_INVALID, "%s: null pointer", who);
+  SGF_REQUIRE(lda >= d_in && ldy >= d_out && ldw >= (d_in > d_out ? d_in : d_out), SGF_E_INVALID,
+              "%s: leading dimension smaller than the width", who);
+  SGF_REQUIRE(lda % 8 == 0 && ldy % 8 == 0 && ldw % 8 == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(w) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0,
+              SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers % 16, leading dims % 8 elements)", who);
+  return SGF_OK;
+}
+
+}  // namespace
+}  // namespace sgf
+
+using namespace sgf;
+
+extern "C" int32_t sgf_gcn_epilogue_supported(int32_t d_in, int32_t d_out, int32_t dtype) {
+  return supported(d_in, d_out, dtype) ? 1 : 0;
+}
+
+extern "C" size_t sgf_gcn_epilogue_workspace_bytes(int64_t n, int32_t d_out) {
+  if (n < 0 || d_out <= 0) return 0;
+  return static_cast<size_t>(grid_blocks(n)) * 2 * static_cast<size_t>(d_out) * sizeof(float);
+}
+
+extern "C" int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                                      int64_t n, int32_t d_in, int32_t d_out, int32_t dtype, void* y, int64_t ldy,
+                                      const float* shift, float* stats, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  int rc = check_common("sgf_gcn_epilogue_stats", a, lda, w, ldw, n, d_in, d_out, dtype, y, ldy);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (stats) SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * static_cast<size_t>(d_out) * sizeof(float), st));
+    return SGF_OK;
+  }
+  const int blocks = grid_blocks(n);
+  RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, bias, shift,
+                   nullptr, static_cast<uint16_t*>(y), ldy, n};
+  if (!stats) return launch_rowgemm<false>(args, d_out, blocks, st);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
+              "sgf_gcn_epilogue_stats: workspace %zu < %zu", workspace_bytes, sgf_gcn_epilogue_workspace_bytes(n, d_out));
+  args.part = static_cast<float*>(workspace);
+  rc = launch_rowgemm<true>(args, d_out, blocks, st);
+  if (rc != SGF_OK) return rc;
+  hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, args.part, blocks, 2 * d_out,
+                     stats);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw, int64_t n, int32_t d_in,
+                                   int32_t d_out, int32_t dtype, void* dx, int64_t lddx, void* stream) {
+  // dx [n, d_in] = dy [n, d_out] W [d_out, d_in]: contraction over W's rows
+  int rc = check_common("sgf_gcn_epilogue_dx", dy, lddy, w, ldw, n, d_out, d_in, dtype, dx, lddx);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  RowGemmArgs args{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(w), ldw, 1, nullptr, nullptr,
+                   nullptr, static_cast<uint16_t*>(dx), lddx, n};
+  return launch_rowgemm<false>(args, d_in, grid_blocks(n), static_cast<hipStream_t>(stream));
+}

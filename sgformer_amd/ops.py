@@ -514,6 +514,39 @@ class HipKernels:
                       dx2.stride(0), _stream(g.device))
         return dx1, dx2
 
+    # ---- T6 / K8: Linear (+ BatchNorm statistics) as one streaming pass ----
+    @staticmethod
+    def gcn_epilogue_supported(d_in: int, d_out: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_gcn_epilogue_supported(d_in, d_out, _lib.SGF_BF16))
+
+    @staticmethod
+    def gcn_epilogue_stats(a, w, bias, shift=None, want_stats=False):
+        """y = a w^T + bias; with want_stats also [sum(y - shift) | sum((y - shift)^2)] per column of the
+        rounded y.  w in a's dtype [d_out, d_in], bias / shift fp32."""
+        n, d_in = a.shape
+        d_out = w.shape[0]
+        dev = a.device
+        y = torch.empty((n, d_out), dtype=a.dtype, device=dev)
+        stats = torch.empty(2 * d_out, dtype=_F32, device=dev) if want_stats else None
+        lib = _lib.load()
+        ws = _workspace(dev, "gcn_epi", lib.sgf_gcn_epilogue_workspace_bytes(n, d_out)) if want_stats else None
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gcn_epilogue_stats", _ptr(a), _ld(a), _ptr(w), w.stride(0), _ptr(bias), n, d_in, d_out,
+                      _code(a), _ptr(y), _ld(y), _ptr(shift), _ptr(stats), _ptr(ws),
+                      0 if ws is None else ws.numel(), _stream(dev))
+        return y, stats
+
+    @staticmethod
+    def gcn_epilogue_dx(dy, w):
+        """dx = dy w  (w [d_out, d_in] in dy's dtype; may be a column slice of a wider matrix)."""
+        n, d_out = dy.shape
+        d_in = w.shape[1]
+        dx = torch.empty((n, d_in), dtype=dy.dtype, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.call("sgf_gcn_epilogue_dx", _ptr(dy), _ld(dy), _ptr(w), w.stride(0), n, d_in, d_out, _code(dy),
+                      _ptr(dx), _ld(dx), _stream(dy.device))
+        return dx
+
     # ---- T7 ----
     @staticmethod
     def axpby(x1, a: float, x2, b: float) -> torch.Tensor:
@@ -1358,7 +1391,7 @@ class _Linear(torch.autograd.Function):
     without materialising the concatenation)."""
 
     @staticmethod
-    def forward(ctx, w, b, *xs):
+    def forward(ctx, w, b, stats_req, *xs):
         K.check(*xs)
         dt = xs[0].dtype
         wc = w if w.dtype == dt else w.to(dt)
@@ -1366,7 +1399,17 @@ class _Linear(torch.autograd.Function):
         widths = [x.shape[1] for x in xs]
         if sum(widths) != w.shape[1]:
             raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
-        if len(xs) == 1:
+        fused = len(xs) == 1 and _streaming_linear_ok(xs[0], wc)
+        if fused:
+            # one streaming pass with W resident in LDS (sgf_gcn_epilogue_stats); the BatchNorm that follows
+            # gets its column sums from the same pass
+            x0 = _rows16(xs[0])
+            b32 = None if b is None else b.detach().float().contiguous()
+            if stats_req is not None:
+                y = _linear_with_stats(x0, wc, b32, stats_req)
+            else:
+                y, _ = K.gcn_epilogue_stats(x0, wc, b32)
+        elif len(xs) == 1:
             y = torch.nn.functional.linear(xs[0], wc, bc)
         else:
             # first operand with the bias, the rest accumulated IN PLACE (torch.addmm(y, ...) out of
@@ -1376,6 +1419,8 @@ class _Linear(torch.autograd.Function):
             for x, k in zip(xs[1:], widths[1:]):
                 y.addmm_(x, wc[:, off:off + k].t())
                 off += k
+        if stats_req is not None and not fused:
+            stats_req["out"] = batch_stats(y, stats_req.get("shard"))
         ctx.save_for_backward(wc, *xs)
         ctx.meta = (w.dtype, None if b is None else b.dtype, widths)
         return y
@@ -1388,7 +1433,12 @@ class _Linear(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and bdtype is not None
         dxs, off = [], 0
         for i, k in enumerate(widths):
-            dxs.append(g @ wc[:, off:off + k] if ctx.needs_input_grad[2 + i] else None)
+            if not ctx.needs_input_grad[3 + i]:
+                dxs.append(None)
+            elif len(widths) == 1 and _streaming_linear_ok(g, wc):
+                dxs.append(K.gcn_epilogue_dx(_rows16(g), wc))
+            else:
+                dxs.append(g @ wc[:, off:off + k])
             off += k
         dw = db = None
         if need_w or need_b:
@@ -1413,18 +1463,61 @@ class _Linear(torch.autograd.Function):
                 off += k
             dw = dw[:m].to(wdtype) if need_w else None
             db = db[:m].to(bdtype) if need_b else None
-        return (dw, db, *dxs)
+        return (dw, db, None, *dxs)
+
+
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """Rows contiguous and 16-byte aligned (what the streaming row-GEMM loads as matrix-core fragments)."""
+    if t.stride(-1) != 1 or (t.stride(0) * t.element_size()) % 16 != 0 or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t
+
+
+def _streaming_linear_ok(x: torch.Tensor, wc: torch.Tensor) -> bool:
+    return (x.dim() == 2 and x.shape[0] > 0 and wc.stride(-1) == 1 and (wc.stride(0) * wc.element_size()) % 16 == 0
+            and wc.data_ptr() % 16 == 0 and K.gcn_epilogue_supported(wc.shape[1], wc.shape[0], x.dtype))
+
+
+def _linear_with_stats(x, wc, b32, stats_req):
+    """y = x wc^T + b32 AND BatchNorm's batch statistics of y, from the same pass (sgf_gcn_epilogue_stats).
+    Same shifted sums as batch_stats: the shift is the column mean of the first rows of y, which a small launch
+    over those rows provides."""
+    shard = stats_req.get("shard")
+    n, d = x.shape[0], wc.shape[0]
+    ns = min(n, _BN_SAMPLE_ROWS)
+    _, st_s = K.gcn_epilogue_stats(x[:ns], wc, b32, None, want_stats=True)
+    samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
+    n_tot = float(n)
+    if shard is not None:
+        shard.all_reduce(samp)
+        n_tot = float(shard.n_global)
+    shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
+    y, st = K.gcn_epilogue_stats(x, wc, b32, shift, want_stats=True)
+    if shard is not None:
+        shard.all_reduce(st)
+    m1 = st[:d] / max(n_tot, 1.0)
+    stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
+    return y
 
 
 def linear(x, w, b):
-    """nn.Linear forward on hipBLASLt, weight / bias gradients on sgf_gram."""
-    return _Linear.apply(w, b, x)
+    """nn.Linear: square bf16 layers on the streaming row-GEMM (sgf_gcn_epilogue_stats / _dx), the rest
+    on hipBLASLt; weight / bias gradients on sgf_gram."""
+    return _Linear.apply(w, b, None, x)
+
+
+def linear_bn_stats(x, w, b, shard=None):
+    """(y, (mean, var, n_tot)): nn.Linear and the batch statistics BatchNorm1d needs of its output
+    (large/ours.py:36-40 followed by :87-88) — one pass when the layer is square bf16, else linear + batch_stats."""
+    req = {"shard": shard, "out": None}
+    y = _Linear.apply(w, b, req, x)
+    return y, req["out"]
 
 
 def linear_cat(xs, w, b):
     """[x_1 | x_2 | ...] W^T + b without the concatenation (GraphConvLayer with use_init)."""
-    return _Linear.apply(w, b, *xs)
+    return _Linear.apply(w, b, None, *xs)
 
 
 def out_linear(x, w, b):
-    return _Linear.apply(w, b, x)
+    return _Linear.apply(w, b, None, x)

@@ -126,6 +126,11 @@ def _attention_matrix(qs, ks):
     return attention / normalizer
 
 
+def _uses_batch_stats(module: nn.Module, bn: nn.BatchNorm1d) -> bool:
+    """nn.BatchNorm1d's rule for normalising with batch (not running) statistics."""
+    return module.training or not bn.track_running_stats or bn.running_mean is None
+
+
 class GraphConvLayer(nn.Module):
     """A_norm X -> [cat x0] -> Linear   (large/ours.py:10-42)."""
 
@@ -140,7 +145,10 @@ class GraphConvLayer(nn.Module):
     def reset_parameters(self):
         self.W.reset_parameters()
 
-    def forward(self, x, edge_index, x0):
+    def forward(self, x, edge_index, x0, bn_stats=False):
+        """`bn_stats` (not in the reference signature): also return the batch statistics (mean, var, count) of
+        the output, which the Linear's streaming pass accumulates for the BatchNorm that follows — (y, stats);
+        stats is None when this layer has nothing to fuse them into."""
         shard = self._shard
         if isinstance(edge_index, ops.CSRGraph):   # SGFormer.forward resolved (and maybe re-ordered) it already
             graph = edge_index
@@ -153,8 +161,10 @@ class GraphConvLayer(nn.Module):
             # W [y | x0] + b without materialising the concatenation
             y = ops.linear_cat((y, x0), self.W.weight, self.W.bias)
         elif self.use_weight:
+            if bn_stats:
+                return ops.linear_bn_stats(y, self.W.weight, self.W.bias, shard)
             y = _lin(y, self.W)
-        return y
+        return (y, None) if bn_stats else y
 
 
 class GraphConv(nn.Module):
@@ -187,12 +197,13 @@ class GraphConv(nn.Module):
         for fc in self.fcs:
             fc.reset_parameters()
 
-    def _bn_act_res(self, bn: nn.BatchNorm1d, x, res, relu):
-        """[relu](BatchNorm1d(x)) [+ res] with nn.BatchNorm1d's train/eval + running-stat rules."""
+    def _bn_act_res(self, bn: nn.BatchNorm1d, x, res, relu, stats=None):
+        """[relu](BatchNorm1d(x)) [+ res] with nn.BatchNorm1d's train/eval + running-stat rules.
+        `stats`: (mean, var, count) of x if its producer already accumulated them."""
         shard = self._shard
-        use_batch = self.training or not bn.track_running_stats or bn.running_mean is None
+        use_batch = _uses_batch_stats(self, bn)
         if use_batch:
-            mean, var, n_tot = ops.batch_stats(x, shard)
+            mean, var, n_tot = stats if stats is not None else ops.batch_stats(x, shard)
             if n_tot <= 1 and self.training:
                 raise ValueError("Expected more than 1 value per channel when training")
             if self.training and bn.track_running_stats and bn.running_mean is not None:
@@ -207,12 +218,12 @@ class GraphConv(nn.Module):
         rstd = torch.rsqrt(var + bn.eps)
         return ops.bn_act_res(x, res, bn.weight, bn.bias, mean, rstd, relu, use_batch, n_tot, shard)
 
-    def _stage(self, bn, x, res, relu):
+    def _stage(self, bn, x, res, relu, stats=None):
         """BN -> act -> dropout -> + res, fused into one pass whenever dropout is inactive."""
         drop_on = self.training and self.dropout is not None and self.dropout > 0.0
         fuse_res = res is not None and not drop_on
         if self.use_bn:
-            x = self._bn_act_res(bn, x, res if fuse_res else None, relu)
+            x = self._bn_act_res(bn, x, res if fuse_res else None, relu, stats)
         else:
             if relu:
                 x = torch.relu(x)
@@ -234,8 +245,13 @@ class GraphConv(nn.Module):
         hub = list(ops.fan_out(x, k)) if k <= 8 else [x] * k
         x = hub.pop()
         for i, conv in enumerate(self.convs):
-            x = conv(x, edge_index, hub.pop() if uses_init[i] else None)
-            x = self._stage(self.bns[i + 1], x, hub.pop() if self.use_residual else None, self.use_act)
+            want = self.use_bn and _uses_batch_stats(self, self.bns[i + 1])
+            x0 = hub.pop() if uses_init[i] else None
+            if want:    # the conv's Linear accumulates the statistics its BatchNorm needs in the same pass
+                x, stats = conv(x, edge_index, x0, bn_stats=True)
+            else:
+                x, stats = conv(x, edge_index, x0), None
+            x = self._stage(self.bns[i + 1], x, hub.pop() if self.use_residual else None, self.use_act, stats)
         return x
 
 

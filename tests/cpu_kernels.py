@@ -61,6 +61,26 @@ class CpuKernels:
         dx = g.to(dtype).float() @ w.to(dtype).float()
         return (a * dx).to(dtype), (b * dx).to(dtype)
 
+    # ---- streaming row-GEMM (csrc/rowgemm.hip) ----
+    @staticmethod
+    def gcn_epilogue_supported(d_in, d_out, dtype):
+        return dtype == torch.bfloat16 and d_in == d_out and d_in in (64, 128, 256)
+
+    @staticmethod
+    def gcn_epilogue_stats(a, w, bias, shift=None, want_stats=False):
+        y = a.float() @ w.float().t()
+        if bias is not None:
+            y = y + bias.float()
+        y = y.to(a.dtype)
+        if not want_stats:
+            return y, None
+        v = y.float() - (shift.float() if shift is not None else 0.0)
+        return y, torch.cat([v.sum(0), (v * v).sum(0)])
+
+    @staticmethod
+    def gcn_epilogue_dx(dy, w):
+        return (dy.float() @ w.float()).to(dy.dtype)
+
     # ---- graph-side planning (oracle/graph_oracle.py) ----
     @staticmethod
     def graph_prologue(ei, n, undirected, remove_loops, add_loops):

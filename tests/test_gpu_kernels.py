@@ -707,3 +707,99 @@ def test_combine_fc_fused(cuda, n, d, c):
     # and the unfused path (sgf_axpby + library GEMM) agrees to bf16 rounding of the logits
     unf = ops.out_linear(ops.axpby(x2.to(cuda), x1.to(cuda), gw, 1.0 - gw), w.to(cuda), b.to(cuda)).float()
     assert float((unf.cpu() - out.detach().cpu()).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# T6 / K8: Linear (+ BatchNorm statistics) as one streaming pass (csrc/rowgemm.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(1, 64), (31, 256), (32, 128), (77, 64), (1000, 256), (4097, 128), (20001, 256)])
+def test_gcn_epilogue_stats_and_dx(cuda, n, d):
+    """large/ours.py:36-40 (x = self.W(x)) and the batch statistics of :87-88 in one pass, against fp64 ON THE HOST
+    of the same bf16-rounded operands: y within one bf16 rounding of the fp64 product, the statistics equal to the
+    fp64 column sums of the y the kernel RETURNED (rel 2e-6: fp32 accumulation of at most 20 001 terms), dx = dy W."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(13 * n + d)
+    a = torch.randn(n, d, generator=g).bfloat16()
+    w = (torch.randn(d, d, generator=g) / d ** 0.5).bfloat16()
+    bias = torch.randn(d, generator=g)
+    shift = torch.randn(d, generator=g) * 0.1
+    assert ops.K.gcn_epilogue_supported(d, d, torch.bfloat16)
+    y, st = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
+    y2, none = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), bias.to(cuda))
+    assert none is None and torch.equal(y, y2) and y.dtype == torch.bfloat16
+    ref = a.double() @ w.double().t() + bias.double()
+    err = (y.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), float((err - 2.0 ** -8 * ref.abs()).max())
+    v = y.double().cpu() - shift.double()
+    st_ref = torch.cat([v.sum(0), (v * v).sum(0)])
+    tol = 2e-6 * torch.cat([v.abs().sum(0), (v * v).sum(0)]).clamp_min(1e-3)
+    assert bool(((st.double().cpu() - st_ref).abs() <= tol).all())
+    # no shift, no bias
+    y0, st0 = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), None, None, want_stats=True)
+    v0 = y0.double().cpu()
+    assert bool(((y0.double().cpu() - a.double() @ w.double().t()).abs() <= 2.0 ** -8 * v0.abs() + 1e-6).all())
+    assert _rel(st0[d:], (v0 * v0).sum(0)) <= 2e-6
+    # dx = dy W (contraction over W's rows)
+    dx = ops.K.gcn_epilogue_dx(a.to(cuda), w.to(cuda))
+    refdx = a.double() @ w.double()
+    errdx = (dx.double().cpu() - refdx).abs()
+    assert bool((errdx <= 2.0 ** -8 * refdx.abs() + 1e-6).all())
+
+
+def test_gcn_epilogue_strided_operands(cuda):
+    """Leading dimensions wider than the width: a column slice of a wider activation / weight matrix (the [. | x0]
+    Linear of large/ours.py:36-38 takes W[:, :d] and W[:, d:])."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, d = 333, 128
+    a_wide = torch.randn(n, 2 * d, generator=g).bfloat16().to(cuda)
+    w_wide = (torch.randn(d, 2 * d, generator=g) / d ** 0.5).bfloat16().to(cuda)
+    a, w = a_wide[:, d:], w_wide[:, d:]
+    y, _ = ops.K.gcn_epilogue_stats(a, w, None)
+    ref = a.double() @ w.double().t()
+    assert bool(((y.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all())
+    dx = ops.K.gcn_epilogue_dx(a, w)
+    refdx = a.double() @ w.double()
+    assert bool(((dx.double() - refdx).abs() <= 2.0 ** -8 * refdx.abs() + 1e-6).all())
+
+
+def test_gcn_epilogue_refusals(cuda):
+    from sgformer_amd import ops
+    from sgformer_amd._lib import SgfError
+    assert not ops.K.gcn_epilogue_supported(100, 256, torch.bfloat16)
+    assert not ops.K.gcn_epilogue_supported(256, 256, torch.float32)
+    assert not ops.K.gcn_epilogue_supported(512, 512, torch.bfloat16)
+    a = torch.randn(10, 100, device=cuda).bfloat16()
+    w = torch.randn(256, 100, device=cuda).bfloat16()
+    with pytest.raises(SgfError):
+        ops.K.gcn_epilogue_stats(a, w, None)
+    a = torch.randn(10, 256, device=cuda).bfloat16()
+    w = torch.randn(256, 256, device=cuda).bfloat16()
+    with pytest.raises(SgfError):                       # rows not 16-byte aligned
+        ops.K.gcn_epilogue_stats(a.view(-1)[4:4 + 9 * 256].view(9, 256), w, None)
+
+
+@pytest.mark.parametrize("n,d", [(3000, 256), (517, 64)])
+def test_linear_bn_stats_matches_unfused(cuda, n, d):
+    """ops.linear_bn_stats (what GraphConv feeds its BatchNorm with) == ops.linear + ops.batch_stats, forward and
+    all gradients, on the same inputs; the statistics against fp64 of the returned y."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(d, d, generator=g) / d ** 0.5).to(cuda)
+    b = (torch.randn(d, generator=g) * 0.1 + 0.5).to(cuda)
+    go = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y, (mean, var, n_tot) = ops.linear_bn_stats(xa, wa, ba)
+    (y.float() * go.float()).sum().backward()
+    yd = y.detach().double()
+    assert n_tot == float(n)
+    assert float((mean.double() - yd.mean(0)).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max()))
+    assert _rel(var, yd.var(0, unbiased=False)) <= 1e-5
+    ref = x.double() @ w.bfloat16().double().t() + b.double()
+    assert bool(((yd - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all())
+    assert _rel(xa.grad.float(), go.double() @ w.bfloat16().double()) <= 4e-3
+    assert _rel(wa.grad, go.double().t() @ x.double()) <= 2e-5
+    assert _rel(ba.grad, go.double().sum(0)) <= 2e-5
+    m2, v2, _ = ops.batch_stats(y.detach())
+    assert float((m2 - mean).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max())) and _rel(var, v2) <= 1e-5

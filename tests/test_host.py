@@ -45,7 +45,7 @@ def test_header_binding_and_library_agree():
     for name in decls:
         assert hasattr(lib, name), f"{name} not exported"
     lib.sgf_version.restype = ctypes.c_int
-    assert lib.sgf_version() == 200
+    assert lib.sgf_version() == 210
     # pure host queries are safe without a GPU
     lib.sgf_attn_stats_len.restype = ctypes.c_int64
     assert lib.sgf_attn_stats_len(2, 64) == 2 * 64 * 64 + 2 * 64 + 2

@@ -422,6 +422,23 @@ int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ld
                            void* stream);
 int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw, int64_t n, int32_t d_in,
                         int32_t d_out, int32_t dtype, void* dx, int64_t lddx, void* stream);
+/* GraphConvLayer with use_init (large/ours.py:36-38):  y = [a1 | a2] W^T + bias,  W = [W1 | W2] of width 2 d.
+ *   sgf_gcn_epilogue_partial   : partial = a1 W1^T + bias, rounded to the storage dtype and kept in the matrix
+ *                                cores' accumulator layout (an opaque buffer of sgf_gcn_epilogue_partial_bytes,
+ *                                16-byte aligned; lane-contiguous 16-byte stores, no transposition);
+ *   sgf_gcn_epilogue_stats_add : y = a2 W2^T + partial (+ the column sums, as sgf_gcn_epilogue_stats) — the addend
+ *                                returns to the registers it left from and the sum is rounded once: the arithmetic
+ *                                of a library GEMM with beta = 1 on the rounded first product.
+ * W1 / W2 are passed as pointers into W with ldw = 2 d.  5 [n, d] passes in total where
+ * GEMM + GEMM(beta = 1) + sgf_colstats take 6. */
+size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out);
+int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t n,
+                             int32_t d_in, int32_t d_out, int32_t dtype, void* partial, size_t partial_bytes,
+                             void* stream);
+int sgf_gcn_epilogue_stats_add(const void* a, int64_t lda, const void* w, int64_t ldw, const void* partial,
+                               size_t partial_bytes, int64_t n, int32_t d_in, int32_t d_out, int32_t dtype,
+                               void* y, int64_t ldy, const float* shift, float* stats, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T7 — branch combine alone.   large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.

@@ -46,9 +46,10 @@ struct RowGemmArgs {
   const uint16_t* w; int64_t ldw; int trans;           // trans = 0: B^T[j][k] = w[j ldw + k];  1: = w[k ldw + j]
   const float* bias;                                   // [d_out] or null
   const float* shift;                                  // [d_out] or null (statistics only)
-  float* part;                                         // [gridDim.x][2][d_out] statistics partials, or null
+  float* spart;                                        // [gridDim.x][2][d_out] statistics partials, or null
   uint16_t* y; int64_t ldy;
   int64_t n;
+  uint4* part;                                         // IO 1 (written) / IO 2 (read): [tiles][NS][2][64 lanes] x 16 B
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
@@ -67,7 +68,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // D = d_in = d_out (64 / 128 / 256); KS = D / 16 k-steps, NS = D / 32 column strips, processed in pairs so that a row
 // leaves in 128-byte pieces (full cache lines: 64-byte pieces measured 0.71 ms against 0.55 ms at N = 2.45 M).
-template <int D, bool STATS, int DBG = 0>   // DBG: timing ablations only (SGF_ROWGEMM_DEBUG): 2 no stores, 4 no re-loads
+// IO: 0  y (row-major) = a W^T + bias
+//     1  part = a W^T + bias kept in ACCUMULATOR layout (lane-contiguous 16-byte pieces, rounded to bf16): the first
+//        half of a two-operand Linear [a1 | a2] W^T; no LDS patch, no statistics
+//     2  y (row-major) = a W^T + part: the second half; the addend comes back into the registers it left from, so the
+//        sum is rounded once, like a library GEMM with beta = 1 on the rounded first product
+template <int D, bool STATS, int IO = 0, int DBG = 0>   // DBG: timing ablations only (SGF_ROWGEMM_DEBUG): 2 no stores, 4 no re-loads
 __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
   constexpr int KS = D / 16, NS = D / 32;
   constexpr int BT = D * 2 + 16;                       // bytes per row of B^T in LDS (16-byte slots rotate by one per row)
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
     const int64_t row0 = t * 32;
     const bool tail = row0 + 32 > p.n;
     uint16_t* const yrow = p.y + (row0 + (lane >> 3)) * p.ldy + 8 * (lane & 7);
+    uint4* const ptile = IO != 0 ? p.part + t * (NS * 2 * 64) + lane : nullptr;
 #pragma unroll
     for (int u = 0; u < NS / 2; ++u) {
       f32x16 acc[2];
@@ -147,6 +154,13 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
         acc[1][r] = 0.f;
       }
       const unsigned char* const bu = bfrag0 + 64 * u * BT;
+      uint4 addend[2][2];
+      if (IO == 2) {                                   // requested before the MFMAs, consumed after them
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) addend[c][q] = ptile[((2 * u + c) * 2 + q) * 64];
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bu + 32 * s);
@@ -154,14 +168,43 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b0, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b1, acc[1], 0, 0, 0);
       }
-      // accumulator register r of lane (i31, hi): row (r & 3) + 8 (r >> 2) + 4 hi, column 32 w + i31.
-      // Rows 0-15 are registers 0-7, rows 16-31 registers 8-15: two passes through the 16-row patch.
       float bias_c[2], shift_c[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bias_c[c] = cvec[32 * (2 * u + c) + i31];
         shift_c[c] = STATS ? cvec[D + 32 * (2 * u + c) + i31] : 0.f;
       }
+      // accumulator register r of lane (i31, hi): row (r & 3) + 8 (r >> 2) + 4 hi, column 32 w + i31.
+      if (IO == 2) {                                   // the first operand's product, in this very layout
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint4 v = addend[c][q];
+            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[c][8 * q + 2 * e] += __uint_as_float(d4[e] << 16);
+              acc[c][8 * q + 2 * e + 1] += __uint_as_float(d4[e] & 0xffff0000u);
+            }
+          }
+      }
+      if (IO == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            uint4 v;
+            v.x = cvt_pk_bf16(acc[c][8 * q + 0] + bias_c[c], acc[c][8 * q + 1] + bias_c[c]);
+            v.y = cvt_pk_bf16(acc[c][8 * q + 2] + bias_c[c], acc[c][8 * q + 3] + bias_c[c]);
+            v.z = cvt_pk_bf16(acc[c][8 * q + 4] + bias_c[c], acc[c][8 * q + 5] + bias_c[c]);
+            v.w = cvt_pk_bf16(acc[c][8 * q + 6] + bias_c[c], acc[c][8 * q + 7] + bias_c[c]);
+            if (!(DBG & 2)) ptile[((2 * u + c) * 2 + q) * 64] = v;
+          }
+        __builtin_amdgcn_sched_barrier(0);             // keep the strip pairs apart (32 accumulator registers, not 128)
+        continue;
+      }
+      // Rows 0-15 are registers 0-7, rows 16-31 registers 8-15: two passes through the 16-row patch.
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         uint32_t pk[2][4];
@@ -235,7 +278,7 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
       float s = 0.f;
 #pragma unroll
       for (int v = 0; v < kRgWaves; ++v) s += redb[v * 2 * D + c];
-      p.part[static_cast<int64_t>(blockIdx.x) * 2 * D + c] = s;
+      p.spart[static_cast<int64_t>(blockIdx.x) * 2 * D + c] = s;
     }
   }
 }
@@ -262,19 +305,19 @@ int grid_blocks(int64_t n) {
   return static_cast<int>(b);
 }
 
-template <bool STATS>
+template <bool STATS, int IO>
 int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
   switch (d) {
-    case 64: hipLaunchKernelGGL((k_rowgemm_bf16<64, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((k_rowgemm_bf16<128, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((k_rowgemm_bf16<64, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((k_rowgemm_bf16<128, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
     case 256: {
       const char* e = getenv("SGF_ROWGEMM_DEBUG");
       const int dbg = e ? atoi(e) : 0;
-      switch (dbg) {
-#define SGF_RG_DBG(X) case X: hipLaunchKernelGGL((k_rowgemm_bf16<256, false, X>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+      switch (IO == 0 && !STATS ? dbg : 0) {
+#define SGF_RG_DBG(X) case X: hipLaunchKernelGGL((k_rowgemm_bf16<256, false, 0, X>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
         SGF_RG_DBG(2) SGF_RG_DBG(4) SGF_RG_DBG(6)
 #undef SGF_RG_DBG
-        default: hipLaunchKernelGGL((k_rowgemm_bf16<256, STATS>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_rowgemm_bf16<256, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
       }
       break;
     }
@@ -331,14 +374,14 @@ extern "C" int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w,
   }
   const int blocks = grid_blocks(n);
   RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, bias, shift,
-                   nullptr, static_cast<uint16_t*>(y), ldy, n};
-  if (!stats) return launch_rowgemm<false>(args, d_out, blocks, st);
+                   nullptr, static_cast<uint16_t*>(y), ldy, n, nullptr};
+  if (!stats) return launch_rowgemm<false, 0>(args, d_out, blocks, st);
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
               "sgf_gcn_epilogue_stats: workspace %zu < %zu", workspace_bytes, sgf_gcn_epilogue_workspace_bytes(n, d_out));
-  args.part = static_cast<float*>(workspace);
-  rc = launch_rowgemm<true>(args, d_out, blocks, st);
+  args.spart = static_cast<float*>(workspace);
+  rc = launch_rowgemm<true, 0>(args, d_out, blocks, st);
   if (rc != SGF_OK) return rc;
-  hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, args.part, blocks, 2 * d_out,
+  hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, args.spart, blocks, 2 * d_out,
                      stats);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -351,6 +394,57 @@ extern "C" int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, 
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
   RowGemmArgs args{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(w), ldw, 1, nullptr, nullptr,
-                   nullptr, static_cast<uint16_t*>(dx), lddx, n};
-  return launch_rowgemm<false>(args, d_in, grid_blocks(n), static_cast<hipStream_t>(stream));
+                   nullptr, static_cast<uint16_t*>(dx), lddx, n, nullptr};
+  return launch_rowgemm<false, 0>(args, d_in, grid_blocks(n), static_cast<hipStream_t>(stream));
+}
+
+// ---- two-operand Linear  y = [a1 | a2] W^T + bias  (GraphConvLayer with use_init, large/ours.py:36-38) -------------
+extern "C" size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out) {
+  if (n < 0 || d_out <= 0) return 0;
+  return static_cast<size_t>((n + 31) / 32) * 32 * static_cast<size_t>(d_out) * 2;
+}
+
+extern "C" int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                                        int64_t n, int32_t d_in, int32_t d_out, int32_t dtype, void* partial,
+                                        size_t partial_bytes, void* stream) {
+  int rc = check_common("sgf_gcn_epilogue_partial", a, lda, w, ldw, n, d_in, d_out, dtype, partial, d_out);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(partial_bytes >= sgf_gcn_epilogue_partial_bytes(n, d_out), SGF_E_WORKSPACE,
+              "sgf_gcn_epilogue_partial: partial buffer %zu < %zu", partial_bytes,
+              sgf_gcn_epilogue_partial_bytes(n, d_out));
+  RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, bias, nullptr,
+                   nullptr, nullptr, 0, n, static_cast<uint4*>(partial)};
+  return launch_rowgemm<false, 1>(args, d_out, grid_blocks(n), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sgf_gcn_epilogue_stats_add(const void* a, int64_t lda, const void* w, int64_t ldw, const void* partial,
+                                          size_t partial_bytes, int64_t n, int32_t d_in, int32_t d_out, int32_t dtype,
+                                          void* y, int64_t ldy, const float* shift, float* stats, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  int rc = check_common("sgf_gcn_epilogue_stats_add", a, lda, w, ldw, n, d_in, d_out, dtype, y, ldy);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (stats) SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * static_cast<size_t>(d_out) * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(partial && reinterpret_cast<uintptr_t>(partial) % 16 == 0 &&
+                  partial_bytes >= sgf_gcn_epilogue_partial_bytes(n, d_out),
+              SGF_E_INVALID, "sgf_gcn_epilogue_stats_add: partial buffer missing, misaligned or too small");
+  const int blocks = grid_blocks(n);
+  RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, nullptr, shift,
+                   nullptr, static_cast<uint16_t*>(y), ldy, n,
+                   const_cast<uint4*>(static_cast<const uint4*>(partial))};
+  if (!stats) return launch_rowgemm<false, 2>(args, d_out, blocks, st);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
+              "sgf_gcn_epilogue_stats_add: workspace %zu < %zu", workspace_bytes,
+              sgf_gcn_epilogue_workspace_bytes(n, d_out));
+  args.spart = static_cast<float*>(workspace);
+  rc = launch_rowgemm<true, 2>(args, d_out, blocks, st);
+  if (rc != SGF_OK) return rc;
+  hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, args.spart, blocks, 2 * d_out,
+                     stats);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
 }

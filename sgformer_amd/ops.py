@@ -537,6 +537,26 @@ class HipKernels:
         return y, stats
 
     @staticmethod
+    def gcn_epilogue_cat(a1, a2, w, bias, shift=None, want_stats=False):
+        """y = [a1 | a2] w^T + bias (w [d, 2 d]) in two streaming passes: a1's product stays in the matrix cores'
+        accumulator layout (an opaque scratch buffer) and is added, unrounded-sum-wise, in a2's pass."""
+        n, d = a1.shape
+        dev = a1.device
+        lib = _lib.load()
+        part = _workspace(dev, "gcn_part", lib.sgf_gcn_epilogue_partial_bytes(n, d))
+        y = torch.empty((n, d), dtype=a1.dtype, device=dev)
+        stats = torch.empty(2 * d, dtype=_F32, device=dev) if want_stats else None
+        ws = _workspace(dev, "gcn_epi", lib.sgf_gcn_epilogue_workspace_bytes(n, d)) if want_stats else None
+        w1, w2 = w[:, :d], w[:, d:]
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gcn_epilogue_partial", _ptr(a1), _ld(a1), _ptr(w1), w.stride(0), _ptr(bias), n, d, d,
+                      _code(a1), _ptr(part), part.numel(), _stream(dev))
+            _lib.call("sgf_gcn_epilogue_stats_add", _ptr(a2), _ld(a2), _ptr(w2), w.stride(0), _ptr(part),
+                      part.numel(), n, d, d, _code(a2), _ptr(y), _ld(y), _ptr(shift), _ptr(stats), _ptr(ws),
+                      0 if ws is None else ws.numel(), _stream(dev))
+        return y, stats
+
+    @staticmethod
     def gcn_epilogue_dx(dy, w):
         """dx = dy w  (w [d_out, d_in] in dy's dtype; may be a column slice of a wider matrix)."""
         n, d_out = dy.shape
@@ -1399,16 +1419,18 @@ class _Linear(torch.autograd.Function):
         widths = [x.shape[1] for x in xs]
         if sum(widths) != w.shape[1]:
             raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
-        fused = len(xs) == 1 and _streaming_linear_ok(xs[0], wc)
+        d_out = wc.shape[0]
+        fused = (len(xs) <= 2 and all(k == d_out for k in widths)
+                 and all(_streaming_linear_ok(x, wc[:, i * d_out:(i + 1) * d_out]) for i, x in enumerate(xs)))
         if fused:
-            # one streaming pass with W resident in LDS (sgf_gcn_epilogue_stats); the BatchNorm that follows
-            # gets its column sums from the same pass
-            x0 = _rows16(xs[0])
+            # streaming passes with W resident in LDS (sgf_gcn_epilogue_*); the BatchNorm that follows gets its
+            # column sums from the same pass
+            xr = [_rows16(x) for x in xs]
             b32 = None if b is None else b.detach().float().contiguous()
             if stats_req is not None:
-                y = _linear_with_stats(x0, wc, b32, stats_req)
+                y = _linear_with_stats(xr, wc, b32, stats_req)
             else:
-                y, _ = K.gcn_epilogue_stats(x0, wc, b32)
+                y, _ = _streaming_linear(xr, wc, b32)
         elif len(xs) == 1:
             y = torch.nn.functional.linear(xs[0], wc, bc)
         else:
@@ -1435,8 +1457,8 @@ class _Linear(torch.autograd.Function):
         for i, k in enumerate(widths):
             if not ctx.needs_input_grad[3 + i]:
                 dxs.append(None)
-            elif len(widths) == 1 and _streaming_linear_ok(g, wc):
-                dxs.append(K.gcn_epilogue_dx(_rows16(g), wc))
+            elif k == wc.shape[0] and _streaming_linear_ok(g, wc[:, off:off + k]):
+                dxs.append(K.gcn_epilogue_dx(_rows16(g), wc[:, off:off + k]))
             else:
                 dxs.append(g @ wc[:, off:off + k])
             off += k
@@ -1478,21 +1500,28 @@ def _streaming_linear_ok(x: torch.Tensor, wc: torch.Tensor) -> bool:
             and wc.data_ptr() % 16 == 0 and K.gcn_epilogue_supported(wc.shape[1], wc.shape[0], x.dtype))
 
 
-def _linear_with_stats(x, wc, b32, stats_req):
-    """y = x wc^T + b32 AND BatchNorm's batch statistics of y, from the same pass (sgf_gcn_epilogue_stats).
-    Same shifted sums as batch_stats: the shift is the column mean of the first rows of y, which a small launch
-    over those rows provides."""
+def _streaming_linear(xr, wc, b32, shift=None, want_stats=False, rows=None):
+    """[x_1 | x_2] wc^T + b32 on the first `rows` rows (all by default): one or two streaming passes."""
+    xs = xr if rows is None else [x[:rows] for x in xr]
+    if len(xs) == 1:
+        return K.gcn_epilogue_stats(xs[0], wc, b32, shift, want_stats=want_stats)
+    return K.gcn_epilogue_cat(xs[0], xs[1], wc, b32, shift, want_stats=want_stats)
+
+
+def _linear_with_stats(xr, wc, b32, stats_req):
+    """y = [x_1 | x_2] wc^T + b32 AND BatchNorm's batch statistics of y, from the same pass.  Same shifted sums as
+    batch_stats: the shift is the column mean of the first rows of y, which a small launch over those rows provides."""
     shard = stats_req.get("shard")
-    n, d = x.shape[0], wc.shape[0]
+    n, d = xr[0].shape[0], wc.shape[0]
     ns = min(n, _BN_SAMPLE_ROWS)
-    _, st_s = K.gcn_epilogue_stats(x[:ns], wc, b32, None, want_stats=True)
-    samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
+    _, st_s = _streaming_linear(xr, wc, b32, None, want_stats=True, rows=ns)
+    samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=xr[0].device)])
     n_tot = float(n)
     if shard is not None:
         shard.all_reduce(samp)
         n_tot = float(shard.n_global)
     shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
-    y, st = K.gcn_epilogue_stats(x, wc, b32, shift, want_stats=True)
+    y, st = _streaming_linear(xr, wc, b32, shift, want_stats=True)
     if shard is not None:
         shard.all_reduce(st)
     m1 = st[:d] / max(n_tot, 1.0)
@@ -1506,11 +1535,13 @@ def linear(x, w, b):
     return _Linear.apply(w, b, None, x)
 
 
-def linear_bn_stats(x, w, b, shard=None):
-    """(y, (mean, var, n_tot)): nn.Linear and the batch statistics BatchNorm1d needs of its output
-    (large/ours.py:36-40 followed by :87-88) — one pass when the layer is square bf16, else linear + batch_stats."""
+def linear_bn_stats(xs, w, b, shard=None):
+    """(y, (mean, var, n_tot)): nn.Linear of x (or of [x_1 | x_2] for a tuple, GraphConvLayer's use_init) and the
+    batch statistics BatchNorm1d needs of its output (large/ours.py:36-40 followed by :87-88) — from the Linear's own
+    pass when its blocks are square bf16, else linear + batch_stats."""
     req = {"shard": shard, "out": None}
-    y = _Linear.apply(w, b, req, x)
+    xs = xs if isinstance(xs, (tuple, list)) else (xs,)
+    y = _Linear.apply(w, b, req, *xs)
     return y, req["out"]
 
 

@@ -159,6 +159,8 @@ class GraphConvLayer(nn.Module):
         y = ops.spmm(graph, x, shard)
         if self.use_init:
             # W [y | x0] + b without materialising the concatenation
+            if bn_stats:
+                return ops.linear_bn_stats((y, x0), self.W.weight, self.W.bias, shard)
             y = ops.linear_cat((y, x0), self.W.weight, self.W.bias)
         elif self.use_weight:
             if bn_stats:

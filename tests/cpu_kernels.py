@@ -78,6 +78,16 @@ class CpuKernels:
         return y, torch.cat([v.sum(0), (v * v).sum(0)])
 
     @staticmethod
+    def gcn_epilogue_cat(a1, a2, w, bias, shift=None, want_stats=False):
+        d = a1.shape[1]
+        part, _ = CpuKernels.gcn_epilogue_stats(a1, w[:, :d], bias)          # rounded first product
+        y = (a2.float() @ w[:, d:].float().t() + part.float()).to(a1.dtype)
+        if not want_stats:
+            return y, None
+        v = y.float() - (shift.float() if shift is not None else 0.0)
+        return y, torch.cat([v.sum(0), (v * v).sum(0)])
+
+    @staticmethod
     def gcn_epilogue_dx(dy, w):
         return (dy.float() @ w.float()).to(dy.dtype)
 

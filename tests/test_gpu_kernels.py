@@ -803,3 +803,60 @@ def test_linear_bn_stats_matches_unfused(cuda, n, d):
     assert _rel(ba.grad, go.double().sum(0)) <= 2e-5
     m2, v2, _ = ops.batch_stats(y.detach())
     assert float((m2 - mean).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max())) and _rel(var, v2) <= 1e-5
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (1000, 128), (20001, 256)])
+def test_gcn_epilogue_two_operands(cuda, n, d):
+    """GraphConvLayer with use_init, large/ours.py:36-38: y = [a1 | a2] W^T + b in two streaming passes with the first
+    product kept in the accumulator layout.  Reference on the host in fp64: first product rounded to bf16 (what the
+    partial buffer stores), the sum rounded once; statistics of the returned y; both input gradients."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(7 * n + d)
+    a1 = torch.randn(n, d, generator=g).bfloat16()
+    a2 = torch.randn(n, d, generator=g).bfloat16()
+    w = (torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5).bfloat16()
+    bias = torch.randn(d, generator=g)
+    shift = torch.randn(d, generator=g) * 0.1
+    y, st = ops.K.gcn_epilogue_cat(a1.to(cuda), a2.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
+    part = (a1.double() @ w[:, :d].double().t() + bias.double())
+    ref = a2.double() @ w[:, d:].double().t() + part
+    # the rounded partial may sit one bf16 ulp of `part` away from the exact one; then one rounding of the sum
+    tol = 2.0 ** -8 * (ref.abs() + part.abs()) + 1e-6
+    assert bool(((y.double().cpu() - ref).abs() <= tol).all())
+    part_r = part.float().bfloat16().double()
+    ref_r = a2.double() @ w[:, d:].double().t() + part_r
+    frac_exact = float(((y.double().cpu() - ref_r).abs() <= 2.0 ** -8 * ref_r.abs() + 1e-6).float().mean())
+    assert frac_exact >= 0.999, frac_exact            # single rounding of (product 2 + rounded product 1)
+    v = y.double().cpu() - shift.double()
+    st_ref = torch.cat([v.sum(0), (v * v).sum(0)])
+    tolst = 2e-6 * torch.cat([v.abs().sum(0), (v * v).sum(0)]).clamp_min(1e-3)
+    assert bool(((st.double().cpu() - st_ref).abs() <= tolst).all())
+    y2, none = ops.K.gcn_epilogue_cat(a1.to(cuda), a2.to(cuda), w.to(cuda), bias.to(cuda))
+    assert none is None and torch.equal(y, y2)
+
+
+def test_linear_cat_bn_stats_matches_unfused(cuda):
+    """ops.linear_bn_stats((y, x0), W, b) == addmm path + batch_stats: values, statistics and all gradients."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, d = 2500, 256
+    x1 = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    x2 = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5).to(cuda)
+    b = (torch.randn(d, generator=g) * 0.1).to(cuda)
+    go = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    a1, a2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    wa, ba = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y, (mean, var, n_tot) = ops.linear_bn_stats((a1, a2), wa, ba)
+    (y.float() * go.float()).sum().backward()
+    yd = y.detach().double()
+    wr = w.bfloat16().double()
+    ref = torch.cat([x1, x2], 1).double() @ wr.t() + b.double()
+    part = x1.double() @ wr[:, :d].t() + b.double()              # stored rounded: its ulp enters the sum's error
+    assert bool(((yd - ref).abs() <= 2.0 ** -8 * (ref.abs() + part.abs()) + 1e-6).all())
+    assert float((mean.double() - yd.mean(0)).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max()))
+    assert _rel(var, yd.var(0, unbiased=False)) <= 1e-5
+    assert _rel(a1.grad.float(), go.double() @ wr[:, :d]) <= 4e-3
+    assert _rel(a2.grad.float(), go.double() @ wr[:, d:]) <= 4e-3
+    assert _rel(wa.grad, go.double().t() @ torch.cat([x1, x2], 1).double()) <= 2e-5
+    assert _rel(ba.grad, go.double().sum(0)) <= 2e-5

@@ -303,7 +303,10 @@ int sgf_attn_h_bwd_reduce(const void* h, int64_t ldh, const void* g, int64_t ldg
 int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o,
                          int64_t ldo, const float* den, int64_t n, int32_t d, int32_t dtype,
                          const float* M, const float* w, const float* D, const float* ds, void* dh,
-                         int64_t lddh, void* stream);
+                         int64_t lddh, void* workspace, size_t workspace_bytes, void* stream);
+/* scratch of sgf_attn_h_bwd_apply: bf16 storage with d in {64, 128, 256} runs as two per-wave streaming passes
+ * (csrc/rowgemm.hip) with the first product parked in the matrix cores' accumulator layout; 0 otherwise */
+size_t sgf_attn_h_bwd_apply_workspace_bytes(int64_t n, int32_t d, int32_t dtype);
 
 /* ------------------------------------------------------------------------------------------
  * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for

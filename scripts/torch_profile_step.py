@@ -45,7 +45,7 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45,
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=int(os.environ.get("SGF_PROFILE_ROWS", "45")),
                                                              max_name_column_width=48, max_shapes_column_width=60))
 
 

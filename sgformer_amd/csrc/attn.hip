@@ -1295,6 +1295,9 @@ extern "C" int sgf_attn_h_fwd(const void* h, int64_t ldh, int64_t n, int32_t d, 
   SGF_REQUIRE(h && M && m && w && beta && out && den, SGF_E_INVALID, "sgf_attn_h_fwd: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == SGF_F32) return h_fwd_t<float>(h, ldh, n, d, M, m, w, beta, out, ldo, den, st);
+  // bf16, d in {64, 128, 256}, 16-byte aligned rows: the per-wave streaming kernel of csrc/rowgemm.hip
+  if (hrow_supported(d, dtype, h, ldh, nullptr, 0, nullptr, 0, out, ldo) && reinterpret_cast<uintptr_t>(den) % 16 == 0)
+    return hrow_fwd(h, ldh, n, d, M, m, w, beta, out, ldo, den, st);
   return h_fwd_t<uint16_t>(h, ldh, n, d, M, m, w, beta, out, ldo, den, st);
 }
 
@@ -1321,7 +1324,8 @@ extern "C" int sgf_attn_h_bwd_reduce(const void* h, int64_t ldh, const void* g, 
 extern "C" int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, int64_t ldg,
                                     const void* o, int64_t ldo, const float* den, int64_t n, int32_t d,
                                     int32_t dtype, const float* M, const float* w, const float* D,
-                                    const float* ds, void* dh, int64_t lddh, void* stream) {
+                                    const float* ds, void* dh, int64_t lddh, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   int rc = check_common("sgf_attn_h_bwd_apply", n, 1, d, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
@@ -1330,7 +1334,18 @@ extern "C" int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == SGF_F32)
     return h_bwd_apply_t<float>(h, ldh, g, ldg, o, ldo, den, n, d, M, w, D, ds, dh, lddh, st);
+  if (hrow_supported(d, dtype, h, ldh, g, ldg, o, ldo, dh, lddh)) {
+    SGF_REQUIRE(workspace && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 &&
+                    workspace_bytes >= hrow_partial_bytes(n, d),
+                SGF_E_WORKSPACE, "sgf_attn_h_bwd_apply: workspace %zu < %zu", workspace_bytes, hrow_partial_bytes(n, d));
+    return hrow_bwd(h, ldh, g, ldg, o, ldo, den, n, d, M, w, D, ds, dh, lddh, workspace, st);
+  }
   return h_bwd_apply_t<uint16_t>(h, ldh, g, ldg, o, ldo, den, n, d, M, w, D, ds, dh, lddh, st);
+}
+
+extern "C" size_t sgf_attn_h_bwd_apply_workspace_bytes(int64_t n, int32_t d, int32_t dtype) {
+  if (n <= 0 || dtype != SGF_BF16 || !(d == 64 || d == 128 || d == 256)) return 0;
+  return hrow_partial_bytes(n, d);
 }
 
 extern "C" int64_t sgf_attn_stats_len(int32_t heads, int32_t d) {

@@ -123,4 +123,14 @@ __device__ __forceinline__ int mfma32_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
+// ---- per-wave streaming row kernels of csrc/rowgemm.hip, used by csrc/attn.hip for the attention-from-input passes ----
+bool hrow_supported(int d, int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc,
+                    const void* o, int64_t ldo);
+size_t hrow_partial_bytes(int64_t n, int d);
+int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const float* m, const float* w,
+             const float* beta, void* out, int64_t ldo, float* den, hipStream_t st);
+int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den,
+             int64_t n, int d, const float* M, const float* w, const float* Dm, const float* ds, void* dh, int64_t lddh,
+             void* partial, hipStream_t st);
+
 }  // namespace sgf

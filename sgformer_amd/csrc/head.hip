@@ -153,33 +153,38 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd_bf16(
       fb.u.z = pack2(g[4], g[5]);
       fb.u.w = pack2(g[6], g[7]);
       // TRANSPOSED product: D[feature][node] = W^T[feature][class] dlogits^T[class][node].  The W^T fragment is the
-      // A operand (lane: feature 32 t + i31, 8 classes), the dlogits fragment the B operand (lane: node i31, the
-      // same 8 classes), so in the result a lane holds 16 FEATURES of ITS node in four runs of 4 consecutive
-      // ones: 8-byte stores, 16 contiguous bytes per node row and instruction (a lane-per-feature result would
-      // store 2 bytes per lane)
+      // A operand (lane: one feature, 8 classes), the dlogits fragment the B operand (lane: node i31, the same 8
+      // classes), so in the result a lane holds 16 features of ITS node.  WHICH features is ours to choose (the rows
+      // of the A operand can be any 32 features): MFMA row 8 q + 4 h + j of strip t is feature (DP / 2) h + 16 t + 4 q + j,
+      // which makes accumulator register r of lane (node, hi) feature (DP / 2) hi + 16 t + r — 16 consecutive ones,
+      // two 16-byte stores (the natural order gives four separate runs of 4: 8-byte stores, and this kernel is bound
+      // by the NUMBER of partial-line writes the L2 accepts, ~260 G/s, not by bytes).
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (32 * t < d) {
-          const bf16x8 at = *reinterpret_cast<const bf16x8*>(&wt[(32 * t + i31) * PITCH + k0]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, fb.v, acc[t], 0, 0, 0);
-        }
+        const int feat = (DP / 2) * ((i31 >> 2) & 1) + 16 * t + 4 * (i31 >> 3) + (i31 & 3);
+        const bf16x8 at = *reinterpret_cast<const bf16x8*>(&wt[feat * PITCH + k0]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, fb.v, acc[t], 0, 0, 0);
       }
     }
     const int64_t orow = tile * 32 + i31;
     if (orow < n) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (32 * t < d) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * t + 8 * q + 4 * hi;          // C layout: row index = (r & 3) + 8 (r >> 2) + 4 hi
-            uint2 o1, o2;
-            o1.x = pack2(a * acc[t][4 * q + 0], a * acc[t][4 * q + 1]);
-            o1.y = pack2(a * acc[t][4 * q + 2], a * acc[t][4 * q + 3]);
-            o2.x = pack2(b * acc[t][4 * q + 0], b * acc[t][4 * q + 1]);
-            o2.y = pack2(b * acc[t][4 * q + 2], b * acc[t][4 * q + 3]);
-            *reinterpret_cast<uint2*>(dx1 + orow * ld1 + f0) = o1;
-            *reinterpret_cast<uint2*>(dx2 + orow * ld2 + f0) = o2;
+        for (int q = 0; q < 2; ++q) {
+          const int f0 = (DP / 2) * hi + 16 * t + 8 * q;
+          if (f0 < d) {                                      // d % 8 == 0; features >= d are zero padding
+            uint4 o1, o2;
+            o1.x = pack2(a * acc[t][8 * q + 0], a * acc[t][8 * q + 1]);
+            o1.y = pack2(a * acc[t][8 * q + 2], a * acc[t][8 * q + 3]);
+            o1.z = pack2(a * acc[t][8 * q + 4], a * acc[t][8 * q + 5]);
+            o1.w = pack2(a * acc[t][8 * q + 6], a * acc[t][8 * q + 7]);
+            o2.x = pack2(b * acc[t][8 * q + 0], b * acc[t][8 * q + 1]);
+            o2.y = pack2(b * acc[t][8 * q + 2], b * acc[t][8 * q + 3]);
+            o2.z = pack2(b * acc[t][8 * q + 4], b * acc[t][8 * q + 5]);
+            o2.w = pack2(b * acc[t][8 * q + 6], b * acc[t][8 * q + 7]);
+            *reinterpret_cast<uint4*>(dx1 + orow * ld1 + f0) = o1;
+            *reinterpret_cast<uint4*>(dx2 + orow * ld2 + f0) = o2;
           }
         }
       }
@@ -243,9 +248,9 @@ extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const floa
   int rc = check_head("sgf_combine_fc_bwd", n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
-  SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d && ld1 % 4 == 0 && ld2 % 4 == 0 &&
-                  reinterpret_cast<uintptr_t>(dx1) % 8 == 0 && reinterpret_cast<uintptr_t>(dx2) % 8 == 0,
-              SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 8-byte aligned, ld %% 4 == 0)");
+  SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d && ld1 % 8 == 0 && ld2 % 8 == 0 &&
+                  reinterpret_cast<uintptr_t>(dx1) % 16 == 0 && reinterpret_cast<uintptr_t>(dx2) % 16 == 0,
+              SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 16-byte aligned, ld %% 8 == 0)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(head_grid(n)), block(kHeadThreads);
 #define SGF_HEAD_BWD(DP_)                                                                                   \

@@ -283,6 +283,254 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same skeleton for the attention-from-input apply passes (include/sgf.h, sgf_attn_h_fwd / sgf_attn_h_bwd_apply;
+// large/ours.py:130-151 with the projections folded into d x d matrices): a streamed [n, d] operand times a resident
+// d x d matrix, with PER-ROW scalars in the epilogue.  In the accumulator layout a lane's 16 registers are 16 rows, so
+// a row scalar is one register per accumulator register:
+//   F   out = (h M + m) / den,  den = h.w + beta.   h.w comes out of the matrix cores too: a ninth "strip" whose B
+//       fragment is w for EVERY lane gives D[row][*] = h_row . w — already one value per accumulator register.
+//   B1  part = (g M^T) / den - ((g.o) / den^2) w      (dnum M^T + dden w, scaled after the product, in fp32);
+//       g.o is a lane-local dot over the fragments of g and o, den is read; kept in accumulator layout
+//   B2  dh = h D + ds + part
+// B1 + B2 move 6 [n, d] tensors like the two k_apply_bf16 launches they replace (1.28 + 1.66 ms at N = 2.45 M),
+// with whole-line stores, lane-contiguous partials and no block barrier.
+constexpr int kHF = 0, kHB1 = 1, kHB2 = 2;
+
+struct HRowArgs {
+  const uint16_t* a; int64_t lda;        // F, B2: h    B1: g
+  const uint16_t* a2; int64_t lda2;      // B1: o
+  const float* bmat; int trans_b;        // fp32 [d, d]; B[k][j] = trans_b ? bmat[j d + k] : bmat[k d + j]
+  const float* cvec;                     // F: m    B1: w    B2: ds
+  const float* dvec; const float* beta;  // F: w and the device scalar beta
+  float* den;                            // F: written    B1: read      [n]
+  uint16_t* out; int64_t ldo;            // F, B2
+  uint4* part;                           // B1: written    B2: read
+  int64_t n;
+};
+
+template <int D, int MODE>
+__global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
+  constexpr int KS = D / 16, NS = D / 32;
+  constexpr int BT = D * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[D * BT + kRgWaves * kStageBytes + D * 4 + D * 2];
+  unsigned char* const ldsB = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const stg = lds + D * BT + wave * kStageBytes;
+  float* const cvec = reinterpret_cast<float*>(lds + D * BT + kRgWaves * kStageBytes);
+  uint16_t* const wdot = reinterpret_cast<uint16_t*>(lds + D * BT + kRgWaves * kStageBytes + D * 4);   // F: bf16(w)
+
+  // ---- B^T -> LDS as bf16: B^T[j][k] = B[k][j] ----
+  if (p.trans_b) {                                     // B[k][j] = bmat[j d + k]: rows of bmat are rows of B^T
+    for (int c = tid; c < D * (D / 8); c += kRgThreads) {
+      const int j = c / (D / 8), q = c % (D / 8);
+      const float4 f0 = *reinterpret_cast<const float4*>(p.bmat + j * D + 8 * q);
+      const float4 f1 = *reinterpret_cast<const float4*>(p.bmat + j * D + 8 * q + 4);
+      uint4 v;
+      v.x = cvt_pk_bf16(f0.x, f0.y); v.y = cvt_pk_bf16(f0.z, f0.w);
+      v.z = cvt_pk_bf16(f1.x, f1.y); v.w = cvt_pk_bf16(f1.z, f1.w);
+      *reinterpret_cast<uint4*>(ldsB + j * BT + 16 * q) = v;
+    }
+  } else {                                             // B[k][j] = bmat[k d + j]: scatter a row of bmat down a column
+    for (int c = tid; c < D * (D / 4); c += kRgThreads) {
+      const int k = c / (D / 4), q = c % (D / 4);
+      const float4 f = *reinterpret_cast<const float4*>(p.bmat + k * D + 4 * q);
+      const uint32_t lo = cvt_pk_bf16(f.x, f.y), hi2 = cvt_pk_bf16(f.z, f.w);
+      *reinterpret_cast<uint16_t*>(ldsB + (4 * q + 0) * BT + 2 * k) = static_cast<uint16_t>(lo & 0xffffu);
+      *reinterpret_cast<uint16_t*>(ldsB + (4 * q + 1) * BT + 2 * k) = static_cast<uint16_t>(lo >> 16);
+      *reinterpret_cast<uint16_t*>(ldsB + (4 * q + 2) * BT + 2 * k) = static_cast<uint16_t>(hi2 & 0xffffu);
+      *reinterpret_cast<uint16_t*>(ldsB + (4 * q + 3) * BT + 2 * k) = static_cast<uint16_t>(hi2 >> 16);
+    }
+  }
+  for (int c = tid; c < D; c += kRgThreads) {
+    cvec[c] = p.cvec[c];
+    if (MODE == kHF) wdot[c] = static_cast<uint16_t>(cvt_pk_bf16(p.dvec[c], 0.f) & 0xffffu);
+  }
+  __syncthreads();
+  const float beta = MODE == kHF ? p.beta[0] : 0.f;
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kRgWaves;
+  auto load_tile = [&](int64_t t, bf16x8 (&dst)[KS]) {
+    int64_t row = t * 32 + i31;
+    if (row >= p.n) row = p.n - 1;
+    const uint16_t* src = p.a + row * p.lda + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+  };
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+
+  bf16x8 cur[KS], nxt[KS];
+  int64_t t = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+  if (t < ntiles) load_tile(t, cur);
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    if (tn < ntiles) load_tile(tn, nxt);
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    uint16_t* const yrow = p.out + (row0 + (lane >> 3)) * p.ldo + 8 * (lane & 7);
+    uint4* const ptile = MODE != kHF ? p.part + t * (NS * 2 * 64) + lane : nullptr;
+
+    // ---- per-row scalars, one per accumulator register: rs[r] multiplies the product, rc[r] the vector ----
+    float rs[16], rc[16];
+    if (MODE == kHF) {
+      f32x16 dacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wdot) + 32 * s + 16 * hi);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b, dacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float den = dacc[r] + beta;
+        rs[r] = 1.0f / den;
+        rc[r] = rs[r];
+        dacc[r] = den;
+      }
+      if (i31 == 0) {                                  // every lane of a half-wave holds the same 16 denominators
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t r0 = row0 + 8 * q + 4 * hi;
+          if (!tail) {
+            *reinterpret_cast<float4*>(p.den + r0) = make_float4(dacc[4 * q], dacc[4 * q + 1], dacc[4 * q + 2], dacc[4 * q + 3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (r0 + j < p.n) p.den[r0 + j] = dacc[4 * q + j];
+          }
+        }
+      }
+    } else if (MODE == kHB1) {
+      // g.o of row i31: lane-local over this lane's k chunks, then the other half-wave's
+      int64_t row = row0 + i31;
+      if (row >= p.n) row = p.n - 1;
+      const uint16_t* po = p.a2 + row * p.lda2 + 8 * hi;
+      float dot = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 o = *reinterpret_cast<const uint4*>(po + 16 * s);
+        const uint4 g = *reinterpret_cast<const uint4*>(&cur[s]);
+        const uint32_t ov[4] = {o.x, o.y, o.z, o.w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dot = fmaf(__uint_as_float(gv[e] << 16), __uint_as_float(ov[e] << 16), dot);
+          dot = fmaf(__uint_as_float(gv[e] & 0xffff0000u), __uint_as_float(ov[e] & 0xffff0000u), dot);
+        }
+      }
+      dot += __shfl_xor(dot, 32, 64);
+      const float inv_row = 1.0f / p.den[row];
+      const float coef_row = -dot * inv_row * inv_row;                   // dden / den folded: -(g.o) / den^2
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int src = (r & 3) + 8 * (r >> 2) + 4 * hi;                 // the lane that owns this register's row
+        rs[r] = __shfl(inv_row, src, 64);
+        rc[r] = __shfl(coef_row, src, 64);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rs[r] = 1.f;
+        rc[r] = 1.f;
+      }
+    }
+
+#pragma unroll
+    for (int u = 0; u < NS / 2; ++u) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[0][r] = 0.f;
+        acc[1][r] = 0.f;
+      }
+      const unsigned char* const bu = bfrag0 + 64 * u * BT;
+      uint4 addend[2][2];
+      if (MODE == kHB2) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) addend[c][q] = ptile[((2 * u + c) * 2 + q) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bu + 32 * s);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bu + 32 * BT + 32 * s);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b1, acc[1], 0, 0, 0);
+      }
+      float vc[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vc[c] = cvec[32 * (2 * u + c) + i31];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (MODE == kHB2) acc[c][r] += vc[c];
+          else acc[c][r] = fmaf(rs[r], acc[c][r], rc[r] * vc[c]);
+        }
+      if (MODE == kHB2) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint4 v = addend[c][q];
+            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[c][8 * q + 2 * e] += __uint_as_float(d4[e] << 16);
+              acc[c][8 * q + 2 * e + 1] += __uint_as_float(d4[e] & 0xffff0000u);
+            }
+          }
+      }
+      if (MODE == kHB1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            uint4 v;
+            v.x = cvt_pk_bf16(acc[c][8 * q + 0], acc[c][8 * q + 1]);
+            v.y = cvt_pk_bf16(acc[c][8 * q + 2], acc[c][8 * q + 3]);
+            v.z = cvt_pk_bf16(acc[c][8 * q + 4], acc[c][8 * q + 5]);
+            v.w = cvt_pk_bf16(acc[c][8 * q + 6], acc[c][8 * q + 7]);
+            ptile[((2 * u + c) * 2 + q) * 64] = v;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+            const uint32_t v = cvt_pk_bf16(acc[c][r], acc[c][r + 1]);
+            const int rl = (r & 3) + 8 * ((r >> 2) & 1);
+            *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
+            *reinterpret_cast<uint4*>(yrow + (16 * hh + 8 * q) * p.ldo + 64 * u) = v;
+        }
+        wave_lds_sync();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+  }
+}
+
 // stats[c] = Σ_blocks part[b][c], fixed order (deterministic).  One block per 64 entries, 4 block-groups per entry.
 __global__ __launch_bounds__(256) void k_rowgemm_stats(const float* __restrict__ part, int nblk, int len,
                                                        float* __restrict__ stats) {
@@ -347,7 +595,53 @@ int check_common(const char* who, const void* a, int64_t lda, const void* w, int
   return SGF_OK;
 }
 
+template <int MODE>
+int launch_hrow(const HRowArgs& a, int d, hipStream_t st) {
+  const int blocks = grid_blocks(a.n);
+  switch (d) {
+    case 64: hipLaunchKernelGGL((k_hrow_bf16<64, MODE>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((k_hrow_bf16<128, MODE>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((k_hrow_bf16<256, MODE>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
+    default: set_error("hrow: width %d not in {64, 128, 256}", d); return SGF_E_UNSUPPORTED;
+  }
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+bool rows16(const void* p, int64_t ld) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 8 == 0; }
+
 }  // namespace
+
+// ---- internal entry points used by attn.hip (declared in common.h) ----
+bool hrow_supported(int d, int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc,
+                    const void* o, int64_t ldo) {
+  return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) && rows16(a, lda) && (!b || rows16(b, ldb)) &&
+         (!c || rows16(c, ldc)) && rows16(o, ldo);
+}
+
+size_t hrow_partial_bytes(int64_t n, int d) { return static_cast<size_t>((n + 31) / 32) * 32 * static_cast<size_t>(d) * 2; }
+
+int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const float* m, const float* w,
+             const float* beta, void* out, int64_t ldo, float* den, hipStream_t st) {
+  HRowArgs a{static_cast<const uint16_t*>(h), ldh, nullptr, 0, M, 0, m, w, beta, den, static_cast<uint16_t*>(out), ldo,
+             nullptr, n};
+  return launch_hrow<kHF>(a, d, st);
+}
+
+int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den,
+             int64_t n, int d, const float* M, const float* w, const float* Dm, const float* ds, void* dh, int64_t lddh,
+             void* partial, hipStream_t st) {
+  // part = (g M^T) / den - ((g.o) / den^2) w
+  HRowArgs a{static_cast<const uint16_t*>(g), ldg, static_cast<const uint16_t*>(o), ldo, M, 1, w, nullptr, nullptr,
+             const_cast<float*>(den), nullptr, 0, static_cast<uint4*>(partial), n};
+  int rc = launch_hrow<kHB1>(a, d, st);
+  if (rc != SGF_OK) return rc;
+  // dh = h D + ds + part
+  HRowArgs b{static_cast<const uint16_t*>(h), ldh, nullptr, 0, Dm, 0, ds, nullptr, nullptr, nullptr,
+             static_cast<uint16_t*>(dh), lddh, static_cast<uint4*>(partial), n};
+  return launch_hrow<kHB2>(b, d, st);
+}
+
 }  // namespace sgf
 
 using namespace sgf;

@@ -331,10 +331,12 @@ class HipKernels:
         n, d = h.shape
         dev = h.device
         dh = torch.empty((n, d), dtype=h.dtype, device=dev)
+        nb = _lib.load().sgf_attn_h_bwd_apply_workspace_bytes(n, d, _code(h))
+        ws = _workspace(dev, "attn_h_part", nb) if nb else None
         with torch.cuda.device(dev):
             _lib.call("sgf_attn_h_bwd_apply", _ptr(h), _ld(h), _ptr(g), _ld(g), _ptr(o), _ld(o),
                       _ptr(den), n, d, _code(h), _ptr(M), _ptr(w), _ptr(D), _ptr(ds), _ptr(dh),
-                      dh.stride(0), _stream(dev))
+                      dh.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream(dev))
         return dh
 
     # ---- T4: dW = a^T b, db = colsum(a) ----

@@ -78,27 +78,37 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_bf16(
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    for (int s0 = 0; s0 < ks; s0 += 4) {
-      uint4 r1[4], r2[4];
+    // k-steps in batches of 4 (8 loads), the NEXT batch requested before the current one is multiplied
+    constexpr int NB = DP / 64;
+    uint4 r1[2][4], r2[2][4];
+    auto fetch = [&](int bi, uint4 (&q1)[4], uint4 (&q2)[4]) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int s = s0 + u < ks ? s0 + u : ks - 1;
-        r1[u] = *reinterpret_cast<const uint4*>(p1 + 16 * s);
-        r2[u] = *reinterpret_cast<const uint4*>(p2 + 16 * s);
+        const int s = 4 * bi + u < ks ? 4 * bi + u : ks - 1;
+        q1[u] = *reinterpret_cast<const uint4*>(p1 + 16 * s);
+        q2[u] = *reinterpret_cast<const uint4*>(p2 + 16 * s);
       }
+    };
+    fetch(0, r1[0], r2[0]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (s0 + u < ks) {
-          Frag fa;
-          fa.u.x = pack2(a * lo16(r1[u].x) + b * lo16(r2[u].x), a * hi16(r1[u].x) + b * hi16(r2[u].x));
-          fa.u.y = pack2(a * lo16(r1[u].y) + b * lo16(r2[u].y), a * hi16(r1[u].y) + b * hi16(r2[u].y));
-          fa.u.z = pack2(a * lo16(r1[u].z) + b * lo16(r2[u].z), a * hi16(r1[u].z) + b * hi16(r2[u].z));
-          fa.u.w = pack2(a * lo16(r1[u].w) + b * lo16(r2[u].w), a * hi16(r1[u].w) + b * hi16(r2[u].w));
-          const int k0 = 16 * (s0 + u) + 8 * hi;
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wl[i31 * PITCH + k0]);
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&wl[(32 + i31) * PITCH + k0]);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b1, acc1, 0, 0, 0);
+    for (int bi = 0; bi < NB; ++bi) {
+      if (4 * bi < ks) {
+        if (bi + 1 < NB && 4 * (bi + 1) < ks) fetch(bi + 1, r1[(bi + 1) & 1], r2[(bi + 1) & 1]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (4 * bi + u < ks) {
+            const uint4 v1 = r1[bi & 1][u], v2 = r2[bi & 1][u];
+            Frag fa;
+            fa.u.x = pack2(a * lo16(v1.x) + b * lo16(v2.x), a * hi16(v1.x) + b * hi16(v2.x));
+            fa.u.y = pack2(a * lo16(v1.y) + b * lo16(v2.y), a * hi16(v1.y) + b * hi16(v2.y));
+            fa.u.z = pack2(a * lo16(v1.z) + b * lo16(v2.z), a * hi16(v1.z) + b * hi16(v2.z));
+            fa.u.w = pack2(a * lo16(v1.w) + b * lo16(v2.w), a * hi16(v1.w) + b * hi16(v2.w));
+            const int k0 = 16 * (4 * bi + u) + 8 * hi;
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wl[i31 * PITCH + k0]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&wl[(32 + i31) * PITCH + k0]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b0, acc0, 0, 0, 0);
+            if (c > 32) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, b1, acc1, 0, 0, 0);
+          }
         }
       }
     }
@@ -115,80 +125,120 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_bf16(
 }
 
 // dx1 = a (dlogits W), dx2 = b (dlogits W).   d % 32 == 0, d <= 256, C <= 64.
+// 2 [n, d] tensors written, almost nothing read: a store kernel.  Product D[node][feature] (lane = feature, registers =
+// 16 nodes); each wave parks its whole 32 x d result tile in a private LDS patch and writes it back out as complete
+// rows, two rows (1 KiB) per store instruction.  (Storing straight from the accumulator layout — 8- or 16-byte pieces
+// of 32 different rows per instruction — measured 1.2-1.5 ms at N = 2.45 M, d = 256: bound by partial-line writes.)
+constexpr int kHeadBwdThreads = 512;             // 8 waves, one 32-node tile each per trip
+
 template <int DP>
-__global__ __launch_bounds__(kHeadThreads) void k_head_bwd_bf16(
+__global__ __launch_bounds__(kHeadBwdThreads) void k_head_bwd_bf16(
     const float* __restrict__ dl, int64_t lddl, const float* __restrict__ w, int64_t n, int d, int c, float a, float b,
     uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2) {
   constexpr int PITCH = kMaxClasses + 8;           // bf16 elements per LDS row of W^T (+16 B)
-  constexpr int NT = DP / 32;
+  constexpr int HW = DP >= 128 ? DP / 2 : DP;      // features per pass: the tile leaves in two column halves
+  constexpr int NH = DP / HW;                      // passes
+  constexpr int NT = HW / 32;                      // 32-feature strips per pass
+  constexpr int PROW = HW * 2 + 16;                // bytes per row of a wave's result patch (16-byte slots rotate)
+  constexpr int LPR = HW / 8;                      // lanes per row in the read-back (16 B each)
+  constexpr int RPI = 64 / LPR;                    // rows per read-back instruction
+  constexpr int KSMAX = kMaxClasses / 16;
   __shared__ __align__(16) uint16_t wt[DP * PITCH];   // wt[feature][class]
+  __shared__ __align__(16) unsigned char patch_all[(kHeadBwdThreads / 64) * 32 * PROW];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < DP * kMaxClasses; i += kHeadThreads) {
+  for (int i = threadIdx.x; i < DP * kMaxClasses; i += kHeadBwdThreads) {
     const int f = i % DP, cl = i / DP;             // consecutive threads read consecutive features of one class
     const float v = (cl < c && f < d) ? w[static_cast<int64_t>(cl) * d + f] : 0.f;
     wt[f * PITCH + cl] = f32_to_bf16(v);
   }
   __syncthreads();
   const int i31 = lane & 31, hi = lane >> 5;
+  unsigned char* const patch = patch_all + wid * 32 * PROW;
+  unsigned char* const pw = patch + 4 * hi * PROW + 2 * i31;                       // + row * PROW + 64 t
+  const unsigned char* const pr = patch + (lane / LPR) * PROW + 16 * (lane % LPR); // + RPI j * PROW
   const int ks = (c + 15) / 16;
   const int64_t ntiles = (n + 31) / 32;
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wid; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+  constexpr int W = kHeadBwdThreads / 64;
+
+  // A operand of one tile: node i31, classes 16 s + 8 hi .. + 7 (rows of dlogits are C floats: unaligned, scalar loads)
+  auto load_frags = [&](int64_t tile, Frag (&fa)[KSMAX]) {
     int64_t row = tile * 32 + i31;
     if (row >= n) row = n - 1;
     const float* pg = dl + row * lddl;
-    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int s = 0; s < KSMAX; ++s) {
+      if (s < ks) {
+        const int k0 = 16 * s + 8 * hi;
+        float g[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int s = 0; s < ks; ++s) {
-      const int k0 = 16 * s + 8 * hi;
-      float g[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = k0 + j < c ? pg[k0 + j] : 0.f;   // rows of dlogits are C floats: unaligned
-      Frag fb;
-      fb.u.x = pack2(g[0], g[1]);
-      fb.u.y = pack2(g[2], g[3]);
-      fb.u.z = pack2(g[4], g[5]);
-      fb.u.w = pack2(g[6], g[7]);
-      // TRANSPOSED product: D[feature][node] = W^T[feature][class] dlogits^T[class][node].  The W^T fragment is the
-      // A operand (lane: one feature, 8 classes), the dlogits fragment the B operand (lane: node i31, the same 8
-      // classes), so in the result a lane holds 16 features of ITS node.  WHICH features is ours to choose (the rows
-      // of the A operand can be any 32 features): MFMA row 8 q + 4 h + j of strip t is feature (DP / 2) h + 16 t + 4 q + j,
-      // which makes accumulator register r of lane (node, hi) feature (DP / 2) hi + 16 t + r — 16 consecutive ones,
-      // two 16-byte stores (the natural order gives four separate runs of 4: 8-byte stores, and this kernel is bound
-      // by the NUMBER of partial-line writes the L2 accepts, ~260 G/s, not by bytes).
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int feat = (DP / 2) * ((i31 >> 2) & 1) + 16 * t + 4 * (i31 >> 3) + (i31 & 3);
-        const bf16x8 at = *reinterpret_cast<const bf16x8*>(&wt[feat * PITCH + k0]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, fb.v, acc[t], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) g[j] = k0 + j < c ? pg[k0 + j] : 0.f;
+        fa[s].u.x = pack2(g[0], g[1]);
+        fa[s].u.y = pack2(g[2], g[3]);
+        fa[s].u.z = pack2(g[4], g[5]);
+        fa[s].u.w = pack2(g[6], g[7]);
       }
     }
-    const int64_t orow = tile * 32 + i31;
-    if (orow < n) {
+  };
+
+  Frag cur[KSMAX], nxt[KSMAX];
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * W + wid;
+  const int64_t step = static_cast<int64_t>(gridDim.x) * W;
+  if (tile < ntiles) load_frags(tile, cur);
+  for (; tile < ntiles; tile += step) {
+    if (tile + step < ntiles) load_frags(tile + step, nxt);        // in flight while this tile is multiplied and stored
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+    for (int h = 0; h < NH; ++h) {
+      if (HW * h >= d) break;
+      f32x16 acc[NT];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int f0 = (DP / 2) * hi + 16 * t + 8 * q;
-          if (f0 < d) {                                      // d % 8 == 0; features >= d are zero padding
-            uint4 o1, o2;
-            o1.x = pack2(a * acc[t][8 * q + 0], a * acc[t][8 * q + 1]);
-            o1.y = pack2(a * acc[t][8 * q + 2], a * acc[t][8 * q + 3]);
-            o1.z = pack2(a * acc[t][8 * q + 4], a * acc[t][8 * q + 5]);
-            o1.w = pack2(a * acc[t][8 * q + 6], a * acc[t][8 * q + 7]);
-            o2.x = pack2(b * acc[t][8 * q + 0], b * acc[t][8 * q + 1]);
-            o2.y = pack2(b * acc[t][8 * q + 2], b * acc[t][8 * q + 3]);
-            o2.z = pack2(b * acc[t][8 * q + 4], b * acc[t][8 * q + 5]);
-            o2.w = pack2(b * acc[t][8 * q + 6], b * acc[t][8 * q + 7]);
-            *reinterpret_cast<uint4*>(dx1 + orow * ld1 + f0) = o1;
-            *reinterpret_cast<uint4*>(dx2 + orow * ld2 + f0) = o2;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KSMAX; ++s) {
+        if (s < ks) {
+          const int k0 = 16 * s + 8 * hi;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {                            // B operand: feature HW h + 32 t + i31, the same classes
+            const bf16x8 bt = *reinterpret_cast<const bf16x8*>(&wt[(HW * h + 32 * t + i31) * PITCH + k0]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s].v, bt, acc[t], 0, 0, 0);
           }
         }
       }
+      // accumulator register r of lane (i31, hi): node (r & 3) + 8 (r >> 2) + 4 hi, feature HW h + 32 t + i31
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float sc = which == 0 ? a : b;
+        uint16_t* const dst = which == 0 ? dx1 : dx2;
+        const int64_t ld = which == 0 ? ld1 : ld2;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const uint32_t v = pack2(sc * acc[t][r], sc * acc[t][r + 1]);
+            const int rl = (r & 3) + 8 * (r >> 2);
+            *reinterpret_cast<uint16_t*>(pw + rl * PROW + 64 * t) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(pw + (rl + 1) * PROW + 64 * t) = static_cast<uint16_t>(v >> 16);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int fcol = HW * h + 8 * (lane % LPR);
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pr + RPI * j * PROW);
+          const int64_t orow = tile * 32 + RPI * j + lane / LPR;
+          if (fcol < d && orow < n) *reinterpret_cast<uint4*>(dst + orow * ld + fcol) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
+#pragma unroll
+    for (int s = 0; s < KSMAX; ++s) cur[s] = nxt[s];
   }
 }
 
@@ -252,7 +302,9 @@ extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const floa
                   reinterpret_cast<uintptr_t>(dx1) % 16 == 0 && reinterpret_cast<uintptr_t>(dx2) % 16 == 0,
               SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 16-byte aligned, ld %% 8 == 0)");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(head_grid(n)), block(kHeadThreads);
+  int64_t nb = ((n + 31) / 32 + kHeadBwdThreads / 64 - 1) / (kHeadBwdThreads / 64);
+  if (nb > kNumCU) nb = kNumCU;
+  const dim3 grid(static_cast<unsigned>(nb)), block(kHeadBwdThreads);
 #define SGF_HEAD_BWD(DP_)                                                                                   \
   hipLaunchKernelGGL((k_head_bwd_bf16<DP_>), grid, block, 0, st, dlogits, lddl, w, n, d, classes, a, b,       \
                      static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2)

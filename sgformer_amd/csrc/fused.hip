@@ -99,6 +99,84 @@ __global__ __launch_bounds__(kThreads) void k_ln_fwd(
   }
 }
 
+// bf16 rows of d = 8 * LPR elements, 16-byte aligned: 16 bytes per lane and load, R independent rows per lane in flight
+// (the generic kernel above has one 8-byte load per lane outstanding while it reduces a row: latency-bound, 3.1-3.9 TB/s
+// at d = 256).  Column of a lane is fixed, so gamma / beta live in registers.
+template <int LPR, int R>
+__global__ __launch_bounds__(kThreads) void k_ln_fwd_bf16x8(
+    const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ res, int64_t ldr, float a, float b,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, float eps, int64_t n,
+    uint16_t* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd) {
+  constexpr int RPS = kThreads / LPR;                 // rows per slot of the block
+  constexpr int RPB = RPS * R;
+  constexpr float inv_d = 1.0f / static_cast<float>(8 * LPR);
+  const int sl = threadIdx.x % LPR;
+  const int sr = threadIdx.x / LPR;
+  const int col = sl * 8;
+  float g[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    g[e] = gamma ? gamma[col + e] : 1.f;
+    be[e] = gamma ? beta[col + e] : 0.f;
+  }
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * RPB; row0 < n; row0 += static_cast<int64_t>(gridDim.x) * RPB) {
+    uint4 xv[R], rv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int64_t row = row0 + q * RPS + sr;
+      const int64_t rr = row < n ? row : n - 1;
+      xv[q] = *reinterpret_cast<const uint4*>(x + rr * ldx + col);
+      if (res) rv[q] = *reinterpret_cast<const uint4*>(res + rr * ldr + col);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int64_t row = row0 + q * RPS + sr;
+      const uint32_t xu[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = a * __uint_as_float(xu[e] << 16);
+        v[2 * e + 1] = a * __uint_as_float(xu[e] & 0xffff0000u);
+      }
+      if (res) {
+        const uint32_t ru[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = fmaf(b, __uint_as_float(ru[e] << 16), v[2 * e]);
+          v[2 * e + 1] = fmaf(b, __uint_as_float(ru[e] & 0xffff0000u), v[2 * e + 1]);
+        }
+      }
+      float mu = 0.f, rs = 1.f;
+      if (gamma) {
+        float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        mu = group_sum<LPR>(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq = fmaf(v[e] - mu, v[e] - mu, sq);
+        rs = 1.0f / sqrtf(group_sum<LPR>(sq) * inv_d + eps);
+        if (sl == 0 && row < n) {
+          mean[row] = mu;
+          rstd[row] = rs;
+        }
+      }
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = gamma ? (v[e] - mu) * rs * g[e] + be[e] : v[e];
+        if (relu) o[e] = fmaxf(o[e], 0.f);
+      }
+      if (row < n) {
+        uint4 ov;
+        ov.x = static_cast<uint32_t>(f32_to_bf16(o[0])) | (static_cast<uint32_t>(f32_to_bf16(o[1])) << 16);
+        ov.y = static_cast<uint32_t>(f32_to_bf16(o[2])) | (static_cast<uint32_t>(f32_to_bf16(o[3])) << 16);
+        ov.z = static_cast<uint32_t>(f32_to_bf16(o[4])) | (static_cast<uint32_t>(f32_to_bf16(o[5])) << 16);
+        ov.w = static_cast<uint32_t>(f32_to_bf16(o[6])) | (static_cast<uint32_t>(f32_to_bf16(o[7])) << 16);
+        *reinterpret_cast<uint4*>(y + row * ldy + col) = ov;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  Per-block partial dgamma/dbeta: part[blk][2][d].
 // ------------------------------------------------------------------------------------------------
@@ -540,6 +618,49 @@ __global__ __launch_bounds__(kThreads) void k_sum_n(SumArgs a, int64_t n, int d,
   }
 }
 
+// bf16 operands whose rows are 16-byte aligned: 8 elements per lane and load (an 8-byte-per-lane load runs at 0.54-0.70x
+// the rate of a 16-byte one on this part, MI355X_MICROARCH.md), all K loads in flight before the first add.  Same
+// summation order as k_sum_n: bitwise the same result.
+template <int K>
+__global__ __launch_bounds__(kThreads) void k_sum_n_bf16x8(SumArgs a, int64_t n, int d, uint16_t* __restrict__ y,
+                                                           int64_t ldy) {
+  const int f8 = d / 8;
+  const int64_t total = n * f8;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / f8;
+    const int col = static_cast<int>(i % f8) * 8;
+    uint4 v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      v[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.x[j]) + row * a.ld[j] + col);
+    float s[8];
+    {
+      const uint32_t u[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[2 * e] = __uint_as_float(u[e] << 16);
+        s[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+      const uint32_t u[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[2 * e] += __uint_as_float(u[e] << 16);
+        s[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+      }
+    }
+    uint4 o;
+    o.x = static_cast<uint32_t>(f32_to_bf16(s[0])) | (static_cast<uint32_t>(f32_to_bf16(s[1])) << 16);
+    o.y = static_cast<uint32_t>(f32_to_bf16(s[2])) | (static_cast<uint32_t>(f32_to_bf16(s[3])) << 16);
+    o.z = static_cast<uint32_t>(f32_to_bf16(s[4])) | (static_cast<uint32_t>(f32_to_bf16(s[5])) << 16);
+    o.w = static_cast<uint32_t>(f32_to_bf16(s[6])) | (static_cast<uint32_t>(f32_to_bf16(s[7])) << 16);
+    *reinterpret_cast<uint4*>(y + row * ldy + col) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dropout (F.dropout in large/ours.py:81,92,202,216), fused with the residual add that follows it in
 // GraphConv (:92-93) and WITHOUT a stored mask: the keep decisions are a pure function of
@@ -761,6 +882,28 @@ template <typename T>
 int ln_fwd_t(const void* x, int64_t ldx, const void* res, int64_t ldr, float a, float b,
              const float* gamma, const float* beta, int relu, float eps, int64_t n, int d, void* y,
              int64_t ldy, float* mean, float* rstd, hipStream_t st) {
+  if (sizeof(T) == 2 && (d == 64 || d == 128 || d == 256 || d == 512) && ldx % 8 == 0 && ldy % 8 == 0 &&
+      (!res || ldr % 8 == 0) && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+      (!res || reinterpret_cast<uintptr_t>(res) % 16 == 0)) {
+    constexpr int R = 4;
+    const int l8 = d / 8;
+    const int rpb = kThreads / l8 * R;
+    int64_t nb = (n + rpb - 1) / rpb;
+    if (nb > static_cast<int64_t>(kNumCU) * 8) nb = static_cast<int64_t>(kNumCU) * 8;
+    const dim3 grid(static_cast<unsigned>(nb < 1 ? 1 : nb));
+    const uint16_t* x16 = static_cast<const uint16_t*>(x);
+    const uint16_t* r16 = static_cast<const uint16_t*>(res);
+    uint16_t* y16 = static_cast<uint16_t*>(y);
+#define SGF_LN8(L) hipLaunchKernelGGL((k_ln_fwd_bf16x8<L, R>), grid, dim3(kThreads), 0, st, x16, ldx, r16, ldr, a, b, \
+                                      gamma, beta, relu, eps, n, y16, ldy, mean, rstd)
+    if (l8 == 8) SGF_LN8(8);
+    else if (l8 == 16) SGF_LN8(16);
+    else if (l8 == 32) SGF_LN8(32);
+    else SGF_LN8(64);
+#undef SGF_LN8
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int lpr = lanes_per_row(d);
   const int nc = (d + 4 * lpr - 1) / (4 * lpr);
   return launch_ln_fwd<T>(lpr, nc, dim3(ln_grid(n, lpr)), st, static_cast<const T*>(x), ldx,
@@ -1023,6 +1166,20 @@ extern "C" int sgf_sum_n(const void* const* xs, const int64_t* lds, int32_t k, i
   }
   SGF_REQUIRE(ldy % 4 == 0, SGF_E_INVALID, "sgf_sum_n: bad ldy");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  bool wide = dtype == SGF_BF16 && d % 8 == 0 && ldy % 8 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  for (int j = 0; j < k && wide; ++j) wide = lds[j] % 8 == 0 && reinterpret_cast<uintptr_t>(xs[j]) % 16 == 0;
+  if (wide) {
+    const dim3 grid8(ew_grid(n * (d / 8)));
+    uint16_t* y16 = static_cast<uint16_t*>(y);
+    switch (k) {
+#define SGF_SUM_CASE(K_) case K_: hipLaunchKernelGGL((k_sum_n_bf16x8<K_>), grid8, dim3(kThreads), 0, st, a, n, d, y16, ldy); break;
+      SGF_SUM_CASE(1) SGF_SUM_CASE(2) SGF_SUM_CASE(3) SGF_SUM_CASE(4) SGF_SUM_CASE(5) SGF_SUM_CASE(6) SGF_SUM_CASE(7)
+      SGF_SUM_CASE(8)
+#undef SGF_SUM_CASE
+    }
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const dim3 grid(ew_grid(n * (d / 4)));
   if (dtype == SGF_F32)
     hipLaunchKernelGGL((k_sum_n<float>), grid, dim3(kThreads), 0, st, a, n, d, static_cast<float*>(y), ldy);

@@ -195,6 +195,12 @@ class SpmmTimer:
                 "gather_GBps": round(gat / (mean_ms * 1e-3) / 1e9, 1)}
 
 
+def _sharded(world: int) -> bool:
+    """Node-sharded path: always for N > 1; for N = 1 only when a test asks for it (SGF_BENCH_FORCE_SHARD=1 under
+    torch.distributed.run: the RCCL init, the ShardContext and every collective of the step with a single rank)."""
+    return world > 1 or (os.environ.get("SGF_BENCH_FORCE_SHARD") == "1" and "MASTER_PORT" in os.environ)
+
+
 def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev, graph: str = "uniform"):
     """Synthetic inputs of one rank (host x / y / train_idx, edge_index on `dev`) and its ShardContext.
     Strong-scaling workloads: every rank generates the SAME global graph and task and keeps its rows.
@@ -211,14 +217,14 @@ def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev
         ei = synth.synthetic_graph_shard(n_per, avg_deg, rank, world, seed=seed, device=dev)
         x, y, train_idx = synth.synthetic_task(n_per, f, c, seed=seed + 7919 * rank)
         n_train = train_idx.numel() * world
-        if world > 1:
+        if _sharded(world):
             ctx = ShardContext(n, local_edges=True)
     else:
         gen = synth.synthetic_graph_community if graph == "community" else synth.synthetic_graph
         ei = gen(n, avg_deg, seed=seed, device=dev)
         x, y, train_idx = synth.synthetic_task(n, f, c, seed=seed)
         n_train = train_idx.numel()
-        if world > 1:
+        if _sharded(world):
             ctx = ShardContext(n)
             x, y, train_idx = ctx.shard_rows(x), ctx.shard_rows(y), ctx.local_index(train_idx)
     return n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx
@@ -276,7 +282,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
 
         def fence():
             torch.cuda.synchronize()
-            if world > 1:
+            if _sharded(world):
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -289,7 +295,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
         elapsed = time.perf_counter() - t0
         timer.active = False   # (the extra ATen-loss steps below are not part of the roofline sample)
         loss_val = float(loss.detach())
-        if world > 1:
+        if _sharded(world):
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t)
@@ -348,7 +354,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_sample_nodes, args.seed)
 
-    if world > 1:
+    if _sharded(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -397,7 +403,7 @@ def main():
         if cpu is not None:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if _sharded(world):
         dist.destroy_process_group()
 
 

@@ -79,3 +79,34 @@ def test_sharded_step_over_rccl(kind):
         e = ret[rank]
         assert e["logits"] < 1e-4 and e["grad"] < 2e-3, e
         assert (e["halo_sent"] > 0 and e["gathered"] == 0) if kind == "halo" else e["gathered"] > 0, e
+
+
+@pytest.mark.parametrize("kind", ["halo", "allgather"])
+def test_sharded_step_single_rank_over_rccl(kind):
+    """The same sharded step with ONE rank: every collective of the path (all-reduce of the attention partials and
+    statistics, the halo all_to_all_single / all-gather, the gradient sync) goes through a real RCCL communicator on
+    the 1-GPU test box — degenerate exchanges, but the calls, dtypes, devices and split lists are the ones the
+    multi-GPU run issues.  Parity as above."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(1, _free_port(), kind, ret), nprocs=1, join=True)
+    e = ret[0]
+    assert e["logits"] < 1e-4 and e["grad"] < 2e-3, e
+
+
+def test_bench_under_torchrun_single_rank(tmp_path):
+    """bench.py the way the driver launches it for N > 1 (torch.distributed.run, RCCL init, node-sharded model),
+    with N = 1 on a small graph: one JSON line with the contract's keys."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGF_BENCH_FORCE_SHARD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--nodes", "20000", "--no-cpu-baseline", "--no-structured"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["value"] > 0

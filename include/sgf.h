@@ -434,6 +434,11 @@ int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw
  *                                of a library GEMM with beta = 1 on the rounded first product.
  * W1 / W2 are passed as pointers into W with ldw = 2 d.  5 [n, d] passes in total where
  * GEMM + GEMM(beta = 1) + sgf_colstats take 6. */
+/* the other half of the layer (SURVEY.md §7 K8 "gcn_epilogue_apply"): BN normalise -> ReLU -> + residual, one
+ * elementwise pass; the same entry as sgf_bn_apply under the name the layer-level API uses */
+int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const void* res, int64_t ldr, int32_t relu, int64_t n, int32_t d,
+                           int32_t dtype, void* out, int64_t ldo, void* stream);
 size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out);
 int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t n,
                              int32_t d_in, int32_t d_out, int32_t dtype, void* partial, size_t partial_bytes,

@@ -1,6 +1,6 @@
 """Per-kernel achieved bandwidth from a `rocprofv3 --kernel-trace --stats` CSV of bench.py.
 
-    python scripts/kernel_roofline.py profiles/r01_products_bf16_kernel_stats.csv > profiles/r01_products_bf16_kernel_roofline.md
+    python scripts/kernel_roofline.py profiles/r02_products_bf16_kernel_stats.csv > profiles/r02_products_bf16_kernel_roofline.md
 
 Every kernel of the step streams whole [N, d] activation tensors; its ALGORITHMIC bytes are the number
 of such tensors it must read + write (DESIGN.md §3 column "algorithmic bytes") times T = N*d*s.  The
@@ -28,40 +28,70 @@ def main(path: str, elem: int):
                 return float(r["AverageNs"]) / 1e3, int(r["Calls"])
         return None, 0
 
+    def find_full(*subs):
+        """Kernels that ops.linear_bn_stats also launches on a 1024-row sample (for BatchNorm's shift) appear twice
+        per layer: the full-size launch is (total - the ~12 us sample launches) / (calls / 2)."""
+        for r in rows:
+            if all(s in r["Name"] for s in subs):
+                calls = int(r["Calls"]) // 2
+                return (float(r["TotalDurationNs"]) / 1e3 - 12.0 * calls) / calls, calls
+        return None, 0
+
     csr = (NNZ * 8 + (N + 1) * 8) / 1e9
     gather = (NNZ * (8 + D * elem) + (N + 1) * 8) / 1e9 + T     # every stored entry fetches one X row
+    spmm_name = "k_spmm_row<" if find("k_spmm_row<" + tname)[0] else "k_spmm_wave<"
+    spmm_us = find(spmm_name + tname)[0]
     table = [
-        ("k_spmm_wave", ("k_spmm_wave<" + tname,), csr + 2 * T,
-         "gather-bound: {:.1f} GB of {}-B row fetches per launch = {:.1f} TB/s (r01_spmm_pmc.md)".format(
-             gather, D * elem, gather / (find("k_spmm_wave<" + tname)[0] * 1e-6) / 1e3)),
-        ("k_reduce_bf16<256,Gram,16>  (sgf_gram: G, dW)", ("k_reduce_bf16<256, 2, 16>",), 2 * T, "reads 2 tensors"),
-        ("k_reduce_bf16<256,BwdH,8>", ("k_reduce_bf16<256, 3, 8>",), 3 * T, "reads h, out, dout"),
-        ("k_apply_bf16<256,HFwd>", ("k_apply_bf16<256, 4, 2>",), 2 * T, "h -> out"),
-        ("k_apply_bf16<256,HBwd1>", ("k_apply_bf16<256, 5, 2>",), 3 * T, ""),
-        ("k_apply_bf16<256,HBwd2>", ("k_apply_bf16<256, 6, 2>",), 3 * T, ""),
+        (spmm_name.rstrip("<"), (spmm_name + tname,), csr + 2 * T,
+         "gather-bound: {:.1f} GB of {}-B row fetches per launch = {:.1f} TB/s".format(
+             gather, D * elem, gather / (spmm_us * 1e-6) / 1e3) if spmm_us else "", find),
+        ("k_reduce_bf16<256,Gram,16>  (sgf_gram: G, dW)", ("k_reduce_bf16<256, 2, 16>",), 2 * T, "reads 2 tensors", find),
+        ("k_reduce_bf16<256,BwdH,8>", ("k_reduce_bf16<256, 3, 8>",), 3 * T, "reads h, out, dout", find),
+        ("k_apply_bf16<256,HFwd>", ("k_apply_bf16<256, 4, 2>",), 2 * T, "h -> out", find),
+        ("k_apply_bf16<256,HBwd1>", ("k_apply_bf16<256, 5, 2>",), 3 * T, "", find),
+        ("k_apply_bf16<256,HBwd2>", ("k_apply_bf16<256, 6, 2>",), 3 * T, "", find),
+        ("k_hrow_bf16<256,F>  (sgf_attn_h_fwd)", ("k_hrow_bf16<256, 0>",), 2 * T, "h -> out, den", find),
+        ("k_hrow_bf16<256,B1>  (sgf_attn_h_bwd_apply, pass 1)", ("k_hrow_bf16<256, 1>",), 3 * T,
+         "reads g, out; writes the partial", find),
+        ("k_hrow_bf16<256,B2>  (sgf_attn_h_bwd_apply, pass 2)", ("k_hrow_bf16<256, 2>",), 3 * T,
+         "reads h, the partial; writes dh", find),
+        ("k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx)", ("k_rowgemm_bf16<256, false, 0, 0>",), 2 * T, "dy -> dx", find),
+        ("k_rowgemm_bf16<256,IO 1>  (sgf_gcn_epilogue_partial)", ("k_rowgemm_bf16<256, false, 1, 0>",), 2 * T,
+         "a1 -> partial; full-size launches only", find_full),
+        ("k_rowgemm_bf16<256,stats,IO 2>  (sgf_gcn_epilogue_stats_add)", ("k_rowgemm_bf16<256, true, 2, 0>",), 3 * T,
+         "a2, partial -> y + BatchNorm sums; full-size launches only", find_full),
         ("k_attn_reduce<float,256,Gram>  (sgf_gram: G, dW; exact-fp32 MFMA)", ("k_attn_reduce<float, 256, 2>",), 2 * T,
-         "MFMA-bound: 2*N*d^2 flop at the 157 TF fp32 MFMA peak = 2.0 ms"),
-        ("k_attn_reduce<float,256,BwdH>", ("k_attn_reduce<float, 256, 3>",), 3 * T, "MFMA-bound"),
-        ("k_attn_apply<float,256,HFwd>", ("k_attn_apply<float, 256, 4>",), 2 * T, "MFMA-bound"),
-        ("k_attn_apply<float,256,HBwd1>", ("k_attn_apply<float, 256, 5>",), 3 * T, "MFMA-bound"),
-        ("k_attn_apply<float,256,HBwd2>", ("k_attn_apply<float, 256, 6>",), 3 * T, "MFMA-bound"),
-        ("k_ln_fwd", ("k_ln_fwd<" + tname,), 2.5 * T, "mean of stem (2T) and post-attention (3T) calls"),
-        ("k_ln_bwd", ("k_ln_bwd<" + tname,), 4.5 * T, "mean of stem (4T) and post-attention (5T) calls"),
-        ("k_bn_apply", ("k_bn_apply<" + tname,), 2.75 * T, "stem 2T, layers 3T (residual)"),
-        ("k_colreduce<BnBwdStats>", ("BnBwdStatsF<" + tname,), 2 * T, ""),
-        ("k_bn_bwd_apply", ("k_bn_bwd_apply<" + tname,), 3 * T, ""),
-        ("k_sum_n (7 operands)", ("k_sum_n<" + tname,), 8 * T, "fan-out hub gradient"),
-        ("k_axpby", ("k_axpby<" + tname,), 3 * T, ""),
-        ("hipBLASLt [N,256]x[256,256] (Y = XW^T)", ("Cijk_Alik_Bljk", "MT256x256x32"), 2 * T, "library GEMM, HBM-bound shape"),
-        ("hipBLASLt [N,256]x[256,256] (dX = dY W)", ("Cijk_Ailk_Bljk", "MT256x256x32"), 2 * T, "library GEMM"),
+         "MFMA-bound: 2*N*d^2 flop at the 157 TF fp32 MFMA peak = 2.0 ms", find),
+        ("k_attn_reduce<float,256,BwdH>", ("k_attn_reduce<float, 256, 3>",), 3 * T, "MFMA-bound", find),
+        ("k_attn_apply<float,256,HFwd>", ("k_attn_apply<float, 256, 4>",), 2 * T, "MFMA-bound", find),
+        ("k_attn_apply<float,256,HBwd1>", ("k_attn_apply<float, 256, 5>",), 3 * T, "MFMA-bound", find),
+        ("k_attn_apply<float,256,HBwd2>", ("k_attn_apply<float, 256, 6>",), 3 * T, "MFMA-bound", find),
+        ("k_ln_fwd", ("k_ln_fwd<" + tname,), 2.5 * T, "mean of stem (2T) and post-attention (3T) calls", find),
+        ("k_ln_fwd_bf16x8", ("k_ln_fwd_bf16x8<",), 2.5 * T, "mean of stem (2T) and post-attention (3T) calls", find),
+        ("k_ln_bwd", ("k_ln_bwd<" + tname,), 4.5 * T, "mean of stem (4T) and post-attention (5T) calls", find),
+        ("k_bn_apply", ("k_bn_apply<" + tname,), 2.75 * T, "stem 2T, layers 3T (residual)", find),
+        ("k_colreduce<BnBwdStats>", ("BnBwdStatsF<" + tname,), 2 * T, "", find),
+        ("k_bn_bwd_apply", ("k_bn_bwd_apply<" + tname,), 3 * T, "", find),
+        ("k_sum_n (7 operands)", ("k_sum_n<" + tname,), 8 * T, "fan-out hub gradient", find),
+        ("k_sum_n_bf16x8<7>", ("k_sum_n_bf16x8<7>",), 8 * T, "fan-out hub gradient", find),
+        ("k_head_fwd_bf16  (sgf_combine_fc_fwd)", ("k_head_fwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "x1, x2 -> logits", find),
+        ("k_head_bwd_bf16  (sgf_combine_fc_bwd)", ("k_head_bwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "dlogits -> dx1, dx2", find),
+        ("k_axpby", ("k_axpby<" + tname,), 3 * T, "", find),
     ]
+    if find("k_rowgemm_bf16<")[0]:    # r02 on: the square layers run on k_rowgemm_bf16, the library keeps the two input stems
+        table.append(("hipBLASLt [N,100]x[100,256]  (the two input stems)", ("Cijk_Alik_Bljk", "MT256x256x32"),
+                      N * (100 + 256) * elem / 1e9, "library GEMM (rows of 100 elements are not 16-byte aligned)", find))
+    else:
+        table.append(("hipBLASLt [N,256]x[256,256] (Y = XW^T)", ("Cijk_Alik_Bljk", "MT256x256x32"), 2 * T,
+                      "library GEMM, HBM-bound shape", find))
+        table.append(("hipBLASLt [N,256]x[256,256] (dX = dY W)", ("Cijk_Ailk_Bljk", "MT256x256x32"), 2 * T, "library GEMM", find))
     print(f"# Per-kernel achieved bandwidth — {path.split('/')[-1]}\n")
     print(f"ogbn-products shape: N = {N:,}, d = {D}, {elem}-byte activations, T = N*d*s = {T:.3f} GB.  "
           f"Generated by `python scripts/kernel_roofline.py {path}`.\n")
     print("| kernel | calls | avg us | algorithmic GB | GB/s | of 8 TB/s spec | of 6.3 TB/s copy | note |")
     print("|---|---|---|---|---|---|---|---|")
-    for name, subs, gb, note in table:
-        us, calls = find(*subs)
+    for name, subs, gb, note, finder in table:
+        us, calls = finder(*subs)
         if us is None:
             continue
         bw = gb / (us * 1e-6)

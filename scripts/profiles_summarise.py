@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Turn one run of scripts/collect_profiles.sh (gpurun_out/r2_profiles/) into the tracked summaries under profiles/:
+
+    python scripts/profiles_summarise.py gpurun_out/r2_profiles r02
+
+  <tag>_products_bf16_kernel_stats.{csv,md}            rocprofv3 --kernel-trace --stats of bench.py, uniform graph
+  <tag>_products_community_bf16_kernel_stats.{csv,md}  the same on the community graph
+  <tag>_products_bf16_kernel_roofline.md               scripts/kernel_roofline.py over the uniform-graph statistics
+  <tag>_mfma_sq_counters.csv / <tag>_mfma_sq_summary.md  MFMA / SQ counters of the matrix-core kernels of one step
+"""
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+from collections import defaultdict
+
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS_IN_TRACE = 13     # bench.py --steps 5 --warmup 2: 2 + 5 + 1 + 5 (the ATen-loss leg)
+
+
+def short(name):
+    for pre in ("void sgf::(anonymous namespace)::", "sgf::(anonymous namespace)::", "void at::native::"):
+        name = name.replace(pre, "")
+    return name.replace("sgf::(anonymous namespace)::", "")
+
+
+def kernel_stats(src_dir, log, graph, out_base):
+    rows = list(csv.DictReader(open(os.path.join(src_dir, "b_kernel_stats.csv"))))
+    shutil.copy(os.path.join(src_dir, "b_kernel_stats.csv"), out_base + ".csv")
+    line = [ln for ln in open(log) if ln.startswith("{")]
+    bench = line[-1].strip() if line else "(bench line not captured)"
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    tab = pd.DataFrame([{"Name": short(r["Name"])[:86], "Calls": int(r["Calls"]),
+                         "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                         "ms_per_step": round(float(r["TotalDurationNs"]) / 1e6 / STEPS_IN_TRACE, 3),
+                         "Percentage": round(100 * float(r["TotalDurationNs"]) / total, 4)} for r in rows[:48]])
+    with open(out_base + ".md", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --graph {graph} --steps 5 --warmup 2 "
+                f"--no-cpu-baseline --no-structured` (MI355X, bf16)\n\n")
+        f.write(f"{STEPS_IN_TRACE} training steps are in the trace (2 warm-up + 5 timed + 1 + 5 with the trainer's ATen loss ops) "
+                "plus the one-off graph preparation\n(CSR build, `sgf_reorder`, `sgf_spmm_plan`: the rocPRIM / k_vote_* / "
+                f"k_keys* rows).  `ms_per_step` = total / {STEPS_IN_TRACE}; all kernels together: "
+                f"{total / 1e6 / STEPS_IN_TRACE:.2f} ms per step.\n\n")
+        f.write(f"bench line of the profiled run: `{bench[:1400]} ...`\n\n")
+        f.write(tab.to_markdown(index=False) + "\n")
+
+
+def counters(src, tag):
+    agg = defaultdict(lambda: defaultdict(list))
+    for sub in ("mfma1", "mfma2"):
+        path = os.path.join(src, sub, "m_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        for r in csv.DictReader(open(path)):
+            agg[short(r["Kernel_Name"]).split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = sorted({c for k in agg.values() for c in k})
+    rows = []
+    for k, cs in sorted(agg.items()):
+        row = {"k": k}
+        for c in names:
+            v = cs.get(c, [])
+            row[c] = sum(v) / len(v) if v else float("nan")
+        rows.append(row)
+    df = pd.DataFrame(rows)
+    df.to_csv(os.path.join(ROOT, "profiles", f"{tag}_mfma_sq_counters.csv"), index=False)
+    m = df[(df.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0) | (df.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) > 0)].copy()
+    m["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["SQ_BUSY_CYCLES"] / 32 * 1024)
+    m["wait_any_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    m["issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+    cols = ["k", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "mfma_busy_frac",
+            "wait_any_frac", "issue_stall_frac"]
+    for c in cols[1:]:
+        m[c] = m[c].map(lambda v: float(f"{v:.3g}"))
+    with open(os.path.join(ROOT, "profiles", f"{tag}_mfma_sq_summary.md"), "w") as f:
+        f.write(f"# {tag} — MFMA-busy / SQ counters of the matrix-core kernels in one training step (MI355X, bf16, "
+                "ogbn-products shape)\n\n")
+        f.write("`rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 "
+                "SQ_VALU_MFMA_BUSY_CYCLES -- python bench.py --steps 2 --warmup 1 ...`\nand a second pass with "
+                "`SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY` "
+                "(scripts/collect_profiles.sh, summarised by scripts/profiles_summarise.py); means per dispatch.\n"
+                "`mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs): the share "
+                "of SIMD-time the matrix pipe is busy\n(rocprofv3's MfmaUtil formula).  `wait_any_frac` / `issue_stall_frac` = "
+                "SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES.\n\n")
+        f.write(m[cols].to_markdown(index=False) + "\n\n")
+        f.write("Reading: every MFMA kernel of the bf16 step is HBM-bound by design (DESIGN.md §3: 2 N d^2 flop per [N, d] pass at "
+                "2.5 PF is 0.13 ms against 0.4-0.6 ms of HBM time), so the matrix pipe is busy 5-30 % of the time.  The per-wave "
+                "streaming kernels of csrc/rowgemm.hip (`k_rowgemm_bf16`, `k_hrow_bf16`) and the 16-wave Gram reduce carry the "
+                "same MFMA count per byte as hipBLASLt's GEMM did and finish sooner (profiles/"
+                f"{tag}_products_bf16_kernel_roofline.md), i.e. their matrix pipe is busier; `k_reduce_bf16<256, 3, 8>` "
+                "(the three-stream attention backward reduce, 8 waves x 238 VGPRs, one staging pass in flight) is the one "
+                f"left waiting.  Full table: profiles/{tag}_mfma_sq_counters.csv.\n")
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    prof = os.path.join(ROOT, "profiles")
+    kernel_stats(os.path.join(src, "bench_uniform"), os.path.join(src, "bench_uniform.log"), "uniform",
+                 os.path.join(prof, f"{tag}_products_bf16_kernel_stats"))
+    kernel_stats(os.path.join(src, "bench_community"), os.path.join(src, "bench_community.log"), "community",
+                 os.path.join(prof, f"{tag}_products_community_bf16_kernel_stats"))
+    md = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kernel_roofline.py"),
+                         os.path.join("profiles", f"{tag}_products_bf16_kernel_stats.csv")], capture_output=True, text=True,
+                        cwd=ROOT, check=True).stdout
+    open(os.path.join(prof, f"{tag}_products_bf16_kernel_roofline.md"), "w").write(md)
+    counters(src, tag)
+    js = os.path.join(src, "spmm_pmc.json")
+    if os.path.exists(js):
+        shutil.copy(js, os.path.join(prof, f"{tag}_spmm_pmc.json"))
+        print(json.dumps({k: v for k, v in json.load(open(js)).items()})[:400])
+
+
+if __name__ == "__main__":
+    main()

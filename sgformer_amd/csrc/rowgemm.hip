@@ -742,3 +742,11 @@ extern "C" int sgf_gcn_epilogue_stats_add(const void* a, int64_t lda, const void
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }
+
+extern "C" int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, const void* res, int64_t ldr,
+                                      int32_t relu, int64_t n, int32_t d, int32_t dtype, void* out, int64_t ldo,
+                                      void* stream) {
+  SGF_REQUIRE(n <= 0 || (y && mean && rstd && out), SGF_E_INVALID, "sgf_gcn_epilogue_apply: null pointer");
+  return sgf_bn_apply(y, ldy, mean, rstd, gamma, beta, res, ldr, relu, n, d, dtype, out, ldo, stream);
+}

@@ -1011,7 +1011,9 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
     const bool pair_ok = sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
                          reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
-    const int chunk = 4096 / (kWavesPerBlock * kSegRows);   // one XCD walks ~4096 consecutive rows at a time
+    int chunk_rows = 4096;                                   // one XCD walks ~4096 consecutive rows at a time
+    if (const char* e = getenv("SGF_SPMM_CHUNK_ROWS")) chunk_rows = atoi(e) > 0 ? atoi(e) : chunk_rows;   // experiments
+    const int chunk = chunk_rows / (kWavesPerBlock * kSegRows) > 0 ? chunk_rows / (kWavesPerBlock * kSegRows) : 1;
     if (fits32 && pair_ok && (stream || fk == "seg2"))
       hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
                          reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),

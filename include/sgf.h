@@ -307,6 +307,23 @@ int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, int64_t ldg,
 /* scratch of sgf_attn_h_bwd_apply: bf16 storage with d in {64, 128, 256} runs as two per-wave streaming passes
  * (csrc/rowgemm.hip) with the first product parked in the matrix cores' accumulator layout; 0 otherwise */
 size_t sgf_attn_h_bwd_apply_workspace_bytes(int64_t n, int32_t d, int32_t dtype);
+/* The same backward as three calls (bf16 storage, d in {64, 128, 256}: sgf_attn_h_bwd_split_supported), ordered so that
+ * the node reduction can use what the first apply pass computes anyway:
+ *   sgf_attn_h_bwd_pre            : partial (in `workspace`, sgf_attn_h_bwd_apply_workspace_bytes) = dnum M^T + dden w,
+ *                                   and rowscal[n][2] = (1 / den, dden = -(g . out) / den) per node;
+ *   sgf_attn_h_bwd_reduce_scaled  : hstats as sgf_attn_h_bwd_reduce, from h, g and rowscal — two streams instead of
+ *                                   three (no `out`, no per-row dot);
+ *   sgf_attn_h_bwd_post           : dh = h D + ds + partial.
+ * sgf_attn_h_bwd_reduce + sgf_attn_h_bwd_apply remain for everything else. */
+int32_t sgf_attn_h_bwd_split_supported(int32_t d, int32_t dtype);
+int sgf_attn_h_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, int32_t d,
+                       int32_t dtype, const float* M, const float* w, void* workspace, size_t workspace_bytes,
+                       float* rowscal, void* stream);
+int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const void* g, int64_t ldg, const float* rowscal, int64_t n,
+                                 int32_t d, int32_t dtype, float* hstats, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* D, const float* ds,
+                        const void* workspace, size_t workspace_bytes, void* dh, int64_t lddh, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for

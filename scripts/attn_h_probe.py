@@ -33,5 +33,9 @@ def rec(name, fn, tensors):
 rec("attn_h_fwd", lambda: K.attn_h_fwd(h, M, m, w, beta), 2)
 rec("attn_h_bwd_reduce", lambda: K.attn_h_bwd_reduce(h, g, out_t, den), 3)
 rec("attn_h_bwd_apply (2 passes)", lambda: K.attn_h_bwd_apply(h, g, out_t, den, M, w, D, ds), 6)
+rec("attn_h_bwd_pre (B1 + row scalars)", lambda: K.attn_h_bwd_pre(g, out_t, den, M, w), 3)
+rs = K.attn_h_bwd_pre(g, out_t, den, M, w)
+rec("attn_h_bwd_reduce_scaled", lambda: K.attn_h_bwd_reduce_scaled(h, g, rs), 2)
+rec("attn_h_bwd_post (B2)", lambda: K.attn_h_bwd_post(h, D, ds), 3)
 rec("gram", lambda: K.gram(g, h), 2)
 print(json.dumps(res))

@@ -47,6 +47,8 @@ constexpr int kModeFwd = 0;  // reduce: A=K, B=V          apply: out
 constexpr int kModeBwd = 1;  // reduce: A=Q, B=dnum
 constexpr int kModeGram = 2; // reduce: C = A^T B plus column sums of A (sgf_gram); no third stream
 constexpr int kModeBwdH = 3; // reduce: A=h, B=dnum; vecA = sum h*dden, vecB = sum dnum, scalar = sum dden
+constexpr int kModeBwdHS = 4; // the same sums with the per-row scalars (1/den, dden) READ (p.den = float2 per row,
+                              // written by k_hrow_bf16<B1>): two streams, no row dot (bf16 only)
 constexpr int kApplyFwd = 0, kApplyDQ = 1, kApplyDK = 2, kApplyDV = 3;
 // attention from the un-projected input (sgf_attn_h_*): no E operand, no global scalars
 constexpr int kApplyHFwd = 4;   // out = (h M + m) / (h.w + beta)
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   // half-steps, each = issue the loads of pass t of the next tile, run the MFMAs of half of the
   // current tile's k-steps, then transpose / commit pass t into the other LDS buffer.
   uint2 ra[4], rb[4], rq[4];
-  float rden[4];
+  float rden[4], rden2[4];
 
   auto issue = [&](int64_t tile, int t) {
 #pragma unroll
@@ -693,9 +695,14 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       const bool rok = row < p.n;
       ra[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pa + row * p.lda) : make_uint2(0u, 0u);
       rb[i] = (rok && b_ok) ? *reinterpret_cast<const uint2*>(pb + row * p.ldb) : make_uint2(0u, 0u);
-      if (MODE != kModeGram)
+      if (MODE != kModeGram && MODE != kModeBwdHS)
         rq[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pq + row * p.ldq) : make_uint2(0u, 0u);
       if (MODE == kModeBwd || MODE == kModeBwdH) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
+      if (MODE == kModeBwdHS) {
+        const float2 rs = rok ? reinterpret_cast<const float2*>(p.den)[row] : make_float2(0.f, 0.f);
+        rden[i] = rs.x;      // 1 / den
+        rden2[i] = rs.y;     // dden = -(g.o) / den
+      }
     }
   };
   // column j of a 4x4 patch as 8 bytes: rows 0..3
@@ -724,6 +731,18 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       for (int i = 0; i < 4; ++i) {
         colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
         colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
+      }
+    } else if (MODE == kModeBwdHS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint2 g = rb[i];
+        const float inv = rden[i], dden = rden2[i];
+        const float g0 = bf_lo(g.x) * inv, g1 = bf_hi(g.x) * inv, g2 = bf_lo(g.y) * inv, g3 = bf_hi(g.y) * inv;
+        rb[i] = make_uint2(pack_bf16(g0, g1), pack_bf16(g2, g3));
+        colsum.x += bf_lo(ra[i].x) * dden; colsum.y += bf_hi(ra[i].x) * dden;
+        colsum.z += bf_lo(ra[i].y) * dden; colsum.w += bf_hi(ra[i].y) * dden;
+        colsumb.x += g0; colsumb.y += g1; colsumb.z += g2; colsumb.w += g3;
+        if (c0 == 0) ssq_a += dden;
       }
     } else {
       // rb = g, rq = o: dnum = (g/H)/den (re-rounded to bf16 for the MFMA); dden = -((g/H).o)/den
@@ -836,7 +855,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
     part[kTileElems + DP] = sa;
     part[kTileElems + DP + 1] = sq;
   }
-  if (MODE == kModeBwdH) {
+  if (MODE == kModeBwdH || MODE == kModeBwdHS) {
     __syncthreads();
     *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsumb;
     __syncthreads();
@@ -1068,7 +1087,8 @@ __global__ __launch_bounds__(kBfThreads, RB == 1 ? 4 : 2) void k_apply_bf16(Appl
 // ------------------------------------------------------------------------------------------------
 // NW of k_reduce_bf16 per mode: the two-stream Gram mode fits 16 waves x 128 VGPRs without spilling
 // (twice the loads in flight); the three-stream attention modes need the 8-wave / 256-VGPR shape.
-constexpr int bf_reduce_waves(int mode) { return mode == kModeGram ? 16 : 8; }  // BwdH at 16 waves spills 160 B and runs 2.7x slower
+// (at 16 waves BwdH spills 160 B and runs 2.7x slower, its two-stream form BwdHS spills 84 B: 1.75 ms against 1.10 at 8)
+constexpr int bf_reduce_waves(int mode) { return mode == kModeGram ? 16 : 8; }
 
 template <typename T, int MODE>
 inline int reduce_rows_per_tile(int DP) {
@@ -1346,6 +1366,80 @@ extern "C" int sgf_attn_h_bwd_apply(const void* h, int64_t ldh, const void* g, i
 extern "C" size_t sgf_attn_h_bwd_apply_workspace_bytes(int64_t n, int32_t d, int32_t dtype) {
   if (n <= 0 || dtype != SGF_BF16 || !(d == 64 || d == 128 || d == 256)) return 0;
   return hrow_partial_bytes(n, d);
+}
+
+// ---- the same backward as three calls, so that the reduce can use the row scalars the first apply pass computes ----
+extern "C" int32_t sgf_attn_h_bwd_split_supported(int32_t d, int32_t dtype) {
+  return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) ? 1 : 0;
+}
+
+extern "C" int sgf_attn_h_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n,
+                                  int32_t d, int32_t dtype, const float* M, const float* w, void* workspace,
+                                  size_t workspace_bytes, float* rowscal, void* stream) {
+  int rc = check_common("sgf_attn_h_bwd_pre", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(sgf_attn_h_bwd_split_supported(d, dtype), SGF_E_UNSUPPORTED,
+              "sgf_attn_h_bwd_pre: bf16 storage with d in {64, 128, 256} only (d=%d, dtype=%d)", d, dtype);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(g && o && den && M && w && rowscal, SGF_E_INVALID, "sgf_attn_h_bwd_pre: null pointer");
+  SGF_REQUIRE(hrow_supported(d, dtype, g, ldg, o, ldo, nullptr, 0, g, ldg) && reinterpret_cast<uintptr_t>(rowscal) % 8 == 0,
+              SGF_E_INVALID, "sgf_attn_h_bwd_pre: rows must be 16-byte aligned");
+  SGF_REQUIRE(workspace && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 && workspace_bytes >= hrow_partial_bytes(n, d),
+              SGF_E_WORKSPACE, "sgf_attn_h_bwd_pre: workspace %zu < %zu", workspace_bytes, hrow_partial_bytes(n, d));
+  return hrow_bwd_pre(g, ldg, o, ldo, den, n, d, M, w, workspace, rowscal, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const void* g, int64_t ldg, const float* rowscal,
+                                            int64_t n, int32_t d, int32_t dtype, float* hstats, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  int rc = check_common("sgf_attn_h_bwd_reduce_scaled", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(dtype == SGF_BF16, SGF_E_UNSUPPORTED, "sgf_attn_h_bwd_reduce_scaled: bf16 storage only");
+  SGF_REQUIRE(hstats, SGF_E_INVALID, "sgf_attn_h_bwd_reduce_scaled: null hstats");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(hstats, 0, sgf_attn_h_bstats_len(d) * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(h && g && rowscal, SGF_E_INVALID, "sgf_attn_h_bwd_reduce_scaled: null pointer");
+  SGF_REQUIRE(aligned4<uint16_t>(h, ldh) && aligned4<uint16_t>(g, ldg) && reinterpret_cast<uintptr_t>(rowscal) % 8 == 0,
+              SGF_E_INVALID, "sgf_attn_h_bwd_reduce_scaled: h / g must be 4-element aligned with ld %% 4 == 0");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_attn_workspace_bytes(n, 1, d), SGF_E_WORKSPACE,
+              "sgf_attn_h_bwd_reduce_scaled: workspace too small");
+  const int DP = padded_dim(d);
+  const int R = reduce_rows_per_tile<uint16_t, kModeBwdHS>(DP);
+  const int64_t ntiles = (n + R - 1) / R;
+  const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+  ReduceArgs a{};
+  a.a = h; a.lda = ldh;
+  a.b = g; a.ldb = ldg;
+  a.den = rowscal;
+  a.n = n; a.d = d; a.db = d; a.heads = 1; a.b_heads = 1; a.gscale = 1.f;
+  a.partial = static_cast<float*>(workspace);
+  rc = launch_reduce<uint16_t, kModeBwdHS>(a, DP, nblk, st);
+  if (rc != SGF_OK) return rc;
+  const int RG = reduce_row_groups<uint16_t, kModeBwdHS>(DP);
+  const int64_t len = sgf_attn_h_bstats_len(d);
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, st, a.partial, nblk, d,
+                     DP, RG, hstats);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+extern "C" int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* D,
+                                   const float* ds, const void* workspace, size_t workspace_bytes, void* dh,
+                                   int64_t lddh, void* stream) {
+  int rc = check_common("sgf_attn_h_bwd_post", n, 1, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(sgf_attn_h_bwd_split_supported(d, dtype), SGF_E_UNSUPPORTED,
+              "sgf_attn_h_bwd_post: bf16 storage with d in {64, 128, 256} only (d=%d, dtype=%d)", d, dtype);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(h && D && ds && dh, SGF_E_INVALID, "sgf_attn_h_bwd_post: null pointer");
+  SGF_REQUIRE(hrow_supported(d, dtype, h, ldh, nullptr, 0, nullptr, 0, dh, lddh), SGF_E_INVALID,
+              "sgf_attn_h_bwd_post: rows must be 16-byte aligned");
+  SGF_REQUIRE(workspace && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 && workspace_bytes >= hrow_partial_bytes(n, d),
+              SGF_E_WORKSPACE, "sgf_attn_h_bwd_post: workspace %zu < %zu", workspace_bytes, hrow_partial_bytes(n, d));
+  return hrow_bwd_post(h, ldh, n, d, D, ds, workspace, dh, lddh, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t sgf_attn_stats_len(int32_t heads, int32_t d) {

@@ -289,8 +289,9 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
 // d x d matrix, with PER-ROW scalars in the epilogue.  In the accumulator layout a lane's 16 registers are 16 rows, so
 // a row scalar is one register per accumulator register:
 //   F   out = (h M + m) / den,  den = h.w + beta.   h.w comes out of the matrix cores too: a ninth "strip" whose B
-//       fragment is w for EVERY lane gives D[row][*] = h_row . w — already one value per accumulator register.
-//   B1  part = (g M^T) / den - ((g.o) / den^2) w      (dnum M^T + dden w, scaled after the product, in fp32);
+//       fragment is w for EVERY lane gives D[row][*] = h_row . w — already one value per accumulator register
+//       (w enters as hi + lo bf16 halves, two MFMA chains: the denominators keep fp32-grade accuracy).
+//   B1  part = (g M^T) / den - ((g.o) / den) w        (dnum M^T + dden w, scaled after the product, in fp32);
 //       g.o is a lane-local dot over the fragments of g and o, den is read; kept in accumulator layout
 //   B2  dh = h D + ds + part
 // B1 + B2 move 6 [n, d] tensors like the two k_apply_bf16 launches they replace (1.28 + 1.66 ms at N = 2.45 M),
@@ -307,13 +308,14 @@ struct HRowArgs {
   uint16_t* out; int64_t ldo;            // F, B2
   uint4* part;                           // B1: written    B2: read
   int64_t n;
+  float2* rowscal;                       // B1, optional: (1 / den, dden = -(g.o) / den) per row, for the reduce pass
 };
 
 template <int D, int MODE>
 __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
   constexpr int KS = D / 16, NS = D / 32;
   constexpr int BT = D * 2 + 16;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[D * BT + kRgWaves * kStageBytes + D * 4 + D * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[D * BT + kRgWaves * kStageBytes + D * 4 + 2 * D * 2];
   unsigned char* const ldsB = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
   const int hi = lane >> 5;
   unsigned char* const stg = lds + D * BT + wave * kStageBytes;
   float* const cvec = reinterpret_cast<float*>(lds + D * BT + kRgWaves * kStageBytes);
-  uint16_t* const wdot = reinterpret_cast<uint16_t*>(lds + D * BT + kRgWaves * kStageBytes + D * 4);   // F: bf16(w)
+  // F: w as two bf16 vectors, w = hi + lo to 16 mantissa bits (the denominators keep fp32-grade accuracy)
+  uint16_t* const wdot = reinterpret_cast<uint16_t*>(lds + D * BT + kRgWaves * kStageBytes + D * 4);
 
   // ---- B^T -> LDS as bf16: B^T[j][k] = B[k][j] ----
   if (p.trans_b) {                                     // B[k][j] = bmat[j d + k]: rows of bmat are rows of B^T
@@ -348,7 +351,12 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
   }
   for (int c = tid; c < D; c += kRgThreads) {
     cvec[c] = p.cvec[c];
-    if (MODE == kHF) wdot[c] = static_cast<uint16_t>(cvt_pk_bf16(p.dvec[c], 0.f) & 0xffffu);
+    if (MODE == kHF) {
+      const float wv = p.dvec[c];
+      const uint32_t whi = cvt_pk_bf16(wv, 0.f) & 0xffffu;
+      wdot[c] = static_cast<uint16_t>(whi);
+      wdot[D + c] = static_cast<uint16_t>(cvt_pk_bf16(wv - __uint_as_float(whi << 16), 0.f) & 0xffffu);
+    }
   }
   __syncthreads();
   const float beta = MODE == kHF ? p.beta[0] : 0.f;
@@ -385,8 +393,11 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
       for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wdot) + 32 * s + 16 * hi);
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(wdot) + 32 * s + 16 * hi;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 2 * D);
         dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], bl, dacc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -427,7 +438,8 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
       }
       dot += __shfl_xor(dot, 32, 64);
       const float inv_row = 1.0f / p.den[row];
-      const float coef_row = -dot * inv_row * inv_row;                   // dden / den folded: -(g.o) / den^2
+      const float coef_row = -dot * inv_row;                             // dden = -(g.o) / den
+      if (p.rowscal && hi == 0 && row0 + i31 < p.n) p.rowscal[row0 + i31] = make_float2(inv_row, coef_row);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int src = (r & 3) + 8 * (r >> 2) + 4 * hi;                 // the lane that owns this register's row
@@ -624,22 +636,32 @@ size_t hrow_partial_bytes(int64_t n, int d) { return static_cast<size_t>((n + 31
 int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const float* m, const float* w,
              const float* beta, void* out, int64_t ldo, float* den, hipStream_t st) {
   HRowArgs a{static_cast<const uint16_t*>(h), ldh, nullptr, 0, M, 0, m, w, beta, den, static_cast<uint16_t*>(out), ldo,
-             nullptr, n};
+             nullptr, n, nullptr};
   return launch_hrow<kHF>(a, d, st);
+}
+
+// part = (g M^T) / den - ((g.o) / den) w;  rowscal (optional) = (1 / den, -(g.o) / den) per row
+int hrow_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, int d,
+                 const float* M, const float* w, void* partial, float* rowscal, hipStream_t st) {
+  HRowArgs a{static_cast<const uint16_t*>(g), ldg, static_cast<const uint16_t*>(o), ldo, M, 1, w, nullptr, nullptr,
+             const_cast<float*>(den), nullptr, 0, static_cast<uint4*>(partial), n, reinterpret_cast<float2*>(rowscal)};
+  return launch_hrow<kHB1>(a, d, st);
+}
+
+// dh = h D + ds + part
+int hrow_bwd_post(const void* h, int64_t ldh, int64_t n, int d, const float* Dm, const float* ds, const void* partial,
+                  void* dh, int64_t lddh, hipStream_t st) {
+  HRowArgs b{static_cast<const uint16_t*>(h), ldh, nullptr, 0, Dm, 0, ds, nullptr, nullptr, nullptr,
+             static_cast<uint16_t*>(dh), lddh, const_cast<uint4*>(static_cast<const uint4*>(partial)), n, nullptr};
+  return launch_hrow<kHB2>(b, d, st);
 }
 
 int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den,
              int64_t n, int d, const float* M, const float* w, const float* Dm, const float* ds, void* dh, int64_t lddh,
              void* partial, hipStream_t st) {
-  // part = (g M^T) / den - ((g.o) / den^2) w
-  HRowArgs a{static_cast<const uint16_t*>(g), ldg, static_cast<const uint16_t*>(o), ldo, M, 1, w, nullptr, nullptr,
-             const_cast<float*>(den), nullptr, 0, static_cast<uint4*>(partial), n};
-  int rc = launch_hrow<kHB1>(a, d, st);
+  int rc = hrow_bwd_pre(g, ldg, o, ldo, den, n, d, M, w, partial, nullptr, st);
   if (rc != SGF_OK) return rc;
-  // dh = h D + ds + part
-  HRowArgs b{static_cast<const uint16_t*>(h), ldh, nullptr, 0, Dm, 0, ds, nullptr, nullptr, nullptr,
-             static_cast<uint16_t*>(dh), lddh, static_cast<uint4*>(partial), n};
-  return launch_hrow<kHB2>(b, d, st);
+  return hrow_bwd_post(h, ldh, n, d, Dm, ds, partial, dh, lddh, st);
 }
 
 }  // namespace sgf

@@ -339,6 +339,48 @@ class HipKernels:
                       dh.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream(dev))
         return dh
 
+    @staticmethod
+    def attn_h_bwd_split_supported(h, g, o) -> bool:
+        d = h.shape[1]
+        return (h.dtype == _BF16 and bool(_lib.load().sgf_attn_h_bwd_split_supported(d, _lib.SGF_BF16))
+                and all(t.stride(-1) == 1 and (t.stride(0) * 2) % 16 == 0 and t.data_ptr() % 16 == 0 for t in (h, g, o)))
+
+    @staticmethod
+    def attn_h_bwd_pre(g, o, den, M, w):
+        """First apply pass of the backward (dnum M^T + dden w -> scratch) + the per-row scalars (1/den, dden)."""
+        n, d = g.shape
+        dev = g.device
+        ws = _workspace(dev, "attn_h_part", _lib.load().sgf_attn_h_bwd_apply_workspace_bytes(n, d, _code(g)))
+        rowscal = torch.empty((n, 2), dtype=_F32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_bwd_pre", _ptr(g), _ld(g), _ptr(o), _ld(o), _ptr(den), n, d, _code(g), _ptr(M),
+                      _ptr(w), _ptr(ws), ws.numel(), _ptr(rowscal), _stream(dev))
+        return rowscal
+
+    @staticmethod
+    def attn_h_bwd_reduce_scaled(h, g, rowscal):
+        n, d = h.shape
+        dev = h.device
+        lib = _lib.load()
+        hstats = torch.empty(lib.sgf_attn_h_bstats_len(d), dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, 1, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_bwd_reduce_scaled", _ptr(h), _ld(h), _ptr(g), _ld(g), _ptr(rowscal), n, d, _code(h),
+                      _ptr(hstats), _ptr(ws), ws.numel(), _stream(dev))
+        return hstats
+
+    @staticmethod
+    def attn_h_bwd_post(h, D, ds):
+        """dh = h D + ds + the scratch attn_h_bwd_pre left on this stream."""
+        n, d = h.shape
+        dev = h.device
+        ws = _workspace(dev, "attn_h_part", _lib.load().sgf_attn_h_bwd_apply_workspace_bytes(n, d, _code(h)))
+        dh = torch.empty((n, d), dtype=h.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_bwd_post", _ptr(h), _ld(h), n, d, _code(h), _ptr(D), _ptr(ds), _ptr(ws), ws.numel(),
+                      _ptr(dh), dh.stride(0), _stream(dev))
+        return dh
+
     # ---- T4: dW = a^T b, db = colsum(a) ----
     @staticmethod
     def gram(a, b, out=None, want_colsum=True):
@@ -1079,7 +1121,12 @@ class _AttentionFromInput(torch.autograd.Function):
         n_rows, n_total, shard, v_is_h, dtypes, sum_v = ctx.meta
         d = h.shape[1]
         g = _rows(g.contiguous())
-        hstats = K.attn_h_bwd_reduce(h, g, out, den)      # [dM | dw | dm | dbeta]
+        split = K.attn_h_bwd_split_supported(h, g, out)
+        if split:   # the first apply pass needs only forward quantities and yields the row scalars the reduce wants
+            rowscal = K.attn_h_bwd_pre(g, out, den, M, w)
+            hstats = K.attn_h_bwd_reduce_scaled(h, g, rowscal)
+        else:
+            hstats = K.attn_h_bwd_reduce(h, g, out, den)      # [dM | dw | dm | dbeta]
         if shard is not None:
             shard.all_reduce(hstats)
         dM, dw_, dm = hstats[:d * d].reshape(d, d), hstats[d * d:d * d + d], hstats[d * d + d:d * d + 2 * d]
@@ -1091,7 +1138,8 @@ class _AttentionFromInput(torch.autograd.Function):
             grads = torch.autograd.grad(outs, leaves, grad_outputs=(dM, dm, dw_, dbeta), allow_unused=True)
         dG, ds = grads[0], grads[1]
         D = (dG + dG.t()).contiguous()
-        dh = K.attn_h_bwd_apply(h, g, out, den, M, w, D, ds.contiguous())
+        dh = K.attn_h_bwd_post(h, D, ds.contiguous()) if split else \
+            K.attn_h_bwd_apply(h, g, out, den, M, w, D, ds.contiguous())
         pg = list(grads[2:])
         if shard is not None:   # parameter grads are summed over ranks again by ShardContext.sync_grads
             pg = [None if t is None else shard.unsum(t) for t in pg]

@@ -157,6 +157,33 @@ class CpuKernels:
         dden = -(gf * of).sum(1, keepdim=True) / den
         return (dnum @ M.t() + dden * w + hf @ D + ds).to(h.dtype)
 
+    # the three-call form of the same backward (bf16 storage): state of the first pass kept on the table
+    _h_partial = None
+
+    @staticmethod
+    def attn_h_bwd_split_supported(h, g, o):
+        return h.dtype == torch.bfloat16 and h.shape[1] in (64, 128, 256)
+
+    @staticmethod
+    def attn_h_bwd_pre(g, o, den, M, w):
+        gf, of = g.float(), o.float()
+        inv = 1.0 / den.reshape(-1, 1)
+        dden = -(gf * of).sum(1, keepdim=True) * inv
+        CpuKernels._h_partial = ((gf @ M.t()) * inv + dden * w).to(g.dtype)   # rounded scratch
+        return torch.cat([inv, dden], 1).contiguous()
+
+    @staticmethod
+    def attn_h_bwd_reduce_scaled(h, g, rowscal):
+        hf = h.float()
+        dnum = (g.float() * rowscal[:, :1]).to(g.dtype).float()      # re-rounded for the matrix cores, as the kernel does
+        dden = rowscal[:, 1:2]
+        return torch.cat([(hf.t() @ dnum).reshape(-1), (hf * dden).sum(0), (g.float() * rowscal[:, :1]).sum(0),
+                          dden.sum().reshape(1)])
+
+    @staticmethod
+    def attn_h_bwd_post(h, D, ds):
+        return (h.float() @ D + ds + CpuKernels._h_partial.float()).to(h.dtype)
+
     @staticmethod
     def dropout(x, res, p, seed):
         g = torch.Generator().manual_seed(seed % (2 ** 31))

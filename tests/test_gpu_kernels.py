@@ -860,3 +860,50 @@ def test_linear_cat_bn_stats_matches_unfused(cuda):
     assert _rel(a2.grad.float(), go.double() @ wr[:, d:]) <= 4e-3
     assert _rel(wa.grad, go.double().t() @ torch.cat([x1, x2], 1).double()) <= 2e-5
     assert _rel(ba.grad, go.double().sum(0)) <= 2e-5
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (77, 128), (3001, 256), (20000, 256)])
+def test_attn_h_backward_split_form(cuda, n, d):
+    """sgf_attn_h_bwd_pre -> _reduce_scaled -> _post (bf16): the backward of large/ours.py:130-151 for one head from the
+    un-projected input, against fp64 ON THE HOST of the same bf16 inputs: hstats = [h^T dnum | h^T dden | sum dnum | sum dden]
+    relative 2e-3 on the matrix (dnum is re-rounded to bf16 for the matrix cores) and 1e-5 on the vectors the kernel keeps
+    in fp32; dh within bf16 rounding (of the result and of the parked first product); and the row scalars themselves."""
+    from sgformer_amd import ops
+    g_ = torch.Generator().manual_seed(n + d)
+    h = torch.randn(n, d, generator=g_).bfloat16()
+    g = torch.randn(n, d, generator=g_).bfloat16()
+    M = torch.randn(d, d, generator=g_) / d ** 0.5
+    D = torch.randn(d, d, generator=g_) / d ** 0.5
+    m, w, ds = torch.randn(d, generator=g_), torch.rand(d, generator=g_) / d, torch.randn(d, generator=g_)
+    beta = torch.full((1,), 3.0)
+    K = ops.K
+    hc, gc = h.to(cuda), g.to(cuda)
+    out, den = K.attn_h_fwd(hc, M.to(cuda), m.to(cuda), w.to(cuda), beta.to(cuda))
+    assert K.attn_h_bwd_split_supported(hc, gc, out)
+    # forward: den = h.w + beta to fp32 accuracy (w enters the matrix cores as hi + lo halves), out within bf16 rounding
+    den_ref = h.double() @ w.double() + 3.0
+    assert float(((den.double().cpu().reshape(-1) - den_ref).abs() / den_ref.abs()).max()) <= 2e-5
+    out_ref = (h.double() @ M.bfloat16().double() + m.double()) / den_ref.reshape(-1, 1)
+    assert bool(((out.double().cpu() - out_ref).abs() <= 2.0 ** -8 * out_ref.abs() + 1e-5).all())
+    rowscal = K.attn_h_bwd_pre(gc, out, den, M.to(cuda), w.to(cuda))
+    hstats = K.attn_h_bwd_reduce_scaled(hc, gc, rowscal)
+    dh = K.attn_h_bwd_post(hc, D.to(cuda), ds.to(cuda))
+    hd, gd, od, dend = h.double(), g.double(), out.double().cpu(), den.double().cpu().reshape(-1, 1)
+    inv = 1.0 / dend
+    dden = -(gd * od).sum(1, keepdim=True) * inv
+    assert _rel(rowscal[:, 0], inv.reshape(-1)) <= 1e-6 and _rel(rowscal[:, 1], dden.reshape(-1)) <= 1e-5
+    dnum = gd * inv
+    assert _rel(hstats[:d * d].reshape(d, d), hd.t() @ dnum) <= 2e-3
+    assert _rel(hstats[d * d:d * d + d], (hd * dden).sum(0)) <= 1e-5
+    assert _rel(hstats[d * d + d:d * d + 2 * d], dnum.sum(0)) <= 1e-5
+    assert abs(float(hstats[-1]) - float(dden.sum())) <= 1e-5 * max(1.0, float(dden.abs().sum()))
+    Mr, Dr = M.bfloat16().double(), D.bfloat16().double()        # the resident matrices are rounded to bf16 (as in r01)
+    part = dnum @ Mr.t() + dden * w.double()
+    ref = part + hd @ Dr + ds.double()
+    err = (dh.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * (ref.abs() + part.abs()) + 1e-4).all()), float(err.max())
+    # and the one-call forms agree with the three-call form
+    hs_old = K.attn_h_bwd_reduce(hc, gc, out, den)
+    assert _rel(hs_old, hstats) <= 2e-3
+    dh_old = K.attn_h_bwd_apply(hc, gc, out, den, M.to(cuda), w.to(cuda), D.to(cuda), ds.to(cuda))
+    assert torch.equal(dh_old, dh)

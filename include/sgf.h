@@ -466,6 +466,22 @@ int sgf_gcn_epilogue_stats_add(const void* a, int64_t lda, const void* w, int64_
                                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * T4 / K10 — both input stems from ONE read of the node features.   Replaces the first line of each branch,
+ * large/ours.py:77 (GraphConv: x = self.fcs[0](x), followed by BatchNorm1d :79) and :198 (TransConv):
+ *     y0 = x W0^T + b0  [+ stats0 = column sums of the rounded y0, as sgf_gcn_epilogue_stats],   y1 = x W1^T + b1
+ * x [n, d_in] in the storage dtype with d_in % 4 == 0, d_in <= 128 (rows 8-byte aligned: 100 features = 200 bytes);
+ * W0, W1 [d_out, d_in] in the storage dtype, biases fp32 or null; w1 / y1 null = one output.  Same per-wave
+ * streaming skeleton as sgf_gcn_epilogue_stats with both weight matrices resident in LDS (csrc/rowgemm.hip).
+ * bf16 storage, d_out in {64, 128, 256} (sgf_stem_pair_supported); workspace (with stats0 only):
+ * sgf_gcn_epilogue_workspace_bytes(n, d_out).
+ * ------------------------------------------------------------------------------------------ */
+int32_t sgf_stem_pair_supported(int32_t d_in, int32_t d_out, int32_t dtype);
+int sgf_stem_pair(const void* x, int64_t ldx, int64_t n, int32_t d_in, const void* w0, int64_t ldw0,
+                  const float* bias0, const void* w1, int64_t ldw1, const float* bias1, int32_t d_out, int32_t dtype,
+                  void* y0, int64_t ldy0, void* y1, int64_t ldy1, const float* shift0, float* stats0, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * T7 — branch combine alone.   large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.
  * (generic axpby: y = a * x1 + b * x2; the 'cat' aggregate is a plain copy done by the caller.)
  * ------------------------------------------------------------------------------------------ */

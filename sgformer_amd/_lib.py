@@ -115,6 +115,9 @@ SIGNATURES = {
                                            c_size_t, _P]),
     "sgf_gcn_epilogue_stats_add": (c_int32, [_P, c_int64, _P, c_int64, _P, c_size_t, c_int64, c_int32, c_int32,
                                              c_int32, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "sgf_stem_pair_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "sgf_stem_pair": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, _P, c_int32, c_int32, _P,
+                                c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
                             c_int64, _P]),
 }

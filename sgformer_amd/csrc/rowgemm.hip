@@ -543,6 +543,184 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K10: the two input stems read the SAME node features (large/ours.py:77 and :198,
+// x = self.fcs[0](x) in GraphConv and in TransConv):  y0 = x W0^T + b0 (+ BatchNorm's column sums),  y1 = x W1^T + b1
+// in ONE pass over x.  x is [n, f] with a small f (100 / 128): its rows are only 8-byte aligned and the contraction is
+// 7-8 k-steps, so the A fragments are two 8-byte loads per k-step with the ragged last step zero-filled, a tile's
+// fragments are 28-32 registers, and both weight matrices (2 D rows of <= 128 k) sit in LDS together.
+constexpr int kStemMaxK = 128;                         // f <= 128
+constexpr int kStemKS = kStemMaxK / 16;
+
+struct StemArgs {
+  const uint16_t* x; int64_t ldx; int d_in;            // d_in % 4 == 0
+  const uint16_t* w0; int64_t ldw0; const float* b0;
+  const uint16_t* w1; int64_t ldw1; const float* b1;   // w1 may be null: one output
+  const float* shift;                                  // statistics of output 0 only
+  float* spart;
+  uint16_t* y0; int64_t ldy0;
+  uint16_t* y1; int64_t ldy1;
+  int64_t n;
+};
+
+template <int D, bool STATS>
+__global__ __launch_bounds__(kRgThreads, 2) void k_stem_bf16(StemArgs p) {
+  constexpr int NS1 = D / 32;                          // strips per output
+  constexpr int BT = kStemMaxK * 2 + 16;               // bytes per row of B^T
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * D * BT + kRgWaves * kStageBytes + 3 * D * 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const ldsB = lds;
+  unsigned char* const stg = lds + 2 * D * BT + wave * kStageBytes;
+  float* const cvec = reinterpret_cast<float*>(lds + 2 * D * BT + kRgWaves * kStageBytes);   // [b0 | b1 | shift0]
+  const int nout = p.w1 ? 2 : 1;
+  const int ks = (p.d_in + 15) / 16;
+
+  // ---- [W0 ; W1] -> LDS: B^T[j][k] = W[j][k], k >= d_in zero ----
+  for (int c = tid; c < nout * D * (kStemMaxK / 4); c += kRgThreads) {
+    const int j = c / (kStemMaxK / 4), q = c % (kStemMaxK / 4);
+    const uint16_t* wsrc = j < D ? p.w0 + static_cast<int64_t>(j) * p.ldw0 : p.w1 + static_cast<int64_t>(j - D) * p.ldw1;
+    uint2 v = make_uint2(0u, 0u);
+    if (4 * q < p.d_in) v = *reinterpret_cast<const uint2*>(wsrc + 4 * q);
+    *reinterpret_cast<uint2*>(ldsB + j * BT + 8 * q) = v;
+  }
+  for (int c = tid; c < D; c += kRgThreads) {
+    cvec[c] = p.b0 ? p.b0[c] : 0.f;
+    cvec[D + c] = (p.w1 && p.b1) ? p.b1[c] : 0.f;
+    cvec[2 * D + c] = (STATS && p.shift) ? p.shift[c] : 0.f;
+  }
+  __syncthreads();
+
+  float s1[NS1], s2[NS1];
+#pragma unroll
+  for (int w = 0; w < NS1; ++w) {
+    s1[w] = 0.f;
+    s2[w] = 0.f;
+  }
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kRgWaves;
+  auto load_tile = [&](int64_t t, bf16x8 (&dst)[kStemKS]) {
+    int64_t row = t * 32 + i31;
+    if (row >= p.n) row = p.n - 1;
+    const uint16_t* src = p.x + row * p.ldx + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < kStemKS; ++s) {
+      const int k0 = 16 * s + 8 * hi;
+      uint2 lo = make_uint2(0u, 0u), hi2 = make_uint2(0u, 0u);
+      if (k0 < p.d_in) lo = *reinterpret_cast<const uint2*>(src + 16 * s);
+      if (k0 + 4 < p.d_in) hi2 = *reinterpret_cast<const uint2*>(src + 16 * s + 4);
+      const uint4 v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+      dst[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  };
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+
+  bf16x8 cur[kStemKS], nxt[kStemKS];
+  int64_t t = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+  if (t < ntiles) load_tile(t, cur);
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    if (tn < ntiles) load_tile(tn, nxt);
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    for (int o = 0; o < nout; ++o) {
+      uint16_t* const yrow = (o == 0 ? p.y0 + (row0 + (lane >> 3)) * p.ldy0 : p.y1 + (row0 + (lane >> 3)) * p.ldy1) +
+                             8 * (lane & 7);
+      const int64_t ldy = o == 0 ? p.ldy0 : p.ldy1;
+#pragma unroll
+      for (int u = 0; u < NS1 / 2; ++u) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[0][r] = 0.f;
+          acc[1][r] = 0.f;
+        }
+        const unsigned char* const bu = bfrag0 + (o * D + 64 * u) * BT;
+#pragma unroll
+        for (int s = 0; s < kStemKS; ++s) {
+          if (s < ks) {
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bu + 32 * s);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bu + 32 * BT + 32 * s);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b1, acc[1], 0, 0, 0);
+          }
+        }
+        float bias_c[2], shift_c[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          bias_c[c] = cvec[o * D + 32 * (2 * u + c) + i31];
+          shift_c[c] = STATS ? cvec[2 * D + 32 * (2 * u + c) + i31] : 0.f;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          uint32_t pk[2][4];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+              const uint32_t v = cvt_pk_bf16(acc[c][r] + bias_c[c], acc[c][r + 1] + bias_c[c]);
+              const int rl = (r & 3) + 8 * ((r >> 2) & 1);
+              *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+              *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+              pk[c][(r >> 1) & 3] = v;
+            }
+          }
+          if (STATS && o == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int64_t ra = row0 + 16 * hh + ((2 * q) & 3) + 8 * (q >> 1) + 4 * hi;
+                const float v0 = (!tail || ra < p.n) ? __uint_as_float(pk[c][q] << 16) - shift_c[c] : 0.f;
+                const float v1 = (!tail || ra + 1 < p.n) ? __uint_as_float(pk[c][q] & 0xffff0000u) - shift_c[c] : 0.f;
+                s1[2 * u + c] += v0 + v1;
+                s2[2 * u + c] = fmaf(v0, v0, fmaf(v1, v1, s2[2 * u + c]));
+              }
+          }
+          wave_lds_sync();
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+            if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
+              *reinterpret_cast<uint4*>(yrow + (16 * hh + 8 * q) * ldy + 64 * u) = v;
+          }
+          wave_lds_sync();
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kStemKS; ++s) cur[s] = nxt[s];
+  }
+
+  if (STATS) {
+    __syncthreads();
+    static_assert(kRgWaves * 2 * D * 4 <= kRgWaves * kStageBytes, "reduction scratch must fit the staging patches");
+    float* const redb = reinterpret_cast<float*>(lds + 2 * D * BT);   // [wave][2][D]
+#pragma unroll
+    for (int w = 0; w < NS1; ++w) {
+      const float a1s = s1[w] + __shfl_xor(s1[w], 32, 64);
+      const float a2s = s2[w] + __shfl_xor(s2[w], 32, 64);
+      if (hi == 0) {
+        redb[(wave * 2 + 0) * D + 32 * w + i31] = a1s;
+        redb[(wave * 2 + 1) * D + 32 * w + i31] = a2s;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * D; c += kRgThreads) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < kRgWaves; ++v) s += redb[v * 2 * D + c];
+      p.spart[static_cast<int64_t>(blockIdx.x) * 2 * D + c] = s;
+    }
+  }
+}
+
 // stats[c] = Σ_blocks part[b][c], fixed order (deterministic).  One block per 64 entries, 4 block-groups per entry.
 __global__ __launch_bounds__(256) void k_rowgemm_stats(const float* __restrict__ part, int nblk, int len,
                                                        float* __restrict__ stats) {
@@ -771,4 +949,55 @@ extern "C" int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* m
                                       void* stream) {
   SGF_REQUIRE(n <= 0 || (y && mean && rstd && out), SGF_E_INVALID, "sgf_gcn_epilogue_apply: null pointer");
   return sgf_bn_apply(y, ldy, mean, rstd, gamma, beta, res, ldr, relu, n, d, dtype, out, ldo, stream);
+}
+
+// ---- K10: both input stems from one read of the node features ----------------------------------------------------
+extern "C" int32_t sgf_stem_pair_supported(int32_t d_in, int32_t d_out, int32_t dtype) {
+  return dtype == SGF_BF16 && d_in > 0 && d_in % 4 == 0 && d_in <= kStemMaxK && (d_out == 64 || d_out == 128 || d_out == 256)
+             ? 1 : 0;
+}
+
+extern "C" int sgf_stem_pair(const void* x, int64_t ldx, int64_t n, int32_t d_in, const void* w0, int64_t ldw0,
+                             const float* bias0, const void* w1, int64_t ldw1, const float* bias1, int32_t d_out,
+                             int32_t dtype, void* y0, int64_t ldy0, void* y1, int64_t ldy1, const float* shift0,
+                             float* stats0, void* workspace, size_t workspace_bytes, void* stream) {
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "sgf_stem_pair: negative n");
+  SGF_REQUIRE(sgf_stem_pair_supported(d_in, d_out, dtype), SGF_E_UNSUPPORTED,
+              "sgf_stem_pair: bf16 storage, d_in %% 4 == 0, d_in <= %d, d_out in {64, 128, 256} (got %d -> %d, dtype %d)",
+              kStemMaxK, d_in, d_out, dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (stats0) SGF_CHECK_HIP(hipMemsetAsync(stats0, 0, 2 * static_cast<size_t>(d_out) * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(x && w0 && y0 && (!w1 || y1), SGF_E_INVALID, "sgf_stem_pair: null pointer");
+  SGF_REQUIRE(ldx >= d_in && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0 && ldw0 >= d_in && ldw0 % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(w0) % 8 == 0 &&
+                  (!w1 || (ldw1 >= d_in && ldw1 % 4 == 0 && reinterpret_cast<uintptr_t>(w1) % 8 == 0)),
+              SGF_E_INVALID, "sgf_stem_pair: rows of x / W must be 8-byte aligned (pointers %% 8, leading dims %% 4 elements)");
+  SGF_REQUIRE(ldy0 >= d_out && ldy0 % 8 == 0 && reinterpret_cast<uintptr_t>(y0) % 16 == 0 &&
+                  (!w1 || (ldy1 >= d_out && ldy1 % 8 == 0 && reinterpret_cast<uintptr_t>(y1) % 16 == 0)),
+              SGF_E_INVALID, "sgf_stem_pair: rows of y must be 16-byte aligned");
+  const int blocks = grid_blocks(n);
+  StemArgs a{static_cast<const uint16_t*>(x), ldx, d_in, static_cast<const uint16_t*>(w0), ldw0, bias0,
+             static_cast<const uint16_t*>(w1), ldw1, bias1, shift0, nullptr, static_cast<uint16_t*>(y0), ldy0,
+             static_cast<uint16_t*>(y1), ldy1, n};
+  if (stats0) {
+    SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
+                "sgf_stem_pair: workspace %zu < %zu", workspace_bytes, sgf_gcn_epilogue_workspace_bytes(n, d_out));
+    a.spart = static_cast<float*>(workspace);
+  }
+#define SGF_STEM(D_)                                                                                              \
+  if (stats0) hipLaunchKernelGGL((k_stem_bf16<D_, true>), dim3(blocks), dim3(kRgThreads), 0, st, a);               \
+  else hipLaunchKernelGGL((k_stem_bf16<D_, false>), dim3(blocks), dim3(kRgThreads), 0, st, a)
+  if (d_out == 64) { SGF_STEM(64); }
+  else if (d_out == 128) { SGF_STEM(128); }
+  else { SGF_STEM(256); }
+#undef SGF_STEM
+  SGF_LAUNCH_CHECK();
+  if (stats0) {
+    hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, a.spart, blocks, 2 * d_out, stats0);
+    SGF_LAUNCH_CHECK();
+  }
+  return SGF_OK;
 }

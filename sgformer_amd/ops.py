@@ -601,6 +601,28 @@ class HipKernels:
         return y, stats
 
     @staticmethod
+    def stem_pair_supported(d_in: int, d_out: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_stem_pair_supported(d_in, d_out, _lib.SGF_BF16))
+
+    @staticmethod
+    def stem_pair(x, w0, b0, w1, b1, shift0=None, want_stats0=False):
+        """y0 = x w0^T + b0 (+ its BatchNorm column sums), y1 = x w1^T + b1 from one read of x (w1 None: y1 None)."""
+        n, d_in = x.shape
+        d_out = w0.shape[0]
+        dev = x.device
+        y0 = torch.empty((n, d_out), dtype=x.dtype, device=dev)
+        y1 = torch.empty((n, d_out), dtype=x.dtype, device=dev) if w1 is not None else None
+        stats = torch.empty(2 * d_out, dtype=_F32, device=dev) if want_stats0 else None
+        lib = _lib.load()
+        ws = _workspace(dev, "gcn_epi", lib.sgf_gcn_epilogue_workspace_bytes(n, d_out)) if want_stats0 else None
+        with torch.cuda.device(dev):
+            _lib.call("sgf_stem_pair", _ptr(x), _ld(x), n, d_in, _ptr(w0), w0.stride(0), _ptr(b0), _ptr(w1),
+                      0 if w1 is None else w1.stride(0), _ptr(b1), d_out, _code(x), _ptr(y0), _ld(y0), _ptr(y1),
+                      0 if y1 is None else _ld(y1), _ptr(shift0), _ptr(stats), _ptr(ws), 0 if ws is None else ws.numel(),
+                      _stream(dev))
+        return y0, y1, stats
+
+    @staticmethod
     def gcn_epilogue_dx(dy, w):
         """dx = dy w  (w [d_out, d_in] in dy's dtype; may be a column slice of a wider matrix)."""
         n, d_out = dy.shape
@@ -1512,30 +1534,96 @@ class _Linear(torch.autograd.Function):
             else:
                 dxs.append(g @ wc[:, off:off + k])
             off += k
-        dw = db = None
-        if need_w or need_b:
-            # sgf_gram wants widths that are multiples of 4 elements: zero-pad the odd ones (e.g. the
-            # C = 47 logits gradient: one extra [N, 48] pass) and slice the result
-            m = g.shape[1]
-            gp = _rows(g if m % 4 == 0 else torch.nn.functional.pad(g, (0, 4 - m % 4)))
-            dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
-            off = 0
-            for i, (x, k) in enumerate(zip(xs, widths)):
-                if k % 4 == 0 and off % 4 == 0:   # sgf_gram stores float4s: the slice must stay 16-B aligned
-                    _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
-                elif k % 4 == 0:
-                    blk, cs = K.gram(gp, _rows(x), want_colsum=(i == 0 and need_b))
-                    dw[:, off:off + k] = blk
-                else:
-                    xp = _rows(torch.nn.functional.pad(x, (0, 4 - k % 4)))
-                    blk, cs = K.gram(gp, xp, want_colsum=(i == 0 and need_b))
-                    dw[:, off:off + k] = blk[:, :k]
-                if i == 0:
-                    db = cs
-                off += k
-            dw = dw[:m].to(wdtype) if need_w else None
-            db = db[:m].to(bdtype) if need_b else None
+        dw, db = _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype)
         return (dw, db, None, *dxs)
+
+
+def _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype):
+    """dW = g^T [x_1 | x_2 | ...], db = sum_n g on sgf_gram (one node reduction per operand)."""
+    dw = db = None
+    if need_w or need_b:
+        # sgf_gram wants widths that are multiples of 4 elements: zero-pad the odd ones (e.g. the
+        # C = 47 logits gradient: one extra [N, 48] pass) and slice the result
+        m = g.shape[1]
+        gp = _rows(g if m % 4 == 0 else torch.nn.functional.pad(g, (0, 4 - m % 4)))
+        dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
+        off = 0
+        for i, (x, k) in enumerate(zip(xs, widths)):
+            if k % 4 == 0 and off % 4 == 0:   # sgf_gram stores float4s: the slice must stay 16-B aligned
+                _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
+            elif k % 4 == 0:
+                blk, cs = K.gram(gp, _rows(x), want_colsum=(i == 0 and need_b))
+                dw[:, off:off + k] = blk
+            else:
+                xp = _rows(torch.nn.functional.pad(x, (0, 4 - k % 4)))
+                blk, cs = K.gram(gp, xp, want_colsum=(i == 0 and need_b))
+                dw[:, off:off + k] = blk[:, :k]
+            if i == 0:
+                db = cs
+            off += k
+        dw = dw[:m].to(wdtype) if need_w else None
+        db = db[:m].to(bdtype) if need_b else None
+    return dw, db
+
+
+class _StemPair(torch.autograd.Function):
+    """(y0, y1) = (x W0^T + b0, x W1^T + b1) from ONE pass over x — the first Linear of GraphConv and of TransConv
+    (large/ours.py:77, :198) read the same node features; y0's BatchNorm column sums ride along (stats_req)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, stats_req):
+        K.check(x)
+        dt = x.dtype
+        w0c, w1c = w0.to(dt), w1.to(dt)
+        f32 = [None if b is None else b.detach().float().contiguous() for b in (b0, b1)]
+        d = w0.shape[0]
+        shift = None
+        if stats_req is not None:
+            shard = stats_req.get("shard")
+            n = x.shape[0]
+            ns = min(n, _BN_SAMPLE_ROWS)
+            _, _, st_s = K.stem_pair(x[:ns], w0c, f32[0], None, None, None, want_stats0=True)
+            samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
+            n_tot = float(n)
+            if shard is not None:
+                shard.all_reduce(samp)
+                n_tot = float(shard.n_global)
+            shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
+        y0, y1, st = K.stem_pair(x, w0c, f32[0], w1c, f32[1], shift, want_stats0=stats_req is not None)
+        if stats_req is not None:
+            if shard is not None:
+                shard.all_reduce(st)
+            m1 = st[:d] / max(n_tot, 1.0)
+            stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
+        ctx.save_for_backward(x, w0c, w1c)
+        ctx.meta = (w0.dtype, None if b0 is None else b0.dtype, w1.dtype, None if b1 is None else b1.dtype)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        x, w0c, w1c = ctx.saved_tensors
+        wd0, bd0, wd1, bd1 = ctx.meta
+        k = [x.shape[1]]
+        dw0, db0 = _linear_param_grads(g0.contiguous(), [x], k, ctx.needs_input_grad[1],
+                                       ctx.needs_input_grad[2] and bd0 is not None, wd0, bd0)
+        dw1, db1 = _linear_param_grads(g1.contiguous(), [x], k, ctx.needs_input_grad[3],
+                                       ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
+        dx = (g0 @ w0c + g1 @ w1c) if ctx.needs_input_grad[0] else None
+        return dx, dw0, db0, dw1, db1, None
+
+
+def stem_pair_supported(x, w0, w1) -> bool:
+    return (x.dim() == 2 and x.shape[0] > 0 and w0.shape == w1.shape and x.stride(-1) == 1
+            and (x.stride(0) * x.element_size()) % 8 == 0 and x.data_ptr() % 8 == 0
+            and K.stem_pair_supported(x.shape[1], w0.shape[0], x.dtype))
+
+
+def stem_pair(x, w0, b0, w1, b1, want_stats0=False, shard=None):
+    """((y0, y1), stats0): both input stems from one read of x; stats0 = (mean, var, count) of y0 for its BatchNorm
+    when asked for, else None."""
+    req = {"shard": shard, "out": None} if want_stats0 else None
+    y0, y1 = _StemPair.apply(x, w0, b0, w1, b1, req)
+    return (y0, y1), (req["out"] if req is not None else None)
 
 
 def _rows16(t: torch.Tensor) -> torch.Tensor:

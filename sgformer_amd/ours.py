@@ -234,11 +234,16 @@ class GraphConv(nn.Module):
         # dropout active: the residual add of large/ours.py:93 rides along in the dropout kernel
         return _drop(x, self.dropout, self.training, res if (res is not None and not fuse_res) else None)
 
-    def forward(self, x, edge_index):
-        """edge_index: the int64 [2, nnz] tensor of the reference, or an ops.CSRGraph built from it."""
+    def forward(self, x, edge_index, stem=None):
+        """edge_index: the int64 [2, nnz] tensor of the reference, or an ops.CSRGraph built from it.
+        `stem` (not in the reference signature): (fcs[0](x), its batch statistics or None), when SGFormer.forward
+        has computed both branches' first Linear in one pass over x (ops.stem_pair)."""
         ops._require_cuda(x, None if isinstance(edge_index, ops.CSRGraph) else edge_index)
-        x = _lin(x, self.fcs[0])
-        x = self._stage(self.bns[0], x, None, True)
+        if stem is not None:
+            x, stats0 = stem
+        else:
+            x, stats0 = _lin(x, self.fcs[0]), None
+        x = self._stage(self.bns[0], x, None, True, stats0)
         # x0 = layer_[0] has up to 2 consumers per layer (the [. | x0] Linear and the residual) plus
         # the first SpMM: hand out aliases through a hub whose backward sums all their gradients in
         # ONE pass (ops.fan_out) instead of autograd's pairwise adds
@@ -360,14 +365,15 @@ class TransConv(nn.Module):
         gamma, beta = (ln.weight, ln.bias) if self.use_bn else (None, None)
         return ops.ln_res_act(x, res, a, b, gamma, beta, relu, ln.eps)
 
-    def _embed(self, x, training):
-        x = _lin(x, self.fcs[0])
+    def _embed(self, x, training, stem=None):
+        x = _lin(x, self.fcs[0]) if stem is None else stem
         x = self._ln(self.bns[0], x, None, 1.0, 0.0, True)
         return _drop(x, self.dropout, training)
 
-    def forward(self, x):
+    def forward(self, x, stem=None):
+        """`stem` (not in the reference signature): fcs[0](x) when SGFormer.forward already has it (ops.stem_pair)."""
         ops._require_cuda(x)
-        x = self._embed(x, self.training)
+        x = self._embed(x, self.training, stem)
         layer_ = [x]
         a, b = self._mix()
         for i, conv in enumerate(self.convs):
@@ -467,6 +473,16 @@ class SGFormer(nn.Module):
             x = ops.permute_rows(x, view.perm, view.inv, cdt)
         elif x.dtype != cdt:
             x = x.to(cdt)
+        # K10: the first Linear of both branches reads the same x — one pass, two outputs, the GCN stem's BatchNorm
+        # sums on the way (bf16 storage, <= 128 input features)
+        stem_t = stem_g = None
+        gc, tc = (self.graph_conv if self.use_graph else None), self.trans_conv
+        if (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
+                and ops.stem_pair_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
+            want = gc.use_bn and _uses_batch_stats(gc, gc.bns[0])
+            (yg, yt), st = ops.stem_pair(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,
+                                         want_stats0=want, shard=gc._shard)
+            stem_t, stem_g = yt, (yg, st)
         if self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None:
             # The two branches are independent until the combine: run the attention branch on a side
             # HIP stream so that its latency-bound kernels fill the gaps of the GCN branch (autograd
@@ -475,14 +491,17 @@ class SGFormer(nn.Module):
             side = _side_stream(x.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                x1 = self.trans_conv(x)
+                x1 = self.trans_conv(x) if stem_t is None else self.trans_conv(x, stem=stem_t)
             x.record_stream(side)
-            x2 = self.graph_conv(x, edge_index)
+            x2 = self.graph_conv(x, edge_index) if stem_g is None else self.graph_conv(x, edge_index, stem=stem_g)
             cur.wait_stream(side)
             x1.record_stream(cur)
         else:
-            x1 = self.trans_conv(x)
-            x2 = self.graph_conv(x, edge_index) if self.use_graph else None
+            x1 = self.trans_conv(x) if stem_t is None else self.trans_conv(x, stem=stem_t)
+            if self.use_graph:
+                x2 = self.graph_conv(x, edge_index) if stem_g is None else self.graph_conv(x, edge_index, stem=stem_g)
+            else:
+                x2 = None
         if self.use_graph and self.aggregate == 'add' and ops.combine_fc_supported(x1, self.fc.out_features):
             # gw * x2 + (1 - gw) * x1 -> fc in ONE kernel (large/ours.py:269-270,275): the combined
             # activations are never written, the logits come out in fp32

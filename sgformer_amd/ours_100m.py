@@ -42,8 +42,8 @@ class TransConv(_large.TransConv):
 
     _attn_post_act = False   # this variant's get_attentions has no activation after a layer
 
-    def forward(self, x, edge_index=None):
-        return super().forward(x)
+    def forward(self, x, edge_index=None, stem=None):
+        return super().forward(x, stem=stem)
 
 
 class SGFormer(_large.SGFormer):

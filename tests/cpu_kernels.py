@@ -91,6 +91,16 @@ class CpuKernels:
     def gcn_epilogue_dx(dy, w):
         return (dy.float() @ w.float()).to(dy.dtype)
 
+    @staticmethod
+    def stem_pair_supported(d_in, d_out, dtype):
+        return dtype == torch.bfloat16 and d_in % 4 == 0 and d_in <= 128 and d_out in (64, 128, 256)
+
+    @staticmethod
+    def stem_pair(x, w0, b0, w1, b1, shift0=None, want_stats0=False):
+        y0, st = CpuKernels.gcn_epilogue_stats(x, w0, b0, shift0, want_stats0)
+        y1 = None if w1 is None else CpuKernels.gcn_epilogue_stats(x, w1, b1)[0]
+        return y0, y1, st
+
     # ---- graph-side planning (oracle/graph_oracle.py) ----
     @staticmethod
     def graph_prologue(ei, n, undirected, remove_loops, add_loops):

@@ -907,3 +907,51 @@ def test_attn_h_backward_split_form(cuda, n, d):
     assert _rel(hs_old, hstats) <= 2e-3
     dh_old = K.attn_h_bwd_apply(hc, gc, out, den, M.to(cuda), w.to(cuda), D.to(cuda), ds.to(cuda))
     assert torch.equal(dh_old, dh)
+
+
+@pytest.mark.parametrize("n,f,d", [(1, 100, 64), (77, 100, 256), (3001, 128, 128), (1000, 64, 256), (20001, 100, 256),
+                                   (500, 4, 64)])
+def test_stem_pair(cuda, n, f, d):
+    """K10, large/ours.py:77 and :198: both branches' first Linear from one read of x (rows of f bf16 elements, 8-byte
+    aligned only), against fp64 ON THE HOST of the same bf16 operands; the first output's BatchNorm sums against fp64
+    sums of the returned tensor; one-output form; gradients through ops.stem_pair against fp64."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + f + d)
+    x = torch.randn(n, f, generator=g).bfloat16()
+    w0 = (torch.randn(d, f, generator=g) / f ** 0.5)
+    w1 = (torch.randn(d, f, generator=g) / f ** 0.5)
+    b0, b1 = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    shift = torch.randn(d, generator=g) * 0.1
+    assert ops.K.stem_pair_supported(f, d, torch.bfloat16)
+    xc = x.to(cuda)
+    w0c, w1c = w0.bfloat16().to(cuda), w1.bfloat16().to(cuda)
+    y0, y1, st = ops.K.stem_pair(xc, w0c, b0.to(cuda), w1c, b1.to(cuda), shift.to(cuda), want_stats0=True)
+    r0 = x.double() @ w0.bfloat16().double().t() + b0.double()
+    r1 = x.double() @ w1.bfloat16().double().t() + b1.double()
+    assert bool(((y0.double().cpu() - r0).abs() <= 2.0 ** -8 * r0.abs() + 1e-6).all())
+    assert bool(((y1.double().cpu() - r1).abs() <= 2.0 ** -8 * r1.abs() + 1e-6).all())
+    v = y0.double().cpu() - shift.double()
+    st_ref = torch.cat([v.sum(0), (v * v).sum(0)])
+    tol = 2e-6 * torch.cat([v.abs().sum(0), (v * v).sum(0)]).clamp_min(1e-3)
+    assert bool(((st.double().cpu() - st_ref).abs() <= tol).all())
+    ya, none1, none2 = ops.K.stem_pair(xc, w0c, None, None, None)
+    ra = x.double() @ w0.bfloat16().double().t()
+    assert none1 is None and none2 is None
+    assert bool(((ya.double().cpu() - ra).abs() <= 2.0 ** -8 * ra.abs() + 1e-6).all())
+    # autograd form
+    w0g, w1g = w0.to(cuda).requires_grad_(True), w1.to(cuda).requires_grad_(True)
+    b0g, b1g = b0.to(cuda).requires_grad_(True), b1.to(cuda).requires_grad_(True)
+    go0 = torch.randn(n, d, generator=g).bfloat16()
+    go1 = torch.randn(n, d, generator=g).bfloat16()
+    assert ops.stem_pair_supported(xc, w0g, w1g)
+    (z0, z1), stats = ops.stem_pair(xc, w0g, b0g, w1g, b1g, want_stats0=True)
+    (z0.float() * go0.to(cuda).float()).sum().backward(retain_graph=True)
+    (z1.float() * go1.to(cuda).float()).sum().backward()
+    assert torch.equal(z0, y0) and torch.equal(z1, y1)
+    mean, var, cnt = stats
+    yd = y0.double().cpu()
+    assert cnt == float(n) and float((mean.double().cpu() - yd.mean(0)).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max()))
+    if n > 1:
+        assert _rel(var, yd.var(0, unbiased=False)) <= 1e-5
+    assert _rel(w0g.grad, go0.double().t() @ x.double()) <= 2e-5 and _rel(w1g.grad, go1.double().t() @ x.double()) <= 2e-5
+    assert _rel(b0g.grad, go0.double().sum(0)) <= 2e-5 and _rel(b1g.grad, go1.double().sum(0)) <= 2e-5

@@ -313,7 +313,10 @@ size_t sgf_attn_h_bwd_apply_workspace_bytes(int64_t n, int32_t d, int32_t dtype)
  *                                   and rowscal[n][2] = (1 / den, dden = -(g . out) / den) per node;
  *   sgf_attn_h_bwd_reduce_scaled  : hstats as sgf_attn_h_bwd_reduce, from h, g and rowscal — two streams instead of
  *                                   three (no `out`, no per-row dot);
- *   sgf_attn_h_bwd_post           : dh = h D + ds + partial.
+ *   sgf_attn_h_bwd_post           : dh = h D + ds + partial [+ addend].  `addend` (nullable, storage dtype, leading
+ *                                   dim ldadd): a second gradient of h — the residual branch's, large/ours.py:206-208 uses
+ *                                   the layer input twice — added to the rounded result here instead of in a separate
+ *                                   three-tensor pass.
  * sgf_attn_h_bwd_reduce + sgf_attn_h_bwd_apply remain for everything else. */
 int32_t sgf_attn_h_bwd_split_supported(int32_t d, int32_t dtype);
 int sgf_attn_h_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, int32_t d,
@@ -323,7 +326,8 @@ int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const void* g, int6
                                  int32_t d, int32_t dtype, float* hstats, void* workspace, size_t workspace_bytes,
                                  void* stream);
 int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* D, const float* ds,
-                        const void* workspace, size_t workspace_bytes, void* dh, int64_t lddh, void* stream);
+                        const void* workspace, size_t workspace_bytes, const void* addend, int64_t ldadd, void* dh,
+                        int64_t lddh, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for

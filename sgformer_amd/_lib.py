@@ -71,7 +71,8 @@ SIGNATURES = {
     "sgf_attn_h_bwd_pre": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P, _P]),
     "sgf_attn_h_bwd_reduce_scaled": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t,
                                                _P]),
-    "sgf_attn_h_bwd_post": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P, c_int64, _P]),
+    "sgf_attn_h_bwd_post": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P, c_int64, _P,
+                                      c_int64, _P]),
     "sgf_gram_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sgf_gram": (c_int32, [_P, c_int64, c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P,
                            _P, c_size_t, _P]),

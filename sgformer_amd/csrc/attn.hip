@@ -1427,8 +1427,8 @@ extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const vo
 }
 
 extern "C" int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* D,
-                                   const float* ds, const void* workspace, size_t workspace_bytes, void* dh,
-                                   int64_t lddh, void* stream) {
+                                   const float* ds, const void* workspace, size_t workspace_bytes, const void* addend,
+                                   int64_t ldadd, void* dh, int64_t lddh, void* stream) {
   int rc = check_common("sgf_attn_h_bwd_post", n, 1, d, dtype);
   if (rc != SGF_OK) return rc;
   SGF_REQUIRE(sgf_attn_h_bwd_split_supported(d, dtype), SGF_E_UNSUPPORTED,
@@ -1439,7 +1439,9 @@ extern "C" int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_
               "sgf_attn_h_bwd_post: rows must be 16-byte aligned");
   SGF_REQUIRE(workspace && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 && workspace_bytes >= hrow_partial_bytes(n, d),
               SGF_E_WORKSPACE, "sgf_attn_h_bwd_post: workspace %zu < %zu", workspace_bytes, hrow_partial_bytes(n, d));
-  return hrow_bwd_post(h, ldh, n, d, D, ds, workspace, dh, lddh, static_cast<hipStream_t>(stream));
+  SGF_REQUIRE(!addend || (reinterpret_cast<uintptr_t>(addend) % 16 == 0 && ldadd % 8 == 0 && ldadd >= d), SGF_E_INVALID,
+              "sgf_attn_h_bwd_post: addend rows must be 16-byte aligned");
+  return hrow_bwd_post(h, ldh, n, d, D, ds, workspace, addend, ldadd, dh, lddh, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t sgf_attn_stats_len(int32_t heads, int32_t d) {

@@ -132,7 +132,7 @@ int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const
 int hrow_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, int d,
                  const float* M, const float* w, void* partial, float* rowscal, hipStream_t st);
 int hrow_bwd_post(const void* h, int64_t ldh, int64_t n, int d, const float* Dm, const float* ds, const void* partial,
-                  void* dh, int64_t lddh, hipStream_t st);
+                  const void* addend, int64_t ldadd, void* dh, int64_t lddh, hipStream_t st);
 int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den,
              int64_t n, int d, const float* M, const float* w, const float* Dm, const float* ds, void* dh, int64_t lddh,
              void* partial, hipStream_t st);

@@ -309,6 +309,8 @@ struct HRowArgs {
   uint4* part;                           // B1: written    B2: read
   int64_t n;
   float2* rowscal;                       // B1, optional: (1 / den, dden = -(g.o) / den) per row, for the reduce pass
+  const uint16_t* addend; int64_t ldadd;  // B2, optional: a row-major tensor added to the (rounded) result — the second
+                                         // gradient of a tensor with two consumers, instead of a separate add pass
 };
 
 template <int D, int MODE>
@@ -531,9 +533,21 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_hrow_bf16(HRowArgs p) {
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
-          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
+          uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n) {
+            if (MODE == kHB2 && p.addend) {
+              const uint4 ad = *reinterpret_cast<const uint4*>(p.addend + (row0 + 16 * hh + 8 * q + (lane >> 3)) * p.ldadd +
+                                                               64 * u + 8 * (lane & 7));
+              const uint32_t a4[4] = {ad.x, ad.y, ad.z, ad.w};
+              uint32_t v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v4[e] = cvt_pk_bf16(__uint_as_float(v4[e] << 16) + __uint_as_float(a4[e] << 16),
+                                    __uint_as_float(v4[e] & 0xffff0000u) + __uint_as_float(a4[e] & 0xffff0000u));
+              v = make_uint4(v4[0], v4[1], v4[2], v4[3]);
+            }
             *reinterpret_cast<uint4*>(yrow + (16 * hh + 8 * q) * p.ldo + 64 * u) = v;
+          }
         }
         wave_lds_sync();
       }
@@ -814,7 +828,7 @@ size_t hrow_partial_bytes(int64_t n, int d) { return static_cast<size_t>((n + 31
 int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const float* m, const float* w,
              const float* beta, void* out, int64_t ldo, float* den, hipStream_t st) {
   HRowArgs a{static_cast<const uint16_t*>(h), ldh, nullptr, 0, M, 0, m, w, beta, den, static_cast<uint16_t*>(out), ldo,
-             nullptr, n, nullptr};
+             nullptr, n, nullptr, nullptr, 0};
   return launch_hrow<kHF>(a, d, st);
 }
 
@@ -822,15 +836,17 @@ int hrow_fwd(const void* h, int64_t ldh, int64_t n, int d, const float* M, const
 int hrow_bwd_pre(const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, int d,
                  const float* M, const float* w, void* partial, float* rowscal, hipStream_t st) {
   HRowArgs a{static_cast<const uint16_t*>(g), ldg, static_cast<const uint16_t*>(o), ldo, M, 1, w, nullptr, nullptr,
-             const_cast<float*>(den), nullptr, 0, static_cast<uint4*>(partial), n, reinterpret_cast<float2*>(rowscal)};
+             const_cast<float*>(den), nullptr, 0, static_cast<uint4*>(partial), n, reinterpret_cast<float2*>(rowscal),
+             nullptr, 0};
   return launch_hrow<kHB1>(a, d, st);
 }
 
 // dh = h D + ds + part
 int hrow_bwd_post(const void* h, int64_t ldh, int64_t n, int d, const float* Dm, const float* ds, const void* partial,
-                  void* dh, int64_t lddh, hipStream_t st) {
+                  const void* addend, int64_t ldadd, void* dh, int64_t lddh, hipStream_t st) {
   HRowArgs b{static_cast<const uint16_t*>(h), ldh, nullptr, 0, Dm, 0, ds, nullptr, nullptr, nullptr,
-             static_cast<uint16_t*>(dh), lddh, const_cast<uint4*>(static_cast<const uint4*>(partial)), n, nullptr};
+             static_cast<uint16_t*>(dh), lddh, const_cast<uint4*>(static_cast<const uint4*>(partial)), n, nullptr,
+             static_cast<const uint16_t*>(addend), ldadd};
   return launch_hrow<kHB2>(b, d, st);
 }
 
@@ -839,7 +855,7 @@ int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void*
              void* partial, hipStream_t st) {
   int rc = hrow_bwd_pre(g, ldg, o, ldo, den, n, d, M, w, partial, nullptr, st);
   if (rc != SGF_OK) return rc;
-  return hrow_bwd_post(h, ldh, n, d, Dm, ds, partial, dh, lddh, st);
+  return hrow_bwd_post(h, ldh, n, d, Dm, ds, partial, nullptr, 0, dh, lddh, st);
 }
 
 }  // namespace sgf

@@ -370,15 +370,15 @@ class HipKernels:
         return hstats
 
     @staticmethod
-    def attn_h_bwd_post(h, D, ds):
-        """dh = h D + ds + the scratch attn_h_bwd_pre left on this stream."""
+    def attn_h_bwd_post(h, D, ds, addend=None):
+        """dh = h D + ds + the scratch attn_h_bwd_pre left on this stream [+ addend, a second gradient of h]."""
         n, d = h.shape
         dev = h.device
         ws = _workspace(dev, "attn_h_part", _lib.load().sgf_attn_h_bwd_apply_workspace_bytes(n, d, _code(h)))
         dh = torch.empty((n, d), dtype=h.dtype, device=dev)
         with torch.cuda.device(dev):
             _lib.call("sgf_attn_h_bwd_post", _ptr(h), _ld(h), n, d, _code(h), _ptr(D), _ptr(ds), _ptr(ws), ws.numel(),
-                      _ptr(dh), dh.stride(0), _stream(dev))
+                      _ptr(addend), 0 if addend is None else _ld(addend), _ptr(dh), dh.stride(0), _stream(dev))
         return dh
 
     # ---- T4: dW = a^T b, db = colsum(a) ----
@@ -1112,10 +1112,13 @@ class _AttentionFromInput(torch.autograd.Function):
     input").  wv / bv None = V is h itself (use_weight=False, large/ours.py:128)."""
 
     @staticmethod
-    def forward(ctx, h, wq, bq, wk, bk, wv, bv, shard, n_override, sum_v=False):
+    def forward(ctx, h, wq, bq, wk, bk, wv, bv, shard, n_override, sum_v=False, tap=None):
         K.check(h)
         h = _rows(h)
         n, d = h.shape
+        ctx.tap = tap
+        if tap is not None:
+            tap["armed"] = tap["sibling"] = True   # a GradTap on the same input may hand its gradient to this node's backward
         f32 = [t.detach().float() for t in (wq, bq, wk, bk)]
         if wv is None:
             f32 += [torch.eye(d, dtype=_F32, device=h.device), torch.zeros(d, dtype=_F32, device=h.device)]
@@ -1160,21 +1163,65 @@ class _AttentionFromInput(torch.autograd.Function):
             grads = torch.autograd.grad(outs, leaves, grad_outputs=(dM, dm, dw_, dbeta), allow_unused=True)
         dG, ds = grads[0], grads[1]
         D = (dG + dG.t()).contiguous()
-        dh = K.attn_h_bwd_post(h, D, ds.contiguous()) if split else \
-            K.attn_h_bwd_apply(h, g, out, den, M, w, D, ds.contiguous())
+        # the other gradient of h (the residual branch's, parked by a GradTap that ran before this node) is added in
+        # the last pass instead of by autograd's separate three-tensor add
+        extra = None
+        if ctx.tap is not None:
+            extra = ctx.tap.pop("grad", None)
+            if extra is None:
+                ctx.tap["armed"] = False     # the tap has not run yet: tell it to pass its gradient through
+        if split:
+            fold = extra is not None and extra.dtype == h.dtype and extra.shape == h.shape
+            dh = K.attn_h_bwd_post(h, D, ds.contiguous(), _rows16(extra) if fold else None)
+            if extra is not None and not fold:
+                dh = dh + extra
+        else:
+            dh = K.attn_h_bwd_apply(h, g, out, den, M, w, D, ds.contiguous())
+            if extra is not None:
+                dh = dh + extra
         pg = list(grads[2:])
         if shard is not None:   # parameter grads are summed over ranks again by ShardContext.sync_grads
             pg = [None if t is None else shard.unsum(t) for t in pg]
         if v_is_h:
             pg[4] = pg[5] = None
         pg = [None if (t is None or dt is None) else t.to(dt) for t, dt in zip(pg, dtypes)]
-        return (dh, *pg, None, None, None)
+        return (dh, *pg, None, None, None, None)
 
 
-def attention_from_input(h, wq, bq, wk, bk, wv=None, bv=None, shard=None, n_total=None, sum_v=False):
+def attention_from_input(h, wq, bq, wk, bk, wv=None, bv=None, shard=None, n_total=None, sum_v=False, tap=None):
     """One-head linear attention from the un-projected input.  sum_v=True: DIFFormer's 'simple' kernel
-    (numerator q S + sum_l V_l instead of q S + N V_n; medium/difformer.py:18-39)."""
-    return _AttentionFromInput.apply(h, wq, bq, wk, bk, wv, bv, shard, n_total, sum_v)
+    (numerator q S + sum_l V_l instead of q S + N V_n; medium/difformer.py:18-39).  tap: see grad_tap."""
+    return _AttentionFromInput.apply(h, wq, bq, wk, bk, wv, bv, shard, n_total, sum_v, tap)
+
+
+class _GradTap(torch.autograd.Function):
+    """Identity.  Its backward PARKS the incoming gradient in `holder` when a sibling consumer of the same tensor
+    (attention_from_input(..., tap=holder)) has armed it, and returns nothing itself: the sibling's last kernel adds
+    the parked gradient to its own.  Works in either execution order of the two backward nodes (the engine runs the
+    node created later first, so call grad_tap AFTER the sibling's forward): if the sibling already ran, the
+    gradient passes through and autograd adds as usual."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        holder = ctx.holder
+        if holder.get("armed"):
+            holder["grad"] = g
+            return None, None
+        holder["armed"] = bool(holder.get("sibling"))    # the sibling ran first: pass through, re-arm for a next backward
+        return g, None
+
+
+def grad_tap(x, holder):
+    """x, as the SECOND consumer of a tensor whose first consumer is attention_from_input(x, ..., tap=holder)
+    (large/ours.py:206-208: the layer input feeds the attention and the residual)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return _GradTap.apply(x, holder)
 
 
 def attention_stats(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):

@@ -292,7 +292,9 @@ class TransConvLayer(nn.Module):
         kv = ops.linear(source_input, torch.cat(ws[1:], 0), torch.cat(bs[1:], 0))
         return torch.cat([q, kv], 1)
 
-    def forward(self, query_input, source_input, output_attn=False):
+    def forward(self, query_input, source_input, output_attn=False, grad_tap=None):
+        """`grad_tap` (not in the reference signature): an ops.grad_tap holder — the caller uses the layer input a
+        second time and wants that gradient folded into this layer's last backward kernel."""
         ops._require_cuda(query_input, source_input)
         h, d = self.num_heads, self.out_channels
         if (h == 1 and query_input is source_input and not output_attn and query_input.shape[1] == d
@@ -302,7 +304,7 @@ class TransConvLayer(nn.Module):
             # un-projected layer input").
             wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             return ops.attention_from_input(query_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
-                                            self.Wk.bias, wv, bv, self._shard)
+                                            self.Wk.bias, wv, bv, self._shard, tap=grad_tap)
         qkv = self._project(query_input, source_input)
         v_ext = None
         if not self.use_weight:
@@ -377,10 +379,17 @@ class TransConv(nn.Module):
         layer_ = [x]
         a, b = self._mix()
         for i, conv in enumerate(self.convs):
-            h = conv(x, x)
-            if self.use_residual:
+            if self.use_residual and layer_[i] is x:
+                # x feeds the attention AND the residual: the residual's gradient is handed to the attention's last
+                # backward kernel instead of being added by autograd in a separate pass (ops.grad_tap)
+                holder = {}
+                h = conv(x, x, grad_tap=holder)
+                x = self._ln(self.bns[i + 1], h, ops.grad_tap(x, holder), a, b, self.use_act)
+            elif self.use_residual:
+                h = conv(x, x)
                 x = self._ln(self.bns[i + 1], h, layer_[i], a, b, self.use_act)
             else:
+                h = conv(x, x)
                 x = self._ln(self.bns[i + 1], h, None, 1.0, 0.0, self.use_act)
             x = _drop(x, self.dropout, self.training)
             layer_.append(x)

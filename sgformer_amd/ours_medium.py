@@ -133,8 +133,8 @@ class GCN(nn.Module):
 
 
 class TransConvLayer(_large.TransConvLayer):
-    def forward(self, query_input, source_input, edge_index=None, edge_weight=None, output_attn=False):
-        return super().forward(query_input, source_input, output_attn=output_attn)
+    def forward(self, query_input, source_input, edge_index=None, edge_weight=None, output_attn=False, grad_tap=None):
+        return super().forward(query_input, source_input, output_attn=output_attn, grad_tap=grad_tap)
 
 
 class TransConv(_large.TransConv):

@@ -191,8 +191,9 @@ class CpuKernels:
                           dden.sum().reshape(1)])
 
     @staticmethod
-    def attn_h_bwd_post(h, D, ds):
-        return (h.float() @ D + ds + CpuKernels._h_partial.float()).to(h.dtype)
+    def attn_h_bwd_post(h, D, ds, addend=None):
+        dh = (h.float() @ D + ds + CpuKernels._h_partial.float()).to(h.dtype)
+        return dh if addend is None else (dh.float() + addend.float()).to(h.dtype)
 
     @staticmethod
     def dropout(x, res, p, seed):

@@ -955,3 +955,25 @@ def test_stem_pair(cuda, n, f, d):
         assert _rel(var, yd.var(0, unbiased=False)) <= 1e-5
     assert _rel(w0g.grad, go0.double().t() @ x.double()) <= 2e-5 and _rel(w1g.grad, go1.double().t() @ x.double()) <= 2e-5
     assert _rel(b0g.grad, go0.double().sum(0)) <= 2e-5 and _rel(b1g.grad, go1.double().sum(0)) <= 2e-5
+
+
+def test_attn_h_bwd_post_addend(cuda):
+    """sgf_attn_h_bwd_post with a second gradient folded in == the un-folded result + that gradient, rounded once more
+    (what autograd's add of the two bf16 gradients gives)."""
+    from sgformer_amd import ops
+    g_ = torch.Generator().manual_seed(9)
+    n, d = 4100, 256
+    h = torch.randn(n, d, generator=g_).bfloat16().to(cuda)
+    g = torch.randn(n, d, generator=g_).bfloat16().to(cuda)
+    extra = torch.randn(n, d, generator=g_).bfloat16().to(cuda)
+    M = (torch.randn(d, d, generator=g_) / 16).to(cuda)
+    D = (torch.randn(d, d, generator=g_) / 16).to(cuda)
+    m, w, ds = (torch.randn(d, generator=g_).to(cuda), (torch.rand(d, generator=g_) / d).to(cuda),
+                torch.randn(d, generator=g_).to(cuda))
+    beta = torch.full((1,), 3.0, device=cuda)
+    K = ops.K
+    out, den = K.attn_h_fwd(h, M, m, w, beta)
+    K.attn_h_bwd_pre(g, out, den, M, w)
+    plain = K.attn_h_bwd_post(h, D, ds)
+    folded = K.attn_h_bwd_post(h, D, ds, extra)
+    assert torch.equal(folded, (plain.float() + extra.float()).bfloat16())

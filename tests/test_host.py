@@ -576,3 +576,40 @@ def test_bf16_streaming_paths_on_the_cpu_table(cpu_table, monkeypatch, variant):
         if k.startswith("graph_conv") and k.endswith("bias") and ("fcs.0" in k or ".W." in k):
             continue      # a bias in front of a BatchNorm: its exact gradient is zero, what is there is rounding noise
         assert _rel(g_f[k], g_u[k]) <= 0.2, k      # bf16 noise through BatchNorm at N = 700; gross agreement only
+
+
+def test_grad_tap_folds_the_second_gradient(cpu_table, monkeypatch):
+    """ops.grad_tap + attention_from_input(tap=...): the residual's gradient of the layer input reaches the attention's
+    backward (folded into its last pass) or passes through autograd — the total is the same in either execution
+    order of the two backward nodes, and over a retained graph twice."""
+    from sgformer_amd import ops
+    monkeypatch.setattr(ops, "_require_cuda", lambda *a, **k: None)
+    torch.manual_seed(0)
+    n, d = 300, 64
+    for dtype in (torch.bfloat16, torch.float32):
+        x = (torch.rand(n, d) + 0.1).to(dtype).requires_grad_(True)
+        ws = [torch.randn(d, d) / 8 for _ in range(3)]
+        bs = [torch.randn(d) * 0.1 for _ in range(3)]
+        wgt = torch.randn(n, d)
+
+        def total(use_tap, tap_first=True):
+            x.grad = None
+            holder = {} if use_tap else None
+            if use_tap and not tap_first:                    # create the tap's node BEFORE the attention's: it runs last
+                r = ops.grad_tap(x, holder)
+                h = ops.attention_from_input(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], None, 4.0, tap=holder)
+            else:
+                h = ops.attention_from_input(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], None, 4.0, tap=holder)
+                r = ops.grad_tap(x, holder) if use_tap else x
+            y = ((h.float() + 0.5 * r.float()) * wgt).sum()
+            y.backward(retain_graph=True)
+            g1 = x.grad.clone()
+            x.grad = None
+            y.backward()
+            return g1, x.grad.clone()
+
+        ref, ref2 = total(False)
+        for first in (True, False):
+            a, b = total(True, first)
+            tol = 1e-6 if dtype == torch.float32 else 2e-2
+            assert _rel(a.float(), ref.float()) <= tol and _rel(b.float(), ref2.float()) <= tol, (dtype, first)

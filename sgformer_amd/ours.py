@@ -502,6 +502,8 @@ class SGFormer(nn.Module):
             with torch.cuda.stream(side):
                 x1 = self.trans_conv(x) if stem_t is None else self.trans_conv(x, stem=stem_t)
             x.record_stream(side)
+            if stem_t is not None:
+                stem_t.record_stream(side)
             x2 = self.graph_conv(x, edge_index) if stem_g is None else self.graph_conv(x, edge_index, stem=stem_g)
             cur.wait_stream(side)
             x1.record_stream(cur)

@@ -346,3 +346,76 @@ def test_bench_inputs_and_step_under_gloo(workload):
             assert e["targets_local"]
         assert e["grads_equal"] and e["loss"] == e["loss"] and 0 < e["loss"] < 50
     assert ret[0]["loss"] == ret[1]["loss"]
+
+
+def _worker_bf16(rank, world, port, ret):
+    """bf16 storage: the square Linear layers, the two-operand Linear and both stems take the streaming row kernels,
+    whose BatchNorm sums are all-reduced INSIDE those ops (ops._linear_with_stats / _StemPair)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import sgformer_oracle as O
+        from sgformer_amd import ops, synth
+        from sgformer_amd.dist import ShardContext, shard_model, sharded_nll_loss
+        from sgformer_amd.ours import SGFormer
+        from tests.cpu_kernels import CpuKernels
+
+        ops.set_kernels(CpuKernels())
+        cfg = dict(synth.RECIPES["ogbn-products"])
+        n, f, d, c = 403, 12, 64, 4
+        torch.manual_seed(5)
+        x = torch.randn(n, f)
+        ei = O.synthetic_graph(n, 6.0, seed=4)
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: n // 2]
+
+        def build():
+            torch.manual_seed(17)
+            return SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16, **cfg).train()
+
+        calls = {"stem": 0, "cat": 0}
+        for name, key in (("stem_pair", "stem"), ("gcn_epilogue_cat", "cat")):
+            orig = getattr(CpuKernels, name)
+            setattr(CpuKernels, name, staticmethod(
+                lambda *a, _o=orig, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _o(*a, **k))[1]))
+        ctx = ShardContext(n)
+        m = build()
+        shard_model(m, ctx)
+        logits = m(ctx.shard_rows(x), ei)
+        loss = sharded_nll_loss(logits, ctx.shard_rows(y), ctx.local_index(idx), idx.numel())
+        loss.backward()
+        ctx.sync_grads(m.parameters())
+        sharded_calls = dict(calls)
+
+        ref_m = build()                                   # the same model, one process, same kernel table
+        ref = ref_m(x, ei)
+        torch.nn.functional.nll_loss(torch.log_softmax(ref.float(), 1)[idx], y[idx]).backward()
+        errs = {"logits": float((logits.detach().float() - ref.detach().float()[ctx.r0:ctx.r1]).abs().max()),
+                "scale": float(ref.detach().float().abs().max()), "calls": sharded_calls}
+        gerr = 0.0
+        rg = dict(ref_m.named_parameters())
+        for k, prm in m.named_parameters():
+            if prm.grad is None or (k.startswith("graph_conv") and k.endswith("bias") and ("fcs.0" in k or ".W." in k)):
+                continue
+            den = float(rg[k].grad.double().norm())
+            gerr = max(gerr, float((prm.grad.double() - rg[k].grad.double()).norm()) / max(den, 1e-6))
+        errs["grad"] = gerr
+        sd, rsd = m.state_dict(), ref_m.state_dict()
+        errs["running_var"] = max(float((sd[k] - rsd[k]).abs().max() / rsd[k].abs().max()) for k in sd if "running_var" in k)
+        ret[rank] = errs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_bf16_streaming_paths_match_single_process():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_bf16, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        e = ret[rank]
+        assert e["calls"]["stem"] >= 2 and e["calls"]["cat"] >= 3, e
+        assert e["logits"] <= 3e-2 * max(1.0, e["scale"]), e
+        assert e["grad"] <= 0.2, e
+        assert e["running_var"] <= 2e-2, e

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_row(
 // is hit.  Per row there is no dependent latency left at all; per group there is one.
 // Rows longer than lq.long_len go to the long-row queue as in the other kernels: a wave that owns one (or
 // whose entry count does not fit the 32-bit stream positions) takes the per-row fallback below.
-constexpr int kSegRows = 8;
+constexpr int kSegRows = 4;   // 2: 3.42 ms, 4: 3.23, 8: 3.28-3.31, 16: 4.4 (community graph after sgf_reorder; more rows per wave = a larger
+                              // concurrent footprint per XCD than its 4 MiB L2 holds)
 
 template <typename T, int G>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_seg(

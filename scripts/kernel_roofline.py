@@ -47,14 +47,18 @@ def main(path: str, elem: int):
              gather, D * elem, gather / (spmm_us * 1e-6) / 1e3) if spmm_us else "", find),
         ("k_reduce_bf16<256,Gram,16>  (sgf_gram: G, dW)", ("k_reduce_bf16<256, 2, 16>",), 2 * T, "reads 2 tensors", find),
         ("k_reduce_bf16<256,BwdH,8>", ("k_reduce_bf16<256, 3, 8>",), 3 * T, "reads h, out, dout", find),
+        ("k_reduce_bf16<256,BwdHS,8>  (sgf_attn_h_bwd_reduce_scaled)", ("k_reduce_bf16<256, 4, 8>",), 2 * T + N * 8 / 1e9,
+         "reads h, dout and 8 B of row scalars per node", find),
+        ("k_stem_bf16<256>  (sgf_stem_pair)", ("k_stem_bf16<256, true>",), N * 100 * elem / 1e9 + 2 * T,
+         "x [N,100] -> both stems + BatchNorm sums; full-size launches only", find_full),
         ("k_apply_bf16<256,HFwd>", ("k_apply_bf16<256, 4, 2>",), 2 * T, "h -> out", find),
         ("k_apply_bf16<256,HBwd1>", ("k_apply_bf16<256, 5, 2>",), 3 * T, "", find),
         ("k_apply_bf16<256,HBwd2>", ("k_apply_bf16<256, 6, 2>",), 3 * T, "", find),
         ("k_hrow_bf16<256,F>  (sgf_attn_h_fwd)", ("k_hrow_bf16<256, 0>",), 2 * T, "h -> out, den", find),
-        ("k_hrow_bf16<256,B1>  (sgf_attn_h_bwd_apply, pass 1)", ("k_hrow_bf16<256, 1>",), 3 * T,
-         "reads g, out; writes the partial", find),
-        ("k_hrow_bf16<256,B2>  (sgf_attn_h_bwd_apply, pass 2)", ("k_hrow_bf16<256, 2>",), 3 * T,
-         "reads h, the partial; writes dh", find),
+        ("k_hrow_bf16<256,B1>  (sgf_attn_h_bwd_pre)", ("k_hrow_bf16<256, 1>",), 3 * T,
+         "reads g, out; writes the partial and the row scalars", find),
+        ("k_hrow_bf16<256,B2>  (sgf_attn_h_bwd_post)", ("k_hrow_bf16<256, 2>",), 4 * T,
+         "reads h, the partial, the residual's gradient; writes dh", find),
         ("k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx)", ("k_rowgemm_bf16<256, false, 0, 0>",), 2 * T, "dy -> dx", find),
         ("k_rowgemm_bf16<256,IO 1>  (sgf_gcn_epilogue_partial)", ("k_rowgemm_bf16<256, false, 1, 0>",), 2 * T,
          "a1 -> partial; full-size launches only", find_full),

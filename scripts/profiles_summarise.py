@@ -90,8 +90,8 @@ def counters(src, tag):
                 "2.5 PF is 0.13 ms against 0.4-0.6 ms of HBM time), so the matrix pipe is busy 5-30 % of the time.  The per-wave "
                 "streaming kernels of csrc/rowgemm.hip (`k_rowgemm_bf16`, `k_hrow_bf16`) and the 16-wave Gram reduce carry the "
                 "same MFMA count per byte as hipBLASLt's GEMM did and finish sooner (profiles/"
-                f"{tag}_products_bf16_kernel_roofline.md), i.e. their matrix pipe is busier; `k_reduce_bf16<256, 3, 8>` "
-                "(the three-stream attention backward reduce, 8 waves x 238 VGPRs, one staging pass in flight) is the one "
+                f"{tag}_products_bf16_kernel_roofline.md), i.e. their matrix pipe is busier; `k_reduce_bf16<256, 4, 8>` "
+                "(the attention backward reduce, 8 waves, one staging pass in flight) is the one "
                 f"left waiting.  Full table: profiles/{tag}_mfma_sq_counters.csv.\n")
 
 

@@ -941,6 +941,204 @@ __global__ __launch_bounds__(1024, MINW) void k_spmm_blk(
   }
 }
 
+// ---- LDS-staged row blocks, bf16, two entries per instruction (k_spmm_blk2) ------------------------------------------
+// k_spmm_blk above spends as many issue slots on an LDS-served entry as on a gathered one (13.8 VALU per entry, 8 bytes
+// per lane) and runs one 16-wave block per CU, so its phases add up.  This form keeps the plan (sgf_spmm_plan) and
+//   * treats a neighbour row as 32 lanes x 16 bytes: lanes 0-31 work on entry 2 j, lanes 32-63 on entry 2 j + 1 — for LDS
+//     entries one ds_read_b128 serves both (two slots), for gathered entries one 16-byte-per-lane buffer load (the
+//     k_spmm_seg_bf16x2 access), the two half-waves' sums are added when the row ends;
+//   * a lane gets ITS entry's {code, value} with one ds_read_b64 from the wave's scratch piece (base + 8 * half);
+//   * runs 64-row blocks with <= 144 staged rows (72 KiB): two 8-wave blocks per CU, one staging while the other multiplies.
+constexpr int kBlk2Stage = 8;                       // staging loads in flight per lane (16 rows per wave)
+
+template <int DG, int LB>
+__global__ __launch_bounds__(512, 2) void k_spmm_blk2(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ ecode, const float* __restrict__ eval,
+    const int32_t* __restrict__ nlds, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_cols,
+    const uint16_t* __restrict__ x, uint32_t pitch, uint32_t x_bytes, uint16_t* __restrict__ y, int64_t ldy,
+    int64_t n_rows, int32_t d, int32_t rows_per_block, int32_t lds_rows, int32_t chunk_blocks, LongQueue lq,
+    int32_t dbg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned char* const tile = smem_raw;               // [slot][512 bytes]
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(blockDim.x >> 6);
+  uint2* const scratch = reinterpret_cast<uint2*>(smem_raw + static_cast<size_t>(lds_rows) * 512) + wid * (2 * kPiece);
+  const int64_t blk = xcd_remap(blockIdx.x, gridDim.x, chunk_blocks);
+  const int q = lane & 31;
+  const int hi = lane >> 5;
+  const bool active = q * 8 < d;                      // d % 8 == 0 (checked by the launcher)
+  const uint32_t lanebase = active ? static_cast<uint32_t>(q) * 16u : 0u;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+  auto row_load = [&](uint32_t col) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(col * pitch + lanebase), 0, 0);
+  };
+
+  // ---- phase 1: stage the shared rows, two per load instruction (half-wave each) ----
+  const int s0 = sh_ptr[blk];
+  const int ns = sh_ptr[blk + 1] - s0;
+  for (int u0 = 2 * wid; u0 < ns && !(dbg & 1); u0 += 2 * nw * kBlk2Stage) {
+    u32x4 r[kBlk2Stage];
+#pragma unroll
+    for (int k = 0; k < kBlk2Stage; ++k) {
+      const int u = u0 + 2 * nw * k + hi;
+      const int uu = u < ns ? u : ns - 1;             // clamp: re-read a valid row, not stored
+      r[k] = row_load(static_cast<uint32_t>(sh_cols[s0 + uu]));
+    }
+#pragma unroll
+    for (int k = 0; k < kBlk2Stage; ++k) {
+      const int u = u0 + 2 * nw * k + hi;
+      if (u < ns) *reinterpret_cast<u32x4*>(tile + u * 512 + q * 16) = r[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2 ----
+  const int64_t r_first = blk * rows_per_block + static_cast<int64_t>(wid) * kBlkRowsPerWave;
+  if (r_first >= n_rows) return;
+  const int nr = n_rows - r_first < kBlkRowsPerWave ? static_cast<int>(n_rows - r_first) : kBlkRowsPerWave;
+  const int64_t nnz = rowptr[n_rows];
+  const int64_t rp_v = rowptr[r_first + (lane < nr ? lane : nr)];
+  const int32_t nl_v = nlds[r_first + (lane < nr ? lane : nr - 1)];
+  auto rp = [&](int i) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(rp_v & 0xffffffff), i);
+    const uint32_t hi32 = __builtin_amdgcn_readlane(static_cast<int>(rp_v >> 32), i);
+    return static_cast<int64_t>((static_cast<uint64_t>(hi32) << 32) | lo);
+  };
+  uint16_t* const yl = y + (active ? q * 8 : 0);
+  auto store_row = [&](int64_t row, const float (&a)[8]) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = a[k] + __shfl_xor(a[k], 32, 64);
+    if (active && !hi) {
+      uint4 o;
+      o.x = static_cast<uint32_t>(f32_to_bf16(t[0])) | (static_cast<uint32_t>(f32_to_bf16(t[1])) << 16);
+      o.y = static_cast<uint32_t>(f32_to_bf16(t[2])) | (static_cast<uint32_t>(f32_to_bf16(t[3])) << 16);
+      o.z = static_cast<uint32_t>(f32_to_bf16(t[4])) | (static_cast<uint32_t>(f32_to_bf16(t[5])) << 16);
+      o.w = static_cast<uint32_t>(f32_to_bf16(t[6])) | (static_cast<uint32_t>(f32_to_bf16(t[7])) << 16);
+      *reinterpret_cast<uint4*>(yl + row * ldy) = o;
+    }
+  };
+
+  int it_i = -1;
+  int64_t it_p = 0, it_e1 = 0;
+  auto next_piece = [&]() {
+    it_p += kPiece;
+    while (it_p >= it_e1) {
+      ++it_i;
+      if (it_i >= nr) return false;
+      const int64_t e0 = rp(it_i), e1 = rp(it_i + 1);
+      if (e1 - e0 > lq.long_len) {
+        push_long_row(lq, r_first + it_i, e1 - e0, lane, 64);
+        continue;
+      }
+      if (e1 == e0) {
+        if (active && !hi) *reinterpret_cast<uint4*>(yl + (r_first + it_i) * ldy) = make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      it_p = e0;
+      it_e1 = e1;
+    }
+    return true;
+  };
+  auto fetch = [&](int64_t p) -> uint2 {
+    int64_t i = p + lane;
+    if (i >= nnz) i = nnz - 1;
+    return make_uint2(static_cast<uint32_t>(ecode[i]), __float_as_uint(eval[i]));
+  };
+
+  it_p = -kPiece;
+  it_e1 = -kPiece;
+  if (!next_piece()) return;
+  uint2 pre = fetch(it_p);
+  int buf = 0;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  auto fma8 = [&](float v, const u32x4& r) {
+    acc[0] = fmaf(v, __uint_as_float(r.x << 16), acc[0]);
+    acc[1] = fmaf(v, __uint_as_float(r.x & 0xffff0000u), acc[1]);
+    acc[2] = fmaf(v, __uint_as_float(r.y << 16), acc[2]);
+    acc[3] = fmaf(v, __uint_as_float(r.y & 0xffff0000u), acc[3]);
+    acc[4] = fmaf(v, __uint_as_float(r.z << 16), acc[4]);
+    acc[5] = fmaf(v, __uint_as_float(r.z & 0xffff0000u), acc[5]);
+    acc[6] = fmaf(v, __uint_as_float(r.w << 16), acc[6]);
+    acc[7] = fmaf(v, __uint_as_float(r.w & 0xffff0000u), acc[7]);
+  };
+  for (;;) {
+    const int ci = it_i;
+    const int64_t cp = it_p, ce1 = it_e1;
+    uint2* const sc = scratch + buf * kPiece;
+    sc[lane] = pre;
+    // (read back below by other lanes of this wave: LDS executes a wave's instructions in order, the compiler must not
+    // re-order them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool more = next_piece();
+    if (more) pre = fetch(it_p);
+
+    const int64_t e0 = rp(ci);
+    const int64_t el = e0 + __builtin_amdgcn_readlane(nl_v, ci);
+    const int len = ce1 - cp < kPiece ? static_cast<int>(ce1 - cp) : kPiece;
+    const int l1x = el > cp ? (el - cp < len ? static_cast<int>(el - cp) : len) : 0;
+    const int d0 = l1x;                                 // [0, l1) LDS entries, [d0, len) gathered
+    const int l1 = (dbg & 2) ? 0 : l1x;
+    if (cp == e0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    }
+    // pair starting at piece-local entry i of a range ending at b: this half-wave's entry is i + hi; beyond the range the
+    // address is clamped to the range's last entry and the weight is 0
+    auto get = [&](int i, int b) -> uint2 {
+      const int idx = i + hi;
+      uint2 c = sc[idx < b ? idx : b - 1];
+      if (idx >= b) c.y = 0u;
+      return c;
+    };
+
+    // first group of gathers: issued now, consumed after the LDS entries
+    uint2 cv[DG];
+    u32x4 xv[DG];
+    const int ng = (dbg & 4) ? 0 : len - d0;            // gathered entries in this piece
+    if (ng > 0) {
+#pragma unroll
+      for (int u = 0; u < DG; ++u) cv[u] = get(d0 + 2 * u, len);
+#pragma unroll
+      for (int u = 0; u < DG; ++u) xv[u] = row_load(cv[u].x);
+    }
+    // LDS entries, LB pairs at a time
+    for (int j = 0; j < l1; j += 2 * LB) {
+      uint2 c[LB];
+      u32x4 t[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) c[u] = get(j + 2 * u, l1);
+#pragma unroll
+      for (int u = 0; u < LB; ++u)
+        t[u] = *reinterpret_cast<const u32x4*>(tile + (c[u].x & 0x7fffffffu) * 512 + q * 16);
+#pragma unroll
+      for (int u = 0; u < LB; ++u) fma8(__uint_as_float(c[u].y), t[u]);
+    }
+    // gathered entries
+    if (ng > 0) {
+#pragma unroll
+      for (int u = 0; u < DG; ++u) fma8(__uint_as_float(cv[u].y), xv[u]);
+      for (int g = d0 + 2 * DG; g < len; g += 2 * DG) {
+#pragma unroll
+        for (int u = 0; u < DG; ++u) cv[u] = get(g + 2 * u, len);
+#pragma unroll
+        for (int u = 0; u < DG; ++u) xv[u] = row_load(cv[u].x);
+#pragma unroll
+        for (int u = 0; u < DG; ++u) fma8(__uint_as_float(cv[u].y), xv[u]);
+      }
+    }
+    if (cp + kPiece >= ce1) store_row(r_first + ci, acc);   // last piece of the row
+    if (!more) break;
+    buf ^= 1;
+  }
+}
+
 template <typename T>
 int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eval, const int32_t* nlds,
                    const int32_t* sh_ptr, const int32_t* sh_cols, const T* x, int64_t ldx, T* y, int64_t ldy,
@@ -973,7 +1171,24 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     attr_set[which] = lds_bytes;
   }
-  if (lean)
+  const char* v2_env = getenv("SGF_SPMM_BLK2");         // "0": keep the 8-byte-per-lane kernel (A/B)
+  const uint64_t xb = static_cast<uint64_t>(n_rows) * static_cast<uint64_t>(ldx) * sizeof(T);
+  if (sizeof(T) == 2 && d % 8 == 0 && d <= 256 && ldx % 8 == 0 && ldy % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(y) % 16 == 0 && xb < (static_cast<uint64_t>(1) << 32) && threads <= 512 &&
+      !(v2_env && v2_env[0] == '0')) {
+    const size_t lds2 = static_cast<size_t>(lds_rows) * 512 + static_cast<size_t>(threads / 64) * kScratchPerWave;
+    auto fn2 = &k_spmm_blk2<8, 4>;
+    static thread_local size_t attr2 = 0;
+    if (lds2 > attr2) {
+      SGF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(lds2)));
+      attr2 = lds2;
+    }
+    hipLaunchKernelGGL(fn2, dim3(static_cast<unsigned>(nb)), dim3(threads), lds2, st, rowptr, ecode, eval, nlds, sh_ptr,
+                       sh_cols, reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
+                       static_cast<uint32_t>(xb), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d, rows_per_block,
+                       lds_rows, chunk, lq, dbg);
+  } else if (lean)
     hipLaunchKernelGGL(lean_fn, dim3(static_cast<unsigned>(nb)), dim3(threads), lds_bytes, st, rowptr, ecode, eval,
                        nlds, sh_ptr, sh_cols, x, ldx, y, ldy, n_rows, d, rows_per_block, lds_rows, chunk, lq, dbg);
   else

@@ -84,7 +84,11 @@ def test_spmm_plan_matches_oracle(cuda, name, rpb, lds_rows):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("name,rpb,lds_rows,d", [("community", 128, 144, 256), ("community", 64, 64, 128),
                                                  ("community", 8, 5, 100), ("hub_dups_isolated", 128, 144, 256),
-                                                 ("uniform", 128, 144, 64), ("directed", 32, 20, 36)])
+                                                 ("uniform", 128, 144, 64), ("directed", 32, 20, 36),
+                                                 # <= 64 rows per block, bf16, d % 8 == 0: k_spmm_blk2 (two entries per
+                                                 # instruction, two blocks per CU)
+                                                 ("community", 64, 144, 256), ("hub_dups_isolated", 64, 96, 256),
+                                                 ("uniform", 16, 8, 64), ("directed", 64, 40, 200)])
 def test_spmm_blocked_vs_oracle(cuda, dtype, name, rpb, lds_rows, d):
     """large/ours.py:34 — Y = A X through the LDS-staged kernel vs the fp64 oracle on the plain CSR."""
     from sgformer_amd import ops

@@ -1518,9 +1518,11 @@ def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:
 
 # ------------------------------------------------------------------------------------------------
 # T4: the Linear layers  y = x W^T + b  (large/ours.py:123-126, :36-40, :77, :198, :275).
-# Forward and dX stay on hipBLASLt (plain library GEMMs); the weight / bias gradients
+# bf16 storage, square layers of width 64 / 128 / 256 (and pairs [x1 | x2] of them): forward, the BatchNorm column sums of
+# the output and dX on the streaming row kernels (sgf_gcn_epilogue_*, csrc/rowgemm.hip); other shapes and fp32 storage:
+# forward and dX on hipBLASLt (plain library GEMMs).  The weight / bias gradients
 #     dW = dY^T X   (a d x d <- [N x d]^T [N x d] reduction over all nodes),   db = colsum(dY)
-# run on sgf_gram: hipBLASLt's kernels for that shape ran at 0.7 TB/s (3.6 ms per call at
+# always run on sgf_gram: hipBLASLt's kernels for that shape ran at 0.7 TB/s (3.6 ms per call at
 # ogbn-products scale, profiles/r01_products_bf16_kernel_stats.md) and ATen's column reduction for
 # the bias gradient at 18.6 ms for C = 47.  Master weights may be fp32 while activations are bf16.
 # ------------------------------------------------------------------------------------------------

@@ -10,12 +10,14 @@ backward run on the hand-written gfx950 kernels behind include/sgf.h.
     reference                                   here
     ----------------------------------------    ---------------------------------------------------
     large/ours.py:26-33  degree+argsort / layer one cached CSR per edge_index   (ops.CSRGraph)
-    large/ours.py:34     torch_sparse.matmul    ops.spmm            (k_spmm_wave / k_spmm_sub)
+    large/ours.py:34     torch_sparse.matmul    ops.spmm            (k_spmm_row / k_spmm_seg_bf16x2 / k_spmm_sub)
     large/ours.py:123-157 Wq/Wk/Wv + 2 norms    ops.attention_from_input: Gram of the layer input +
                           + 4 einsums           d x d algebra + one apply pass, Q/K/V never
                                                 materialised (one head, query == source); otherwise
                                                 one [d -> 3Hd] GEMM + ops.attention (materialised)
-    nn.Linear weights / biases under autograd   ops.linear / linear_cat: dW, db on sgf_gram
+    nn.Linear weights / biases under autograd   ops.linear / linear_cat / linear_bn_stats / stem_pair: bf16 square
+                                                layers + BatchNorm sums on k_rowgemm_bf16, both stems on k_stem_bf16,
+                                                dW / db on sgf_gram
     large/ours.py:198-216 LN / relu / residual  ops.ln_res_act      (k_ln_fwd / k_ln_bwd)
     large/ours.py:77-93  BN / relu / residual   ops.batch_stats + ops.bn_act_res
     large/ours.py:83-93  x0 used 7 times        ops.fan_out         (one fused gradient sum)
@@ -60,8 +62,8 @@ def _side_stream(device):
 
 def _lin(x, lin: nn.Linear):
     """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
-    with bf16 activations (`SGFormer.compute_dtype`).  Forward / dX on hipBLASLt, dW / db on
-    sgf_gram (ops.linear)."""
+    with bf16 activations (`SGFormer.compute_dtype`).  Forward / dX on the streaming row kernels (bf16, square
+    layers) or hipBLASLt, dW / db on sgf_gram (ops.linear)."""
     return ops.linear(x, lin.weight, lin.bias)
 
 

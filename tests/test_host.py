@@ -45,7 +45,8 @@ def test_header_binding_and_library_agree():
     for name in decls:
         assert hasattr(lib, name), f"{name} not exported"
     lib.sgf_version.restype = ctypes.c_int
-    assert lib.sgf_version() == 210
+    want = int(re.search(r"#define\s+SGF_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "sgf.h")).read()).group(1))
+    assert lib.sgf_version() == want
     # pure host queries are safe without a GPU
     lib.sgf_attn_stats_len.restype = ctypes.c_int64
     assert lib.sgf_attn_stats_len(2, 64) == 2 * 64 * 64 + 2 * 64 + 2
@@ -613,3 +614,10 @@ def test_grad_tap_folds_the_second_gradient(cpu_table, monkeypatch):
             a, b = total(True, first)
             tol = 1e-6 if dtype == torch.float32 else 2e-2
             assert _rel(a.float(), ref.float()) <= tol and _rel(b.float(), ref2.float()) <= tol, (dtype, first)
+
+
+def test_graft_entry_build_check_matches_the_header():
+    """__graft_entry__.build() (the driver's "does it build" hook) compares the library's version with include/sgf.h —
+    not with a constant that a version bump would leave behind."""
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "SGF_VERSION" in src and not re.search(r"sgf_version\(\)\s*==\s*\d", src)

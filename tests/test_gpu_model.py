@@ -165,13 +165,19 @@ def test_surface_matches_reference_contract(cuda):
     assert att.shape == (1, 300, 300)
 
 
-def test_bf16_activation_mode(cuda):
+@pytest.mark.parametrize("cfg_name,n,f,d", [("products", 3000, 40, 256),     # two-operand Linear + stems (f % 4 == 0)
+                                            ("arxiv", 2000, 24, 128),        # single-operand Linear + statistics
+                                            ("products", 1700, 100, 64),     # the headline's 100 features: ragged k-step
+                                            ("alpha_100m", 1500, 30, 64),    # f % 4 != 0: the stems stay on the library
+                                            ("heads_cat", 1200, 16, 64)])    # two heads, 'cat': materialised attention
+def test_bf16_activation_mode(cuda, cfg_name, n, f, d):
     """BASELINE.json config 3: bf16 activation storage (fp32 master weights, fp32 accumulation in
     every kernel).  The reference has no bf16 path, so parity is defined
     against the fp64 oracle with a tolerance set from the measured bf16 error: every activation is
-    rounded to 8 mantissa bits (2^-9 relative) once per op, ~25 ops deep."""
-    cfg = CONFIGS["products"]
-    n, f, d, c = 3000, 40, 256, 10
+    rounded to 8 mantissa bits (2^-9 relative) once per op, ~25 ops deep.  The recipes route the Linear layers
+    through every form of the streaming row kernels (csrc/rowgemm.hip) and through the library fallbacks."""
+    cfg = CONFIGS[cfg_name]
+    c = 10
     torch.manual_seed(3)
     x = torch.randn(n, f)
     ei = O.synthetic_graph(n, 8.0, seed=5)
@@ -194,9 +200,10 @@ def test_bf16_activation_mode(cuda):
     for k, prm in m.named_parameters():
         assert prm.grad is not None and prm.grad.dtype == torch.float32 and torch.isfinite(prm.grad).all(), k
     # the big, well-conditioned gradients agree to bf16 accuracy
-    for k in ["fc.weight", "graph_conv.convs.2.W.weight", "graph_conv.fcs.0.weight"]:
+    last = max(int(k.split(".")[2]) for k, _ in m.named_parameters() if k.startswith("graph_conv.convs."))
+    for k in ["fc.weight", f"graph_conv.convs.{last}.W.weight", "graph_conv.fcs.0.weight"]:
         g, gr = dict(m.named_parameters())[k].grad.double().cpu(), p64[k].grad
-        assert float((g - gr).norm() / gr.norm()) <= 8e-2, k
+        assert float((g - gr).norm() / gr.norm()) <= 0.12, k      # three BatchNorm layers deep in bf16: 5-8 % measured
 
 
 def test_host_tensors_are_evaluated_on_the_gpu(cuda):

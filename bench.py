@@ -302,7 +302,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
             lt = torch.tensor([loss_val], device=dev, dtype=torch.float64)
             dist.all_reduce(lt)
             loss_val = float(lt)
-        ms_aten = None
+        ms_aten = ms_launcher = None
         if with_aten and world == 1 and not state["aten"]:
             # transparency: the same step with the trainer's own ATen loss ops
             state["aten"] = True
@@ -313,6 +313,20 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                 step()
             fence()
             ms_aten = (time.perf_counter() - t1) / min(steps, 5) * 1e3
+            # ... and what the UNCHANGED trainer gets under sgformer_amd.launch: its own three loss lines with
+            # nn.NLLLoss served by the gather form (launch.patch_nll_loss)
+            from sgformer_amd import launch as _launch
+            _launch.patch_nll_loss()
+            try:
+                step()
+                fence()
+                t2 = time.perf_counter()
+                for _ in range(min(steps, 5)):
+                    step()
+                fence()
+                ms_launcher = (time.perf_counter() - t2) / min(steps, 5) * 1e3
+            finally:
+                _launch.unpatch_nll_loss()
     finally:
         timer.uninstall()
     roof = timer.summary()
@@ -327,7 +341,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
         exchanged = {"halo_bytes_sent_per_step": ctx.bytes_halo_sent // max(warmup + steps, 1),
                      "all_gather_bytes_per_step": ctx.bytes_all_gathered // max(warmup + steps, 1),
                      "all_reduce_bytes_per_step": ctx.bytes_all_reduced // max(warmup + steps, 1)}
-    out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten,
+    out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_launcher=ms_launcher,
                roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
                peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
     del model, opt, x, y
@@ -388,6 +402,8 @@ def main():
                        "loss": "F.log_softmax + F.nll_loss (ATen, as large/main.py:139-141 writes it)" if args.aten_loss
                                else "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
                        "ms_per_step_with_aten_loss": None if r["ms_aten"] is None else round(r["ms_aten"], 3),
+                       "ms_per_step_with_trainer_loss_lines_under_launcher":
+                           None if r["ms_launcher"] is None else round(r["ms_launcher"], 3),
                        "nodes": n, ("nnz_per_rank" if weak else "nnz"): r["nnz"], "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
                        "graph_view": r["view"],

@@ -16,7 +16,8 @@ trainer's directory name — `large` -> sgformer_amd.ours, `100M` -> sgformer_am
 the libsgf one) — or from --sgf-variant.  `--sgf-dtype bf16` switches every SGFormer the trainer builds to bf16
 activation storage (fp32 master weights / accumulation); the default is the reference's fp32.
 For `main-batch.py` the per-batch `torch_geometric.utils.subgraph` call is served by the GPU
-implementation in sgformer_amd.batching (`--sgf-host-subgraph 1` keeps PyG's host version).
+implementation in sgformer_amd.batching (`--sgf-host-subgraph 1` keeps PyG's host version).  The trainers' own
+`nn.NLLLoss()` runs as a gather + masked sum instead of ATen's one-block reduction (`--sgf-aten-loss 1` keeps ATen's).
 """
 from __future__ import annotations
 
@@ -103,6 +104,37 @@ def patch_resident_features():
     return ds_mod
 
 
+def patch_nll_loss():
+    """The trainers keep their own loss lines (large/main.py:139-141: log_softmax, row indexing, nn.NLLLoss).  ATen's
+    nll_loss kernels take 4.2 ms of an ogbn-products step (one-block reductions); the same arithmetic as a gather + a
+    masked sum (sgformer_amd.loss.gather_nll) takes ~0.3 ms.  Installed behind torch.nn.functional.nll_loss — which
+    nn.NLLLoss.forward looks up at call time — for exactly the case the trainers use (2-D CUDA input, 1-D int64 targets,
+    no class weights, reduction 'mean'); anything else reaches the original.  `--sgf-aten-loss 1` keeps ATen's."""
+    import torch
+    import torch.nn.functional as F
+    from .loss import gather_nll
+    orig = getattr(F.nll_loss, "_sgf_orig", F.nll_loss)
+
+    def nll_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean"):
+        if (torch.is_tensor(input) and torch.is_tensor(target) and input.is_cuda and input.dim() == 2 and target.dim() == 1
+                and input.shape[0] == target.shape[0] and input.shape[0] > 0 and weight is None and size_average is None
+                and reduce is None and reduction == "mean" and input.is_floating_point() and target.dtype == torch.long):
+            return gather_nll(input, target, ignore_index)
+        return orig(input, target, weight=weight, size_average=size_average, ignore_index=ignore_index, reduce=reduce,
+                    reduction=reduction)
+
+    nll_loss._sgf_orig = orig
+    F.nll_loss = nll_loss
+    return orig
+
+
+def unpatch_nll_loss():
+    import torch.nn.functional as F
+    orig = getattr(F.nll_loss, "_sgf_orig", None)
+    if orig is not None:
+        F.nll_loss = orig
+
+
 def limit_host_threads():
     """torch's CPU kernels (the trainer's host-side index / mask ops) slow DOWN beyond ~16 threads on the
     256-thread hosts of MI355X boxes and their OpenMP team then competes with the launch thread (the 75 ms
@@ -131,6 +163,7 @@ def main(argv=None):
     host_subgraph = _pop_option(argv, "--sgf-host-subgraph")   # any value: keep PyG's host subgraph
     host_prologue = _pop_option(argv, "--sgf-host-prologue")   # any value: keep PyG's host to_undirected & co.
     host_features = _pop_option(argv, "--sgf-host-features")   # any value: keep node features on the host
+    aten_loss = _pop_option(argv, "--sgf-aten-loss")           # any value: keep ATen's nll_loss kernels
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -154,6 +187,8 @@ def main(argv=None):
         patch_subgraph()
     if host_prologue is None and variant != "medium":
         patch_prologue()
+    if aten_loss is None:
+        patch_nll_loss()
     if os.path.basename(trainer) == "main-batch.py":
         limit_host_threads()
         if host_features is None:

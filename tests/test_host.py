@@ -621,3 +621,38 @@ def test_graft_entry_build_check_matches_the_header():
     not with a constant that a version bump would leave behind."""
     src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert "SGF_VERSION" in src and not re.search(r"sgf_version\(\)\s*==\s*\d", src)
+
+
+def test_gather_nll_equals_aten_nll_loss():
+    """sgformer_amd.loss.gather_nll (what the launcher installs behind F.nll_loss for the unchanged trainers'
+    `criterion(out[train_idx], y[train_idx])`, large/main.py:139-141) == torch's nll_loss: value and gradient, with and
+    without ignored targets (pokec's labels contain -1 -> rows a trainer may mask with ignore_index)."""
+    import torch.nn.functional as F
+    from sgformer_amd.loss import gather_nll
+    torch.manual_seed(0)
+    for ignore in (-100, -1):
+        logp = torch.log_softmax(torch.randn(500, 7, dtype=torch.float64), 1).requires_grad_(True)
+        tgt = torch.randint(0, 7, (500,))
+        tgt[::9] = ignore
+        ref = F.nll_loss(logp, tgt, ignore_index=ignore)
+        g_ref, = torch.autograd.grad(ref, logp)
+        got = gather_nll(logp, tgt, ignore)
+        g_got, = torch.autograd.grad(got, logp)
+        assert abs(float(got) - float(ref)) <= 1e-12 and float((g_got - g_ref).abs().max()) <= 1e-15
+
+
+def test_launcher_nll_patch_installs_and_restores():
+    import torch.nn.functional as F
+    from sgformer_amd import launch
+    before = F.nll_loss
+    launch.patch_nll_loss()
+    try:
+        assert F.nll_loss is not before and F.nll_loss._sgf_orig is before
+        x = torch.log_softmax(torch.randn(20, 4), 1)
+        t = torch.randint(0, 4, (20,))
+        assert torch.allclose(torch.nn.NLLLoss()(x, t), before(x, t))      # CPU input: the original is reached
+        launch.patch_nll_loss()                                            # idempotent
+        assert F.nll_loss._sgf_orig is before
+    finally:
+        launch.unpatch_nll_loss()
+    assert F.nll_loss is before

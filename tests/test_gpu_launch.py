@@ -65,3 +65,24 @@ def test_launcher_drives_a_trainer_on_the_hip_path(cuda, tmp_path):
         pred = O.sgformer_forward({k: v.detach() for k, v in pc.items()}, x, ei, cfg, training=False).argmax(1)
     acc = float((pred[split["test"]] == y[split["test"]]).float().mean()) * 100
     assert abs(acc - log[-1]["test"]) <= 1.5, (acc, log[-1])
+
+
+def test_launcher_bf16_and_loss_switches(cuda, tmp_path):
+    """`--sgf-dtype bf16` (bf16 activation storage: the streaming row kernels, stems, fused head) and `--sgf-aten-loss 1`
+    (ATen's nll_loss instead of the gather form) through the same stand-in trainer: both runs finish, the bf16 loss curve
+    follows the fp32 one to bf16 accuracy, the fp32 curve does not depend on which nll_loss served it."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(HERE, "standins"), ROOT]))
+
+    def run(*extra):
+        p = subprocess.run([sys.executable, "-m", "sgformer_amd.launch", TRAINER, "--epochs", "3", "--dump",
+                            str(tmp_path / "i.pt"), *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("STANDIN_LOG ")][0][12:])
+
+    f32 = run()
+    aten = run("--sgf-aten-loss", "1")
+    bf16 = run("--sgf-dtype", "bf16")
+    for a, b in zip(f32, aten):
+        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(a["loss"])), (a, b)
+    for a, b in zip(f32, bf16):
+        assert abs(a["loss"] - b["loss"]) <= 3e-2 * max(1.0, abs(a["loss"])), (a, b)

@@ -1213,24 +1213,29 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
            float* partial, bool stream) {
   constexpr int UNROLL = 8;
   const dim3 block(kWavesPerBlock * 64);
-  if (d > 128) {
+  const char* force = getenv("SGF_SPMM_KERNEL");          // timing experiments: wave | row | seg | seg2 | sub
+  const std::string fk = force ? force : "";
+  const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T);
+  const bool fits32 = d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32);   // 32-bit offsets reach all of X
+  const bool pair_ok = sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                       reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+  // 64 < d <= 128, bf16 (the 100M recipe's hidden width): the stream kernel with half of each half-wave idle still
+  // beats the half-wave-per-row kernel — 7.26 vs 8.39 ms = 6.35 vs 5.5 TB/s of 256-byte gathers on a uniform graph of
+  // 6 M nodes, degree 29 (scripts/spmm_d128_probe.py): no per-row tail of dependent single loads, no idle half when the
+  // two rows of a wave differ in length
+  const bool narrow_stream = d > 64 && d <= 128 && fits32 && pair_ok && fk != "sub";
+  if (d > 128 || narrow_stream) {
     const int64_t nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * sizeof(T);
-    const bool fits32 = d <= 256 && n_cols > 0 && x_bytes < (static_cast<uint64_t>(1) << 32);   // 32-bit offsets reach all of X
     // Kernel choice (A/B on one MI355X, ogbn-products scale, profiles/r02_spmm_structured.md):
     //   gathers out of HBM (uniform graph)      wave 10.46  row 10.49  seg 10.65  seg_bf16x2 10.66 ms  -> row
     //   gathers out of L2 (re-ordered, bf16)    wave  3.94  row  3.84  seg  3.96  seg_bf16x2  3.31 ms  -> seg_bf16x2
     //   gathers out of L2 (re-ordered, fp32)    wave  6.00  row  5.97  seg  7.37                       -> row
     // `stream` is the caller's statement that the CSR's gathers mostly hit in L2 (sgf_spmm_stream).
-    const char* force = getenv("SGF_SPMM_KERNEL");          // timing experiments: wave | row | seg | seg2
-    const std::string fk = force ? force : "";
-    const bool pair_ok = sizeof(T) == 2 && d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
-                         reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
     const int64_t nbs = (n_rows + kWavesPerBlock * kSegRows - 1) / (kWavesPerBlock * kSegRows);
     int chunk_rows = 4096;                                   // one XCD walks ~4096 consecutive rows at a time
     if (const char* e = getenv("SGF_SPMM_CHUNK_ROWS")) chunk_rows = atoi(e) > 0 ? atoi(e) : chunk_rows;   // experiments
     const int chunk = chunk_rows / (kWavesPerBlock * kSegRows) > 0 ? chunk_rows / (kWavesPerBlock * kSegRows) : 1;
-    if (fits32 && pair_ok && (stream || fk == "seg2"))
+    if (fits32 && pair_ok && (stream || fk == "seg2" || (narrow_stream && fk.empty())))
       hipLaunchKernelGGL((k_spmm_seg_bf16x2<16>), dim3(static_cast<unsigned>(nbs)), block, 0, st, rowptr, colind, val,
                          reinterpret_cast<const uint16_t*>(x), static_cast<uint32_t>(ldx * sizeof(T)),
                          static_cast<uint32_t>(x_bytes), reinterpret_cast<uint16_t*>(y), ldy, n_rows, d, chunk, lq);

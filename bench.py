@@ -159,8 +159,12 @@ class SpmmTimer:
             y = orig(rowptr, b, *rest, **kw)
             e1.record()
             s, d = x.element_size(), x.shape[1]
-            timer.kernels.append("k_spmm_blk" if blocked else ("k_spmm_sub" if d <= 128 else (
-                "k_spmm_seg_bf16x2" if kw.get("stream_hint") and x.dtype == torch.bfloat16 else "k_spmm_row")))
+            bf16 = x.dtype == torch.bfloat16
+            # the library's dispatch (csrc/spmm.hip::launch): stream kernel for re-ordered graphs and for bf16 rows of
+            # 65-128 elements, wave per row above 128, sub-wave per row below
+            timer.kernels.append("k_spmm_blk" if blocked else (
+                "k_spmm_seg_bf16x2" if bf16 and d % 8 == 0 and (kw.get("stream_hint") and d > 128 or 64 < d <= 128)
+                else ("k_spmm_sub" if d <= 128 else "k_spmm_row")))
             timer.pairs.append((e0, e1))
             timer.bytes_alg.append(nnz * 8 + (n_rows + 1) * 8 + x.shape[0] * d * s + n_rows * d * s)
             timer.bytes_gather.append(nnz * (8 + d * s) + (n_rows + 1) * 8 + n_rows * d * s)

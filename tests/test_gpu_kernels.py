@@ -727,6 +727,8 @@ def test_gcn_epilogue_stats_and_dx(cuda, n, d):
     y, st = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
     y2, none = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), bias.to(cuda))
     assert none is None and torch.equal(y, y2) and y.dtype == torch.bfloat16
+    y3, st3 = ops.K.gcn_epilogue_stats(a.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
+    assert torch.equal(y, y3) and torch.equal(st, st3)            # two-stage fixed-order sums: run-to-run identical
     ref = a.double() @ w.double().t() + bias.double()
     err = (y.double().cpu() - ref).abs()
     assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), float((err - 2.0 ** -8 * ref.abs()).max())

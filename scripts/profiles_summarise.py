@@ -19,7 +19,7 @@ from collections import defaultdict
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEPS_IN_TRACE = 13     # bench.py --steps 5 --warmup 2: 2 + 5 + 1 + 5 (the ATen-loss leg)
+STEPS_IN_TRACE = 19     # bench.py --steps 5 --warmup 2: 2 + 5, then 1 + 5 with the ATen loss lines, then 1 + 5 with them under the launcher
 
 
 def short(name):
@@ -41,7 +41,7 @@ def kernel_stats(src_dir, log, graph, out_base):
     with open(out_base + ".md", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --graph {graph} --steps 5 --warmup 2 "
                 f"--no-cpu-baseline --no-structured` (MI355X, bf16)\n\n")
-        f.write(f"{STEPS_IN_TRACE} training steps are in the trace (2 warm-up + 5 timed + 1 + 5 with the trainer's ATen loss ops) "
+        f.write(f"{STEPS_IN_TRACE} training steps are in the trace (2 warm-up + 5 timed, 1 + 5 with the trainer's ATen loss ops, 1 + 5 with the same lines and the launcher's nll_loss) "
                 "plus the one-off graph preparation\n(CSR build, `sgf_reorder`, `sgf_spmm_plan`: the rocPRIM / k_vote_* / "
                 f"k_keys* rows).  `ms_per_step` = total / {STEPS_IN_TRACE}; all kernels together: "
                 f"{total / 1e6 / STEPS_IN_TRACE:.2f} ms per step.\n\n")

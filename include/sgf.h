@@ -204,6 +204,64 @@ int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* e
                      int32_t lds_rows, int64_t long_len, int64_t long_segments, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * T2 on a re-ordered graph, the matrix-core form (csrc/spmm_tile.hip).   Same product as sgf_spmm
+ * (large/ours.py:34, torch_sparse.matmul, sum-reduce); bf16 storage, d = 128 or 256.
+ * After sgf_reorder a community is a run of consecutive rows whose entries mostly point back into
+ * the run: the diagonal blocks of A are 15-60 % dense.  Per block of <= 128 rows the sources that at
+ * least `min_count` of the block's entries reference are STAGED (their rows of X pass once per block
+ * through LDS) and the block's entries towards them are multiplied as a dense tile on the matrix
+ * cores (value = hi + lo bf16, relative error <= 2^-17; products of bf16 values are exact in fp32,
+ * fp32 accumulation); every other entry keeps its CSR form and is gathered; a row's two parts are
+ * added in fp32 and rounded to bf16 once.  Deterministic.  Non-finite values of X spread inside a
+ * block (0 x inf through the tile's zero cells).
+ *
+ * sgf_spmm_tile_blocks — block boundaries from the level-1 communities of sgf_reorder:
+ *   comm_sorted[p] = community of the row at NEW position p (device; NULL = fixed blocks of max_rows).
+ *   Runs of one community are packed greedily: consecutive runs share a block while they fit
+ *   max_rows (32, 64, 96 or 128); a longer run is cut into ceil(len / max_rows) pieces of
+ *   min(max_rows, round_up(ceil(len / pieces), 32)) rows.  blk_row (device, int32[blk_cap + 1]) gets
+ *   nb + 1 boundaries, *nb_out (host) the count (SGF_E_WORKSPACE with *nb_out set when blk_cap is too
+ *   small; 4 n / max_rows + 4 always suffices).  Synchronises the stream (one device -> host copy of n ints).
+ * sgf_spmm_tile_plan — for a CSR and those blocks: per block the <= cap (multiple of 32, <= 1024)
+ *   most-referenced sources with >= min_count references, most-referenced first, ties to the smaller id,
+ *   padded to a multiple of 32 with the block's first row: sh_cols[sh_ptr[b] .. sh_ptr[b+1]), slot =
+ *   position (sh_cols must hold nb * cap entries).  ecode / eval / nlds as sgf_spmm_plan (tile entries
+ *   first in every row, code 0x80000000 | slot).  tile_ptr[b] (int64[nb + 1]) = first 2 KiB fragment of
+ *   block b, ceil(rows / 32) * (slots / 16) fragments per block; rem_rowptr (int64[n + 1]) = row
+ *   pointers of the entries left on the gather path, every row's share padded to an EVEN count (the
+ *   padding repeats the row's last source with value 0: the kernel fetches two rows of X per instruction
+ *   and no pair straddles two target rows).  Rows longer than long_len stay entirely on it.
+ *   stats (int64[8], device): tile entries, staged rows incl. padding, distinct (block, source) pairs,
+ *   nnz, fragments, gathered entries incl. padding, 0, 1 if a block has 0 or more than 128 rows (plan unusable).
+ * sgf_spmm_tile_fill — the arrays whose size the plan determines: tiles (n_frag * 2048 bytes; fragment
+ *   of chunk q = slot / 32, row tile t, k-step s = (slot / 16) % 2 at tile_ptr[b] + (q * T + t) * 2 + s;
+ *   inside: [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16], lane = (row % 32) + 32 * ((slot % 16) / 8),
+ *   element slot % 8 — the A operand of v_mfma_f32_32x32x16_bf16; duplicate edges are summed in fp32 in
+ *   stored order), rem_col / rem_val (stats[5] entries, stored order + padding).
+ * sgf_spmm_tile — Y = A X with that plan.  x: [n_cols, d] bf16, n_cols * ldx * 2 < 2^32; ldx, ldy
+ *   multiples of 8, x / y 16-byte aligned.  long_len / long_segments / workspace as for sgf_spmm_split,
+ *   counted on the REMAINDER row lengths (0 segments = no row is split).
+ * ------------------------------------------------------------------------------------------ */
+int sgf_spmm_tile_supported(int32_t d, int32_t dtype);
+int sgf_spmm_tile_blocks(const int32_t* comm_sorted, int64_t n, int32_t max_rows, int32_t* blk_row,
+                         int64_t blk_cap, int64_t* nb_out, void* stream);
+size_t sgf_spmm_tile_plan_workspace_bytes(int64_t nnz, int64_t n, int64_t nb);
+int sgf_spmm_tile_plan(const int64_t* rowptr, const int32_t* colind, const float* val, int64_t n, int64_t nnz,
+                       const int32_t* blk_row, int64_t nb, int32_t cap, int32_t min_count, int64_t long_len,
+                       int32_t* ecode, float* eval, int32_t* nlds, int32_t* sh_ptr, int32_t* sh_cols,
+                       int64_t* tile_ptr, int64_t* rem_rowptr, int64_t* stats, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int sgf_spmm_tile_fill(const int64_t* rowptr, const int32_t* ecode, const float* eval, const int32_t* nlds,
+                       int64_t n, int64_t nnz, const int32_t* blk_row, int64_t nb, const int64_t* tile_ptr,
+                       int64_t n_frag, const int64_t* rem_rowptr, void* tiles, int32_t* rem_col, float* rem_val,
+                       void* stream);
+int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, const int32_t* sh_ptr, const int32_t* sh_cols,
+                  const int64_t* tile_ptr, const void* tiles, const int64_t* rem_rowptr, const int32_t* rem_col,
+                  const float* rem_val, const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy,
+                  int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* dst[i, :] = src[idx[i], :] with an optional fp32 <-> bf16 storage change.  Replaces the row
  * gathers at the module boundary: x[idx_i] of a mini-batch (large/main-batch.py:138) and the
  * x[perm] / logits[inv] pair around a re-ordered graph.  idx: int32 or int64 (idx_is_int64) device

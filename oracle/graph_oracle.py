@@ -9,6 +9,7 @@ equals the plain one (the product the reference computes) on the same inputs.
 
   reorder(ei, n, iters1, iters2)             == sgf_reorder        (csrc/reorder.hip)
   spmm_plan(rowptr, colind, val, n, R, ...)  == sgf_spmm_plan      (csrc/spmm_plan.hip)
+  tile_blocks / tile_plan                    == sgf_spmm_tile_blocks / _plan / _fill (csrc/spmm_plan.hip)
   graph_prologue(ei, n)                      == sgf_graph_prologue (csrc/prologue.hip; the trainer prologue
                                                 large/main.py:75-79)
 """
@@ -64,21 +65,21 @@ def reorder(edge_index, n, iters1=6, iters2=6):
     return perm.astype(np.int32), inv.astype(np.int32), cid.astype(np.int32)
 
 
-def spmm_plan(rowptr, colind, val, n, rows_per_block, lds_rows, long_len):
-    """ecode, eval, nlds, sh_ptr, sh_cols, stats — see csrc/spmm_plan.hip."""
+def _plan_core(rowptr, colind, val, n, blk_of_row, nb, lds_rows, long_len, min_count=2):
+    """Shared by spmm_plan and tile_plan: per block the `lds_rows` most-referenced sources with at least `min_count`
+    references (most-referenced first, ties to the smaller id) get slots; entries towards them get the code
+    0x80000000 | slot and move to the front of their row (stable).  Returns ecode, eval, nlds, nsh, cols (list of
+    per-block source arrays), flags-sum, unique count."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colind = np.asarray(colind, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
     nnz = int(colind.size)
-    nb = (n + rows_per_block - 1) // rows_per_block
     lens = np.diff(rowptr)
     rowid = np.repeat(np.arange(n, dtype=np.int64), lens)
     is_long = lens[rowid] > long_len
-    blk = rowid // rows_per_block
+    blk = np.asarray(blk_of_row, dtype=np.int64)[rowid]
     ecode = colind.astype(np.int64).copy()
     flag = np.zeros(nnz, dtype=bool)
-    sh_ptr = np.zeros(nb + 1, dtype=np.int64)
-    sh_cols_parts = []
     eligible = np.nonzero(~is_long)[0]
     key = blk[eligible] * (n + 1) + colind[eligible]
     uk, inverse, cnt = np.unique(key, return_inverse=True, return_counts=True)
@@ -88,13 +89,10 @@ def spmm_plan(rowptr, colind, val, n, rows_per_block, lds_rows, long_len):
     ub_s = ub[order]
     head = np.searchsorted(ub_s, np.arange(nb), side="left")
     rank = np.arange(order.size) - head[ub_s]
-    ok = (rank < lds_rows) & (cclip[order] >= 2)
+    ok = (rank < lds_rows) & (cclip[order] >= min_count)
     slot_of_unique = np.full(uk.size, -1, dtype=np.int64)
     slot_of_unique[order[ok]] = rank[ok]
-    nsh = np.bincount(ub_s[ok], minlength=nb)
-    sh_ptr[1:] = np.cumsum(nsh)
-    sh_cols = np.zeros(int(sh_ptr[-1]), dtype=np.int32)
-    sh_cols[sh_ptr[ub_s[ok]] + rank[ok]] = us[order][ok]
+    nsh = np.bincount(ub_s[ok], minlength=nb).astype(np.int64)
     slots = slot_of_unique[inverse]
     hit = slots >= 0
     ecode[eligible[hit]] = (1 << 31) | slots[hit]
@@ -105,8 +103,155 @@ def spmm_plan(rowptr, colind, val, n, rows_per_block, lds_rows, long_len):
     eval_out = val[part]
     nlds = np.bincount(rowid[flag], minlength=n).astype(np.int32)
     ecode_out = np.where(ecode_out >= (1 << 31), ecode_out - (1 << 32), ecode_out).astype(np.int32)
-    stats = np.array([int(flag.sum()), int(sh_ptr[-1]), int(uk.size) + int(is_long.any()), nnz], dtype=np.int64)
-    return ecode_out, eval_out, nlds, sh_ptr.astype(np.int32), sh_cols, stats
+    staged = (ub_s[ok], rank[ok], us[order][ok])        # (block, slot, source) of every staged source
+    return ecode_out, eval_out, nlds, nsh, staged, int(flag.sum()), int(uk.size) + int(is_long.any())
+
+
+def spmm_plan(rowptr, colind, val, n, rows_per_block, lds_rows, long_len):
+    """ecode, eval, nlds, sh_ptr, sh_cols, stats — see csrc/spmm_plan.hip."""
+    nb = (n + rows_per_block - 1) // rows_per_block
+    nnz = int(np.asarray(colind).size)
+    ecode, ev, nlds, nsh, (sb, sr, ss), nflag, nuniq = _plan_core(
+        rowptr, colind, val, n, np.arange(n, dtype=np.int64) // rows_per_block, nb, lds_rows, long_len)
+    sh_ptr = np.zeros(nb + 1, dtype=np.int64)
+    sh_ptr[1:] = np.cumsum(nsh)
+    sh_cols = np.zeros(int(sh_ptr[-1]), dtype=np.int32)
+    sh_cols[sh_ptr[sb] + sr] = ss
+    stats = np.array([nflag, int(sh_ptr[-1]), nuniq, nnz], dtype=np.int64)
+    return ecode, ev, nlds, sh_ptr.astype(np.int32), sh_cols, stats
+
+
+def f32_to_bf16_bits(f):
+    """round-to-nearest-even bf16 bit patterns of a float32 array (NaN preserved) — csrc/common.h f32_to_bf16."""
+    u = np.asarray(f, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
+    r = np.where(nan, (u >> 16) | 0x40, r)
+    return r.astype(np.uint16)
+
+
+def bf16_bits_to_f32(h):
+    return (np.asarray(h, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def tile_blocks(comm_sorted, n, max_rows):
+    """blk_row — sgf_spmm_tile_blocks (csrc/spmm_plan.hip): runs of one community packed greedily into blocks."""
+    out = [0]
+    if comm_sorted is None:
+        out += list(range(max_rows, n, max_rows))
+        if n > 0:
+            out.append(n)
+        return np.asarray(out, dtype=np.int32)
+    comm = np.asarray(comm_sorted)
+    cur, i = 0, 0
+    while i < n:
+        j = i + 1
+        while j < n and comm[j] == comm[i]:
+            j += 1
+        ln = j - i
+        if ln > max_rows:
+            if cur > 0:
+                out.append(i)
+                cur = 0
+            k = (ln + max_rows - 1) // max_rows
+            piece = min(max_rows, ((ln + k - 1) // k + 31) // 32 * 32)
+            pos = i
+            while pos < j:
+                pos = min(pos + piece, j)
+                out.append(pos)
+        else:
+            if cur + ln > max_rows:
+                out.append(i)
+                cur = 0
+            cur += ln
+        i = j
+    if cur > 0:
+        out.append(n)
+    return np.asarray(out, dtype=np.int32)
+
+
+def tile_plan(rowptr, colind, val, n, blk_row, cap, min_count, long_len):
+    """sh_ptr, sh_cols, tile_ptr, tiles (uint16 [fragments * 1024]), rem_rowptr, rem_col, rem_val, stats —
+    sgf_spmm_tile_plan + sgf_spmm_tile_fill (csrc/spmm_plan.hip)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    blk_row = np.asarray(blk_row, dtype=np.int64)
+    nb = blk_row.size - 1
+    nnz = int(np.asarray(colind).size)
+    row_block = np.repeat(np.arange(nb, dtype=np.int64), np.diff(blk_row))
+    ecode, ev, nlds, nsh, (sb, sr, ss), nflag, nuniq = _plan_core(rowptr, colind, val, n, row_block, nb, cap, long_len,
+                                                                 min_count)
+    nshp = (nsh + 31) // 32 * 32
+    sh_ptr = np.zeros(nb + 1, dtype=np.int64)
+    sh_ptr[1:] = np.cumsum(nshp)
+    sh_cols = np.repeat(blk_row[:-1], nshp).astype(np.int32)           # padding: the block's first row
+    sh_cols[sh_ptr[sb] + sr] = ss
+    rt = (np.diff(blk_row) + 31) // 32
+    tile_ptr = np.zeros(nb + 1, dtype=np.int64)
+    tile_ptr[1:] = np.cumsum(rt * (nshp // 16))
+    nfrag = int(tile_ptr[-1])
+    stage = np.zeros(nfrag * 512, dtype=np.float32)
+    lens = np.diff(rowptr)
+    rowid = np.repeat(np.arange(n, dtype=np.int64), lens)
+    k_in_row = np.arange(nnz, dtype=np.int64) - rowptr[rowid]
+    in_tile = k_in_row < nlds[rowid]
+    r = rowid[in_tile]
+    c = (ecode[in_tile].astype(np.int64)) & 0x7FFFFFFF
+    b = row_block[r]
+    m = r - blk_row[b]
+    f = tile_ptr[b] + ((c >> 5) * rt[b] + (m >> 5)) * 2 + ((c >> 4) & 1)
+    kk = c & 15
+    lane = (m & 31) + 32 * (kk >> 3)
+    np.add.at(stage, f * 512 + lane * 8 + (kk & 7), ev[in_tile])       # sequential: duplicates add in stored order
+    hi = f32_to_bf16_bits(stage)
+    lo = f32_to_bf16_bits(stage - bf16_bits_to_f32(hi))
+    tiles = np.empty((nfrag, 2, 64, 8), dtype=np.uint16)
+    tiles[:, 0] = hi.reshape(nfrag, 64, 8)
+    tiles[:, 1] = lo.reshape(nfrag, 64, 8)
+    # a row's gathered share is padded to an even count: the padding repeats the row's last source with value 0
+    rlen = lens - nlds
+    rpad = (rlen + 1) // 2 * 2
+    rem_rowptr = np.zeros(n + 1, dtype=np.int64)
+    rem_rowptr[1:] = np.cumsum(rpad)
+    rem_col = np.zeros(int(rem_rowptr[-1]), dtype=np.int32)
+    rem_val = np.zeros(int(rem_rowptr[-1]), dtype=np.float32)
+    dst = rem_rowptr[rowid[~in_tile]] + (k_in_row[~in_tile] - nlds[rowid[~in_tile]])
+    rem_col[dst] = ecode[~in_tile]
+    rem_val[dst] = ev[~in_tile]
+    odd = np.nonzero(rlen % 2 == 1)[0]
+    rem_col[rem_rowptr[odd + 1] - 1] = ecode[rowptr[odd + 1] - 1]
+    stats = np.array([nflag, int(sh_ptr[-1]), nuniq, nnz, nfrag, int(rem_rowptr[-1]), 0, 0], dtype=np.int64)
+    return (sh_ptr.astype(np.int32), sh_cols, tile_ptr, tiles.reshape(-1), rem_rowptr, rem_col, rem_val, stats)
+
+
+def spmm_tile(blk_row, sh_ptr, sh_cols, tile_ptr, tiles, rem_rowptr, rem_col, rem_val, x):
+    """Y = A X evaluated THROUGH the tile plan (fragment cell -> slot -> staged source; remainder CSR), float64."""
+    blk_row = np.asarray(blk_row, dtype=np.int64)
+    x = np.asarray(x, dtype=np.float64)
+    n = int(blk_row[-1])
+    y = np.zeros((n, x.shape[1]), dtype=np.float64)
+    t = np.asarray(tiles, dtype=np.uint16).reshape(-1, 2, 64, 8)
+    a = bf16_bits_to_f32(t[:, 0]).astype(np.float64) + bf16_bits_to_f32(t[:, 1]).astype(np.float64)
+    for b in range(blk_row.size - 1):
+        rows = int(blk_row[b + 1] - blk_row[b])
+        rt = (rows + 31) // 32
+        s = int(sh_ptr[b + 1] - sh_ptr[b])
+        cols = np.asarray(sh_cols[sh_ptr[b]:sh_ptr[b + 1]], dtype=np.int64)
+        for q in range(s // 32):
+            for ti in range(rt):
+                for ks in range(2):
+                    fr = a[int(tile_ptr[b]) + (q * rt + ti) * 2 + ks]          # [64 lanes][8]
+                    for lane in range(64):
+                        m = ti * 32 + (lane & 31)
+                        if m >= rows:
+                            continue
+                        for j in range(8):
+                            v = fr[lane, j]
+                            if v != 0.0:
+                                y[blk_row[b] + m] += v * x[cols[q * 32 + ks * 16 + 8 * (lane >> 5) + j]]
+    for r in range(n):
+        for e in range(int(rem_rowptr[r]), int(rem_rowptr[r + 1])):
+            y[r] += float(rem_val[e]) * x[int(rem_col[e])]
+    return y
 
 
 def spmm_blocked(rowptr, ecode, eval_, nlds, sh_ptr, sh_cols, x, rows_per_block):

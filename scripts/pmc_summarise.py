@@ -13,7 +13,8 @@ import sys
 import pandas as pd
 
 LABELS = {"k_spmm_row": ["given node order", "sgf_reorder order"], "k_spmm_seg_bf16x2": ["sgf_reorder order"],
-          "k_spmm_blk": ["sgf_reorder order, LDS-staged row blocks"]}
+          "k_spmm_blk": ["sgf_reorder order, LDS-staged row blocks"],
+          "k_spmm_tile_bf16": ["sgf_reorder order, dense tiles + gather remainder"]}
 
 
 def groups(df):

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--shapes", default="128x288")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tile", default="512,2,128", help="cap,min_count,max_rows of sgf_spmm_tile (empty: skip)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -41,7 +42,7 @@ def main():
     for _ in range(a.reps):          # group 0: given node order, row kernel (sgf_spmm)
         ops.K.spmm(g.rowptr, g.colind, g.val, x, n, long_segments=g.long_segments)
     if a.graph == "community":
-        perm, inv, _ = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
+        perm, inv, comm = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
         g2 = ops.CSRGraph(inv.long()[ei], n, validate=False)
         del ei
         xp = ops.gather_rows(x, perm)
@@ -50,6 +51,13 @@ def main():
             ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments)
         for _ in range(a.reps):      # group 2: sgf_reorder order, stream kernel (sgf_spmm_stream)
             ops.K.spmm(g2.rowptr, g2.colind, g2.val, xp, n, long_segments=g2.long_segments, stream_hint=True)
+        if a.tile:
+            cap, mc, mr = (int(t) for t in a.tile.split(","))
+            g2.blk_row = ops.K.tile_blocks(comm[perm.long()].contiguous(), n, mr, dev)
+            tplan = ops.TilePlan(g2.rowptr, g2.colind, g2.val, n, g2.blk_row, cap=cap, min_count=mc)
+            for _r in range(a.reps):  # group: dense tiles + gather remainder (sgf_spmm_tile)
+                ops.K.spmm_tile(tplan, xp, n)
+            del tplan
         for shape in a.shapes.split(","):
             if not shape:
                 continue

@@ -46,6 +46,14 @@ SIGNATURES = {
     "sgf_spmm_lds_rows_len": (c_int32, [c_int32]),
     "sgf_spmm_blocked": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32,
                                    c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
+    "sgf_spmm_tile_supported": (c_int32, [c_int32, c_int32]),
+    "sgf_spmm_tile_blocks": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    "sgf_spmm_tile_plan_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "sgf_spmm_tile_plan": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_spmm_tile_fill": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
+    "sgf_spmm_tile": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
     "sgf_gather_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                   c_int32, _P]),
     "sgf_attn_stats_len": (c_int64, [c_int32, c_int32]),

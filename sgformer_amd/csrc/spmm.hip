@@ -21,6 +21,7 @@
 //     private 4 MiB L2 caches the X rows of ONE graph neighbourhood instead of 1/8 of everybody's;
 //     chunks are dealt round-robin so that skewed graphs stay load-balanced across XCDs.
 #include "common.h"
+#include "spmm_shared.h"
 
 #include <climits>
 #include <string>
@@ -31,58 +32,11 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 
-// Blocks are dealt to the 8 XCDs in STRIPES: the hardware places block b on XCD b % 8; virtual block
-// v(b) is chosen so that each XCD walks chunks of kChunkBlocks consecutive virtual blocks (4096 rows: its
-// private 4 MiB L2 caches the X rows of one graph neighbourhood instead of 1/8 of everybody's), and
-// consecutive chunks go round-robin over the XCDs.  Round-robin rather than 8 contiguous ranges: when the
-// degree correlates with the node id (datasets sorted by popularity or time) contiguous ranges put most of
-// the work on one XCD — a power-law graph ran 1.5x slower that way.  Bijective for any nblocks.
-constexpr int64_t kChunkBlocks = 1024;
-
-__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks, int64_t chunk = kChunkBlocks) {
-  const int64_t stripe = kNumXCD * chunk;
-  const int64_t full = nblocks / stripe * stripe;
-  if (b >= full) return b;   // ragged tail: identity
-  const int64_t xcd = b % kNumXCD;
-  const int64_t j = b / kNumXCD;              // arrival order inside this XCD
-  return ((j / chunk) * kNumXCD + xcd) * chunk + j % chunk;
-}
-
 __device__ __forceinline__ void fma4(float4& acc, float v, const float4& x) {
   acc.x = fmaf(v, x.x, acc.x);
   acc.y = fmaf(v, x.y, acc.y);
   acc.z = fmaf(v, x.z, acc.z);
   acc.w = fmaf(v, x.w, acc.w);
-}
-
-// ---- long rows (power-law graphs: ogbn-products has rows of 17 k entries) ----------------------------
-// One wave walks a row serially with UNROLL gathers in flight, so a hub row would be a long latency-bound
-// tail.  Rows longer than `long_len` are therefore not processed by the row kernels: the wave that meets
-// one reserves ceil(len / kSegLen) consecutive queue slots with ONE atomic and enqueues (row, seg, k);
-// k_spmm_long_seg then reduces each segment with a whole workgroup (wave-strided slices, fixed-order
-// LDS combine) into an fp32 partial, and k_spmm_long_fin adds a row's partials in segment order.  The
-// slot reservation order is arbitrary, the arithmetic is not: results are deterministic.
-constexpr int kSegLen = 1024;
-
-struct LongEntry {
-  int32_t row, seg, k, pad;
-};
-
-struct LongQueue {
-  int32_t* count;       // [1]
-  LongEntry* entries;   // [cap]
-  int32_t cap;
-  int64_t long_len;     // rows with more stored entries than this are queued (INT64_MAX: never)
-};
-
-__device__ __forceinline__ void push_long_row(const LongQueue& q, int64_t row, int64_t len, int lane_in_group,
-                                              int group_width) {
-  const int k = static_cast<int>((len + kSegLen - 1) / kSegLen);
-  int base = 0;
-  if (lane_in_group == 0) base = atomicAdd(q.count, k);
-  base = __shfl(base, (threadIdx.x & 63) - lane_in_group, 64);
-  for (int s = lane_in_group; s < k; s += group_width)
-    if (base + s < q.cap) q.entries[base + s] = LongEntry{static_cast<int32_t>(row), s, k, 0};
 }
 
 template <typename T, int UNROLL>
@@ -143,9 +97,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_wave(
 // are requested before the current batch's FMAs, so the scalar-memory latency overlaps the gathers instead
 // of following them; the row tail goes through a 4 / 2 / 1 ladder (at most 3 dependent steps, not 7).
 // Needs n_cols * ldx * sizeof(T) < 2^32 (offsets are 32-bit); larger operands keep k_spmm_wave.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 template <typename T> struct BufRow;
 template <> struct BufRow<uint16_t> {
   using Raw = u32x2;
@@ -1279,6 +1230,29 @@ int launch(const int64_t* rowptr, const int32_t* colind, const float* val, const
 }
 
 }  // namespace
+
+int spmm_long_rows(int dtype, const int64_t* rowptr, const int32_t* colind, const float* val, const void* x, int64_t ldx,
+                   int32_t d, const LongQueue& lq, float* partial, void* y, int64_t ldy, hipStream_t st) {
+  if (lq.cap <= 0) return SGF_OK;
+  constexpr int UNROLL = 8;
+  const dim3 block(kWavesPerBlock * 64);
+  const int nb = lq.cap < 2048 ? lq.cap : 2048;
+  if (dtype == SGF_BF16) {
+    hipLaunchKernelGGL((k_spmm_long_seg<uint16_t, UNROLL>), dim3(nb), block, 0, st, rowptr, colind, val,
+                       static_cast<const uint16_t*>(x), ldx, d, lq, partial);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_spmm_long_fin<uint16_t>), dim3(nb), dim3(256), 0, st, lq, partial, d,
+                       static_cast<uint16_t*>(y), ldy);
+  } else {
+    hipLaunchKernelGGL((k_spmm_long_seg<float, UNROLL>), dim3(nb), block, 0, st, rowptr, colind, val,
+                       static_cast<const float*>(x), ldx, d, lq, partial);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_spmm_long_fin<float>), dim3(nb), dim3(256), 0, st, lq, partial, d, static_cast<float*>(y), ldy);
+  }
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
 }  // namespace sgf
 
 using namespace sgf;

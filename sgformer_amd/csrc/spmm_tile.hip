@@ -1,0 +1,478 @@
+// spmm_tile.hip — T2 on a graph with community structure: the shared part of every row block as a DENSE tile on the
+// matrix cores, the rest as a gather stream, one rounding.   (large/ours.py:34, torch_sparse.matmul, sum-reduce)
+//
+// Why (profiles/r02_spmm_structured.md): a kernel that fetches one 512-byte row of X per stored entry is
+// capped by the per-CU vector-memory path (58 GB of rows per launch at ogbn-products size = 2.2 ms even at a 100 % L2 hit
+// rate), and r02's LDS-staged row blocks paid as many issue slots for an LDS-served entry as for a gathered one.  After
+// sgf_reorder a community is a run of consecutive rows whose stored entries mostly point back into the same run, i.e.
+// the diagonal blocks of A are 15-60 % dense.  So, per block of <= 128 rows (plan: spmm_plan.hip, sgf_spmm_tile_*):
+//
+//   staged sources   the S sources at least `min_count` of the block's entries reference (own community first), S padded to
+//                    whole chunks of 32; their rows of X stream ONCE per block through a 2 x 16 KiB LDS ring, chunk by chunk,
+//                    by LDS-DMA (global_load_lds_dwordx4: no staging registers), written directly in the image the
+//                    transposing LDS read wants: [key quad][16-column subtile][4 keys][16 columns];
+//   dense tile       A[rows of the block, staged sources] lives in HBM as ready-made matrix-core A fragments, value = hi +
+//                    lo bf16 (|error| <= 2^-17 relative), built once per graph; wave t owns the 32-row tile t and all 256
+//                    feature columns: per chunk 4 coalesced 1 KiB fragment loads, 32 ds_read_b64_tr_b16 (B fragments:
+//                    k = source, n = feature, straight out of the row-major staged rows) and 32 v_mfma_f32_32x32x16_bf16
+//                    into 8 x 16 accumulator registers — products of bf16 values are exact in fp32, accumulation is fp32;
+//   remainder        the entries that are not in the tile (other communities, 20-40 %) keep their CSR form (rem_*) and
+//                    are gathered two per 16-byte-per-lane load as in k_spmm_seg_bf16x2 (spmm.hip), 16 rows per pass,
+//                    8 pair loads in flight; the tile's fp32 partial sums wait in a per-wave LDS patch (the ring's
+//                    memory, free by then) and are added when a row is finished: ONE rounding to bf16.
+//
+// A staged row is read from L2 / HBM once per block instead of once per entry, the dense part costs 0.2 ms of matrix-core
+// time at products size instead of 2 ms of gathers, and what is left on the gather path is the part no blocking can
+// serve.  Deterministic: tile order and stream order are fixed by the plan.  Non-finite values of X spread inside a block
+// (0 x inf = NaN through the tile's zero cells) — the plain kernels confine them to actual neighbours.
+#include "common.h"
+#include "spmm_shared.h"
+
+#include <type_traits>
+
+namespace sgf {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define SGF_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define SGF_GLB(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  const f32v2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2));
+}
+
+constexpr int kTileWaves = 4;                 // one 32-row tile each
+constexpr int kChunk = 32;                    // staged sources per ring slot
+constexpr int kRingPairs = 8;                 // epilogue: 1 KiB gather slots per wave (two rows of X each)
+constexpr int kStash = 256;                   // epilogue: {source, value} pairs parked in LDS per epoch
+constexpr int kMaxStaged = 1024;
+
+struct TilePlanArgs {
+  const int32_t* blk_row;        // [nb + 1]
+  const int32_t* sh_ptr;         // [nb + 1], multiples of 32
+  const int32_t* sh_cols;        // staged source ids
+  const int64_t* tile_ptr;       // [nb + 1], in 2 KiB fragments
+  const uint4* tiles;            // fragments: [chunk][row tile][k-step] x {hi 64 x 16 B, lo 64 x 16 B}
+  const int64_t* rem_rowptr;     // [n + 1]
+  const int32_t* rem_col;
+  const float* rem_val;
+};
+
+// NCT column tiles of 32 features: d = 32 * NCT
+template <int NCT, bool DMA>
+__global__ __launch_bounds__(kTileWaves * 64, 2) void k_spmm_tile_bf16(
+    TilePlanArgs P, const uint16_t* __restrict__ x, uint32_t pitch, uint32_t x_bytes, uint16_t* __restrict__ y,
+    int64_t ldy, int32_t nb, int32_t chunk_blocks, LongQueue lq, int dbg) {
+  constexpr int D = 32 * NCT;
+  constexpr int kRowBytes = D * 2;                       // one staged row
+  constexpr int kSlotBytes = kChunk * kRowBytes;         // one ring slot (16 KiB at d = 256)
+  constexpr int kQuadBytes = 4 * kRowBytes;              // 4 keys x D columns
+  constexpr int kPatchBytes = 8 * D * 4;                 // per wave: 8 rows of fp32 partial sums
+  constexpr int kRingBytesW = kRingPairs * 1024;         // per wave: the gather ring
+  constexpr int kRingBytes = 2 * kSlotBytes;
+  // [ K-loop ring, later the 4 patches ][ 4 gather rings ][ 4 stashes ]: only the patches alias the K-loop ring, so the
+  // stash can be filled while the tile phase runs
+  constexpr int kBase = kTileWaves * kPatchBytes > kRingBytes ? kTileWaves * kPatchBytes : kRingBytes;
+  constexpr int kDataBytes = kBase + kTileWaves * (kRingBytesW + kStash * 8);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kDataBytes];
+  __shared__ int32_t cols_lds[kMaxStaged];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int b = static_cast<int>(xcd_remap(blockIdx.x, nb, chunk_blocks));
+  const int row0 = P.blk_row[b];
+  const int nrows = P.blk_row[b + 1] - row0;
+  const int RT = (nrows + 31) >> 5;
+  const int s0 = P.sh_ptr[b];
+  const int S = P.sh_ptr[b + 1] - s0;
+  const int NQ = S / kChunk;
+  const uint4* __restrict__ tb = P.tiles + P.tile_ptr[b] * 128;
+  const bool mine = wid < RT;                            // this wave owns rows [row0 + 32 wid, ...)
+
+  for (int i = threadIdx.x; i < S; i += kTileWaves * 64) cols_lds[i] = P.sh_cols[s0 + i];
+  __syncthreads();
+
+  // ---- staging: chunk q -> ring slot.  A 1 KiB DMA piece = 8 subtiles [4 keys][16 columns] of ONE key quad: lane l
+  // writes the 16 bytes (key (l & 7) >> 1, columns 16 * subtile + 8 * (l & 1) ...) of subtile l >> 3.  A quad has
+  // D / 128 such pieces; the chunk's 8 quads are dealt two per wave.
+  constexpr int kPiecesPerQuad = kQuadBytes / 1024;
+  const int key_in_quad = (lane & 7) >> 1;
+  const uint32_t col_byte = static_cast<uint32_t>(((lane >> 3) * 16 + (lane & 1) * 8) * 2);
+  // The DMA is issued from inline assembly on purpose: through the builtin, hipcc orders every later LDS read behind it
+  // with s_waitcnt vmcnt(0) — the chunk being staged would be waited for before the chunk being multiplied is read.
+  // Opaque to the compiler, the only waits are the explicit vmcnt(0) + barrier at the top of the chunk loop.
+  const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(SGF_LDS(unsigned char, smem)));
+  auto stage = [&](int q, int slot) {
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      const int quad = 2 * wid + kq;
+      const int32_t src = cols_lds[q * kChunk + 4 * quad + key_in_quad];
+      const unsigned char* g = reinterpret_cast<const unsigned char*>(x) + static_cast<size_t>(src) * pitch + col_byte;
+#pragma unroll
+      for (int pc = 0; pc < kPiecesPerQuad; ++pc) {
+        const uint32_t dst = smem_lds + static_cast<uint32_t>(slot * kSlotBytes + quad * kQuadBytes + pc * 1024);
+        const unsigned char* gp = g + pc * 256;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gp), "s"(dst)
+            : "memory");
+      }
+    }
+  };
+
+  // the same image through registers (DMA == false): 16-byte-per-lane loads, written to LDS one chunk later — an
+  // LDS-DMA piece costs the CU 60-100 cycles of vector-memory issue (MI355X_MICROARCH.md), a load + ds_write_b128 ~30
+  constexpr int kStageRegs = 2 * kPiecesPerQuad;
+  typedef uint32_t sreg_t __attribute__((ext_vector_type(4 * kStageRegs)));   // a VALUE: never an alloca
+  sreg_t sreg;
+  auto stage_load = [&](int q, sreg_t& sr) {
+    const unsigned char* g[2];
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      const int32_t src = cols_lds[q * kChunk + 4 * (2 * wid + kq) + key_in_quad];
+      g[kq] = reinterpret_cast<const unsigned char*>(x) + static_cast<size_t>(src) * pitch + col_byte;
+    }
+#pragma unroll
+    for (int i = 0; i < kStageRegs; ++i)
+    {
+      const uint4 t = *reinterpret_cast<const uint4*>(g[i / kPiecesPerQuad] + (i % kPiecesPerQuad) * 256);
+      sr[4 * i] = t.x; sr[4 * i + 1] = t.y; sr[4 * i + 2] = t.z; sr[4 * i + 3] = t.w;
+    }
+  };
+  auto stage_write = [&](int slot, const sreg_t& sr) {
+    unsigned char* dst = smem + slot * kSlotBytes + 2 * wid * kQuadBytes + lane * 16;
+#pragma unroll
+    for (int i = 0; i < kStageRegs; ++i)
+      *reinterpret_cast<uint4*>(dst + (i / kPiecesPerQuad) * kQuadBytes + (i % kPiecesPerQuad) * 1024) =
+          make_uint4(sr[4 * i], sr[4 * i + 1], sr[4 * i + 2], sr[4 * i + 3]);
+  };
+
+  // ---- this wave's share of the gather stream: requested now, needed after the tile phase ---------------------------
+  const int nr = mine ? (nrows - 32 * wid < 32 ? nrows - 32 * wid : 32) : 1;
+  const int64_t r_base = mine ? static_cast<int64_t>(row0) + 32 * wid : static_cast<int64_t>(row0);
+  float* patch = reinterpret_cast<float*>(smem + wid * kPatchBytes);                // 8 rows x D fp32
+  unsigned char* ring = smem + kBase + wid * kRingBytesW;                          // kRingPairs x 1 KiB
+  int32_t* stash_col = reinterpret_cast<int32_t*>(smem + kBase + kTileWaves * kRingBytesW + wid * (kStash * 8));
+  float* stash_val = reinterpret_cast<float*>(stash_col + kStash);
+  const int half = lane >> 5;
+  const bool hi = lane >= 32;
+  const int fc = (lane & 31) * 8;
+  const bool active = fc < D;
+  const uint32_t lanebase = active ? static_cast<uint32_t>(fc) * 2u : 0u;
+  auto lane64 = [&](int64_t v, int i) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffff), i);
+    const uint32_t hi32 = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), i);
+    return static_cast<int64_t>((static_cast<uint64_t>(hi32) << 32) | lo);
+  };
+  const int64_t e_first = P.rem_rowptr[r_base];
+  const int64_t end_abs = P.rem_rowptr[r_base + 1 + (lane < nr ? lane : nr - 1)];
+  const int64_t begin_abs = __shfl_up(end_abs, 1, 64);
+  const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);
+  const bool long_i = lane < nr && len_i > lq.long_len;
+  const int64_t total64 = lane64(end_abs, nr - 1) - e_first;
+  const int32_t* __restrict__ ci = P.rem_col + e_first;
+  const float* __restrict__ va = P.rem_val + e_first;
+  const bool slow_path = __ballot(long_i) != 0 || total64 >= (static_cast<int64_t>(1) << 31);
+  const int total = (dbg & 2) ? 0 : static_cast<int>(total64);
+  auto fill_stash = [&](int base) {
+    const int ne = total - base < kStash ? total - base : kStash;
+#pragma unroll
+    for (int i = 0; i < kStash / 64; ++i) {
+      const int idx = 64 * i + lane;
+      if (idx < ne) {
+        stash_col[idx] = ci[base + idx];
+        stash_val[idx] = va[base + idx];
+      }
+    }
+  };
+
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // A fragments of chunk q for this wave's row tile: k-steps 0, 1 x {hi, lo}
+  auto load_a = [&](int q, uint4 (&a)[4]) {
+    const u32x4* f = reinterpret_cast<const u32x4*>(tb + (static_cast<int64_t>(q) * RT + wid) * 256 + lane);
+    if (dbg & 4) {                                       // A/B: the fragments are read once — streaming (nt) loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(f + 64 * i));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(uint4, f[64 * i]);
+    }
+  };
+  // B fragment address of this lane inside a ring slot: 16-lane groups read one [4 keys][16 columns] subtile each
+  const uint32_t b_lane = static_cast<uint32_t>((lane >> 5) * (2 * kQuadBytes) + (lane & 31) * 8);
+
+  const bool tiles_on = NQ > 0 && !(dbg & 1);
+  uint4 a_cur[4], a_nxt[4];
+  if (tiles_on) {                                        // chunk 0: requested together with the stash below
+    if (DMA) stage(0, 0); else stage_load(0, sreg);
+    if (mine) load_a(0, a_cur);
+  }
+  if (mine && !slow_path && total > 0) fill_stash(0);
+  if (tiles_on) {
+    if (!DMA) stage_write(0, sreg);
+    for (int q = 0; q < NQ; ++q) {
+      if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's pieces of chunk q have landed
+      __syncthreads();                                   // chunk q is complete and every
+                                                         // wave is done with the slot chunk q + 1 goes into
+      if (q + 1 < NQ) {
+        if (DMA) stage(q + 1, (q + 1) & 1); else stage_load(q + 1, sreg);
+        if (mine) load_a(q + 1, a_nxt);
+      }
+      if (mine) {
+        const unsigned char* slot = smem + (q & 1) * kSlotBytes + b_lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, a_cur[2 * s]);
+          const bf16x8 al = __builtin_bit_cast(bf16x8, a_cur[2 * s + 1]);
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) {
+            const unsigned char* p = slot + s * (4 * kQuadBytes) + t * 256;
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, p));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, p + kQuadBytes));
+            bf16x8 bb;
+            bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3];
+            bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb, acc[t], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+      }
+      if (!DMA && q + 1 < NQ) stage_write((q + 1) & 1, sreg);
+    }
+  }
+  __syncthreads();                                       // the ring is dead: its memory becomes the waves' patches
+  if (!mine) return;
+
+  // ---- epilogue: this wave's <= 32 rows ------------------------------------------------------------------------------
+  // The entries left on the gather path form ONE stream per wave (rem_* is contiguous over its rows; every row's share is
+  // padded to an even count by the plan, so a pair of stream positions never straddles two rows).  Rows of X are fetched
+  // two per instruction (lanes 0-31: the row of position 2 k, lanes 32-63: of 2 k + 1; 16 bytes per lane) in batches of
+  // kRingPairs loads; TWO batches are in flight per wave (with 128 accumulator registers there are only 8 waves per CU
+  // to cover the gathers' latency, so it has to be covered by loads in flight per wave).  A landed batch is parked in a
+  // per-wave LDS ring and its registers re-issued at once; the consumer is then a compact loop over the ring with ONE
+  // row-finish site (an unrolled register ring needs one per pair: 390 KiB of code in the first version of this kernel).
+  // {source, value} of up to kStash stream positions are parked in LDS first (coalesced loads, requested before the tile
+  // phase); longer streams take several such epochs.
+  // the tile's partial sums of rows 8 q .. 8 q + 7: accumulator register i holds row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  auto refill_q = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+      for (int i = 4 * q; i < 4 * q + 4; ++i)
+        patch[((i & 3) + 4 * (lane >> 5)) * D + 32 * t + (lane & 31)] = acc[t][i];
+  };
+  auto refill = [&](int q) {
+    if (q == 0) refill_q(std::integral_constant<int, 0>{});
+    else if (q == 1) refill_q(std::integral_constant<int, 1>{});
+    else if (q == 2) refill_q(std::integral_constant<int, 2>{});
+    else refill_q(std::integral_constant<int, 3>{});
+  };
+
+  float racc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) racc[k] = 0.f;
+  auto fma8 = [&](float v, const u32x4& r) {
+    racc[0] = fmaf(v, __uint_as_float(r.x << 16), racc[0]);
+    racc[1] = fmaf(v, __uint_as_float(r.x & 0xffff0000u), racc[1]);
+    racc[2] = fmaf(v, __uint_as_float(r.y << 16), racc[2]);
+    racc[3] = fmaf(v, __uint_as_float(r.y & 0xffff0000u), racc[3]);
+    racc[4] = fmaf(v, __uint_as_float(r.z << 16), racc[4]);
+    racc[5] = fmaf(v, __uint_as_float(r.z & 0xffff0000u), racc[5]);
+    racc[6] = fmaf(v, __uint_as_float(r.w << 16), racc[6]);
+    racc[7] = fmaf(v, __uint_as_float(r.w & 0xffff0000u), racc[7]);
+  };
+  uint16_t* __restrict__ yl = y + r_base * ldy + (active ? fc : 0);
+  // row finished: (even + odd stream positions) + the tile's partial sum, one rounding; lanes 0-31 write 8 bf16 each
+  auto flush_row = [&](int local_row) {
+    const float* pr = patch + (local_row & 7) * D + (active ? fc : 0);
+    const float4 p0 = *reinterpret_cast<const float4*>(pr);
+    const float4 p1 = *reinterpret_cast<const float4*>(pr + 4);
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = racc[k] + __shfl_xor(racc[k], 32, 64);
+    t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w;
+    t[4] += p1.x; t[5] += p1.y; t[6] += p1.z; t[7] += p1.w;
+    if (active && !hi) {
+      uint4 o;                                           // v_cvt_pk_bf16_f32: round to nearest even, like f32_to_bf16
+      o.x = pack_bf16(t[0], t[1]);
+      o.y = pack_bf16(t[2], t[3]);
+      o.z = pack_bf16(t[4], t[5]);
+      o.w = pack_bf16(t[6], t[7]);
+      if (dbg & 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(yl + local_row * ldy));
+      else *reinterpret_cast<uint4*>(yl + local_row * ldy) = o;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) racc[k] = 0.f;
+  };
+
+  refill(0);
+  if (slow_path) {
+    // rare: a hub row among these 32 (its tile part is empty by construction: the plan leaves long rows alone)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+    for (int r = 0; r < nr; ++r) {
+      if (r > 0 && (r & 7) == 0) refill(r >> 3);
+      const int64_t re = lane64(end_abs, r);
+      const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
+      if (re - rb > lq.long_len) {
+        push_long_row(lq, r_base + r, re - rb, lane, 64);
+        continue;
+      }
+      for (int64_t e = rb; e < re; ++e) {
+        const uint32_t voff = lanebase + static_cast<uint32_t>(P.rem_col[e]) * pitch;
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(voff), 0, 0);
+        if (!hi) fma8(P.rem_val[e], raw);
+      }
+      flush_row(r);
+    }
+    return;
+  }
+
+  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
+  int row = 0;
+  int row_end = (dbg & 2) ? 0 : __builtin_amdgcn_readlane(rel_v, 0);
+  // rows that end at stream position p (rows without gathered entries included)
+  auto boundary = [&](int p) {
+    while (p == row_end && row < nr) {
+      flush_row(row);
+      ++row;
+      if (row < nr) {
+        if ((row & 7) == 0) refill(row >> 3);
+        row_end = (dbg & 2) ? 0 : __builtin_amdgcn_readlane(rel_v, row);
+      }
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+  u32x4 rga[kRingPairs], rgb[kRingPairs];              // two batches of pair loads in flight
+  for (int base = 0; base < total; base += kStash) {
+    const int ne = total - base < kStash ? total - base : kStash;     // stream positions of this epoch (even)
+    const int np = ne >> 1;
+    if (base > 0) fill_stash(base);                  // (epoch 0 was parked before the tile phase)
+    // pairs b8 .. b8 + 7 (clamped to the epoch's last pair: a valid address, its value is never used)
+    auto issue_batch = [&](int b8, u32x4 (&rg)[kRingPairs]) {
+#pragma unroll
+      for (int j = 0; j < kRingPairs; ++j) {
+        const int kk = b8 + j < np ? b8 + j : np - 1;
+        const uint32_t c = static_cast<uint32_t>(stash_col[2 * kk + half]);
+        rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(lanebase + c * pitch), 0, 0);
+      }
+    };
+    // a landed batch goes through the LDS ring so that the consumer is a compact loop (one row-finish site per batch
+    // set instead of one per pair); its registers are re-issued before the batch is consumed
+    auto drain_batch = [&](int b8, u32x4 (&rg)[kRingPairs]) {
+#pragma unroll
+      for (int j = 0; j < kRingPairs; ++j) *reinterpret_cast<u32x4*>(ring + j * 1024 + lane * 16) = rg[j];
+      if (b8 + 2 * kRingPairs < np) issue_batch(b8 + 2 * kRingPairs, rg);
+      // four pairs per step: their LDS reads are issued together (one LDS latency per step, not per pair); pairs past the
+      // epoch's end read valid LDS and are skipped
+      const int nj = np - b8 < kRingPairs ? np - b8 : kRingPairs;
+      for (int j = 0; j < nj; j += 4) {
+        u32x4 raw[4];
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          raw[u] = *reinterpret_cast<const u32x4*>(ring + (j + u) * 1024 + lane * 16);
+          const int kk = b8 + j + u < np ? b8 + j + u : np - 1;
+          vv[u] = stash_val[2 * kk + half];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + u < nj) {
+            const int pos = base + 2 * (b8 + j + u);
+            if (pos == row_end) boundary(pos);
+            fma8(vv[u], raw[u]);
+          }
+        }
+      }
+    };
+    issue_batch(0, rga);
+    if (kRingPairs < np) issue_batch(kRingPairs, rgb);
+    for (int b8 = 0; b8 < np; b8 += 2 * kRingPairs) {
+      drain_batch(b8, rga);
+      if (b8 + kRingPairs < np) drain_batch(b8 + kRingPairs, rgb);
+    }
+  }
+  // closes the last row with entries and every trailing row without
+  if (dbg & 2) { row_end = 0; boundary(0); } else boundary(total);
+}
+
+}  // namespace
+}  // namespace sgf
+
+using namespace sgf;
+
+extern "C" int sgf_spmm_tile_supported(int32_t d, int32_t dtype) {
+  return dtype == SGF_BF16 && (d == 256 || d == 128) ? 1 : 0;
+}
+
+extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, const int32_t* sh_ptr, const int32_t* sh_cols,
+                             const int64_t* tile_ptr, const void* tiles, const int64_t* rem_rowptr,
+                             const int32_t* rem_col, const float* rem_val, const void* x, int64_t ldx, int64_t n_cols,
+                             void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len,
+                             int64_t long_segments, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_spmm_tile";
+  SGF_REQUIRE(n_rows >= 0 && nb >= 0 && n_cols >= 0, SGF_E_INVALID, "%s: negative size", fn);
+  if (n_rows == 0 || nb == 0) return SGF_OK;
+  SGF_REQUIRE(sgf_spmm_tile_supported(d, dtype), SGF_E_UNSUPPORTED, "%s: bf16 storage with d = 128 or 256 only (d=%d dtype=%d)",
+              fn, d, dtype);
+  SGF_REQUIRE(blk_row && sh_ptr && sh_cols && tile_ptr && rem_rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(nb < (static_cast<int64_t>(1) << 31), SGF_E_UNSUPPORTED, "%s: too many blocks", fn);
+  SGF_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(y) % 16 == 0,
+              SGF_E_INVALID, "%s: x / y rows must be 16-byte aligned (ld %% 8 == 0)", fn);
+  const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * 2;
+  SGF_REQUIRE(x_bytes < (static_cast<uint64_t>(1) << 32), SGF_E_UNSUPPORTED, "%s: x beyond 4 GiB (32-bit gather offsets)", fn);
+  SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31), SGF_E_INVALID,
+              "%s: bad long_len / long_segments", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LongQueue lq{nullptr, nullptr, 0, INT64_MAX};
+  float* partial = nullptr;
+  if (long_segments > 0) {
+    SGF_REQUIRE(workspace && workspace_bytes >= sgf_spmm_split_workspace_bytes(long_segments, d), SGF_E_WORKSPACE,
+                "%s: workspace too small", fn);
+    char* ws = static_cast<char*>(workspace);
+    lq.count = reinterpret_cast<int32_t*>(ws);
+    lq.entries = reinterpret_cast<LongEntry*>(ws + 256);
+    lq.cap = static_cast<int32_t>(long_segments);
+    lq.long_len = long_len;
+    partial = reinterpret_cast<float*>(ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
+    SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
+  }
+  TilePlanArgs P{blk_row, sh_ptr, sh_cols, tile_ptr, static_cast<const uint4*>(tiles), rem_rowptr, rem_col, rem_val};
+  // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers
+  const char* dbg_env = getenv("SGF_SPMM_TILE_DEBUG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  int chunk = 64;                                        // an XCD walks 64 consecutive blocks (<= 8192 rows) at a time
+  if (const char* e = getenv("SGF_SPMM_TILE_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
+  const dim3 block(kTileWaves * 64);
+  const uint16_t* xs = static_cast<const uint16_t*>(x);
+  uint16_t* ys = static_cast<uint16_t*>(y);
+  const char* dma_env = getenv("SGF_SPMM_TILE_DMA");     // "1": stage X through LDS-DMA instead of registers (A/B)
+  const bool dma = dma_env && dma_env[0] == '1';
+#define SGF_TILE_LAUNCH(NCT_, DMA_)                                                                                     \
+  hipLaunchKernelGGL((k_spmm_tile_bf16<NCT_, DMA_>), dim3(static_cast<unsigned>(nb)), block, 0, st, P, xs,              \
+                     static_cast<uint32_t>(ldx * 2), static_cast<uint32_t>(x_bytes), ys, ldy, static_cast<int32_t>(nb), \
+                     chunk, lq, dbg)
+  if (d == 256) {
+    if (dma) SGF_TILE_LAUNCH(8, true); else SGF_TILE_LAUNCH(8, false);
+  } else {
+    if (dma) SGF_TILE_LAUNCH(4, true); else SGF_TILE_LAUNCH(4, false);
+  }
+#undef SGF_TILE_LAUNCH
+  SGF_LAUNCH_CHECK();
+  return spmm_long_rows(dtype, rem_rowptr, rem_col, rem_val, x, ldx, d, lq, partial, y, ldy, st);
+}

@@ -238,6 +238,70 @@ class HipKernels:
                       0 if ws is None else ws.numel(), _stream(x.device))
         return y
 
+    # ---- T2 on a re-ordered graph: dense matrix-core tiles + gather remainder (csrc/spmm_tile.hip) ----
+    @staticmethod
+    def tile_supported(d: int, dtype) -> bool:
+        return bool(_lib.load().sgf_spmm_tile_supported(int(d), _lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32))
+
+    @staticmethod
+    def tile_blocks(comm_sorted: Optional[torch.Tensor], n: int, max_rows: int, device) -> torch.Tensor:
+        """blk_row int32 [nb + 1]: row blocks that follow the communities (comm_sorted[p] = community of new row p)."""
+        cap = 4 * n // int(max_rows) + 4
+        blk = torch.empty(cap + 1, dtype=torch.int32, device=device)
+        nb = ctypes.c_int64(0)
+        with torch.cuda.device(device):
+            _lib.call("sgf_spmm_tile_blocks", _ptr(comm_sorted), n, int(max_rows), _ptr(blk), cap, ctypes.byref(nb),
+                      _stream(device))
+        return blk[: nb.value + 1].clone()
+
+    @staticmethod
+    def tile_plan(rowptr, colind, val, n: int, blk_row: torch.Tensor, cap: int, min_count: int, long_len: int):
+        """(sh_ptr, sh_cols, tile_ptr, tiles, rem_rowptr, rem_col, rem_val, stats) — see include/sgf.h."""
+        dev, nnz, nb = rowptr.device, int(colind.numel()), int(blk_row.numel()) - 1
+        ecode = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        ev = torch.empty(max(nnz, 1), dtype=_F32, device=dev)
+        nlds = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        sh_ptr = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+        sh_cols = torch.empty(max(nb * cap, 1), dtype=torch.int32, device=dev)
+        tile_ptr = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        rem_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        nbytes = _lib.load().sgf_spmm_tile_plan_workspace_bytes(nnz, n, nb)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_spmm_tile_plan", _ptr(rowptr), _ptr(colind), _ptr(val), n, nnz, _ptr(blk_row), nb, int(cap),
+                      int(min_count), int(long_len), _ptr(ecode), _ptr(ev), _ptr(nlds), _ptr(sh_ptr), _ptr(sh_cols),
+                      _ptr(tile_ptr), _ptr(rem_rowptr), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
+            st = [int(v) for v in stats.tolist()]                      # one host sync, once per plan
+            del ws
+            if st[7]:
+                raise ValueError("tile_plan: a row block is empty or longer than 128 rows")
+            n_frag, n_rem = st[4], st[5]
+            tiles = torch.empty(max(n_frag, 1) * 512, dtype=torch.int32, device=dev)     # 2 KiB per fragment
+            rem_col = torch.empty(max(n_rem, 1), dtype=torch.int32, device=dev)
+            rem_val = torch.empty(max(n_rem, 1), dtype=_F32, device=dev)
+            _lib.call("sgf_spmm_tile_fill", _ptr(rowptr), _ptr(ecode), _ptr(ev), _ptr(nlds), n, nnz, _ptr(blk_row), nb,
+                      _ptr(tile_ptr), n_frag, _ptr(rem_rowptr), _ptr(tiles), _ptr(rem_col), _ptr(rem_val), _stream(dev))
+        return sh_ptr, sh_cols[: max(st[1], 1)].clone(), tile_ptr, tiles, rem_rowptr, rem_col, rem_val, st
+
+    @staticmethod
+    def spmm_tile(plan, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _rows16(x)
+        d = x.shape[1]
+        y = torch.empty((n_rows, d), dtype=x.dtype, device=x.device) if out is None else out
+        if n_rows == 0 or d == 0:
+            return y
+        segs = plan.long_segments
+        with torch.cuda.device(x.device):
+            ws = None
+            if segs > 0:
+                ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(segs, d))
+            _lib.call("sgf_spmm_tile", _ptr(plan.blk_row), plan.nb, _ptr(plan.sh_ptr), _ptr(plan.sh_cols),
+                      _ptr(plan.tile_ptr), _ptr(plan.tiles), _ptr(plan.rem_rowptr), _ptr(plan.rem_col),
+                      _ptr(plan.rem_val), _ptr(x), x.stride(0), x.shape[0], _ptr(y), y.stride(0), n_rows, d, _code(x),
+                      LONG_ROW, segs, _ptr(ws), 0 if ws is None else ws.numel(), _stream(x.device))
+        return y
+
     @staticmethod
     def lds_rows_max(dtype) -> int:
         return int(_lib.load().sgf_spmm_lds_rows_len(_lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32))
@@ -744,6 +808,22 @@ class CSRGraph:
             self._plans[key] = BlockedPlan(rp, ci, va, self.n, dtype)
         return self._plans[key]
 
+    # ---- dense matrix-core tiles + gather remainder (sgf_spmm_tile): one plan per orientation ----
+    tiled = False            # set by GraphView when the tile plan covers enough of the stored entries
+    blk_row = None           # int32 [nb + 1] row blocks that follow the communities (GraphView)
+
+    def tile_plan(self, transposed: bool = False):
+        if not hasattr(self, "_tile_plans"):
+            self._tile_plans = {}
+        if transposed:
+            self.transposed()
+            if self.symmetric:
+                transposed = False
+        if transposed not in self._tile_plans:
+            rp, ci, va = self.transposed() if transposed else (self.rowptr, self.colind, self.val)
+            self._tile_plans[transposed] = TilePlan(rp, ci, va, self.n, self.blk_row)
+        return self._tile_plans[transposed]
+
     def view(self, now: bool = False) -> "GraphView":
         """How the model should run on this graph: the graph itself, or a re-ordered copy + the row
         permutation to apply at the module boundary (decided once; see GraphView).  now=True: decide
@@ -833,6 +913,42 @@ class BlockedPlan:
         self.lds_fraction = self.lds_entries / max(self.nnz, 1)
 
 
+# Tile plan parameters: at most TILE_CAP staged sources per block (whole 32-source chunks), a source is staged when at
+# least TILE_MIN_COUNT of the block's entries reference it (a staged source costs one 512-byte row of X plus one
+# 512-byte tile column per block, a gathered entry 520 bytes each time), blocks of at most TILE_MAX_ROWS rows.
+TILE_CAP = 512
+TILE_MIN_COUNT = 2
+TILE_MAX_ROWS = 128
+
+
+def _tile_params():
+    import os
+    env = os.environ.get("SGF_SPMM_TILE", "")          # "cap,min_count,max_rows" (experiments)
+    if env:
+        c, m, r = (int(t) for t in env.split(","))
+        return c, m, r
+    return TILE_CAP, TILE_MIN_COUNT, TILE_MAX_ROWS
+
+
+class TilePlan:
+    """Plan of sgf_spmm_tile for one CSR: row blocks, the sources each block stages, the dense tiles as matrix-core
+    fragments (hi + lo bf16) and the CSR of the entries left on the gather path."""
+
+    def __init__(self, rowptr, colind, val, n: int, blk_row: torch.Tensor, cap=None, min_count=None):
+        c, m, _ = _tile_params()
+        self.blk_row, self.nb = blk_row, int(blk_row.numel()) - 1
+        self.cap, self.min_count = int(cap or c), int(min_count or m)
+        (self.sh_ptr, self.sh_cols, self.tile_ptr, self.tiles, self.rem_rowptr, self.rem_col, self.rem_val,
+         st) = K.tile_plan(rowptr, colind, val, n, blk_row, self.cap, self.min_count, LONG_ROW)
+        self.tile_entries, self.staged_rows, _, self.nnz, self.fragments, self.rem_entries = st[:6]
+        self.tile_fraction = self.tile_entries / max(self.nnz, 1)
+        # stored entries per tile cell: below ~2 % a tile column moves more bytes than the gathers it replaces
+        self.tile_density = self.tile_entries / max(self.fragments * 512, 1)
+        self.long_segments = long_row_segments(self.rem_rowptr, None)
+        self.bytes = (self.tiles.numel() * 4 + self.rem_col.numel() * 8 + self.rem_rowptr.numel() * 8
+                      + self.sh_cols.numel() * 4)
+
+
 # When to re-order (SGF_REORDER): "auto" (default) tries once per cached graph with at least
 # REORDER_MIN_NODES nodes, at its second forward (a graph seen once is a mini-batch: planning would cost
 # more than it saves) or when prepare_graph() asks for it; "1" tries every graph at first use; "0" never.
@@ -877,25 +993,28 @@ class GraphView:
                 return GraphView(g, None, None, {"reordered": False, "why": "small graph"})
             if not now and g.forward_calls < 2:
                 return None                    # undecided: wait for the second forward on this graph
-        perm, inv, _ = K.reorder(g.edge_index, g.n, *REORDER_ITERS)
-        g2 = CSRGraph(inv.long()[g.edge_index], g.n, validate=False)
-        # how much neighbour sharing the new order exposes: the share of stored entries a row-block plan could
-        # serve from LDS (bf16 rows, the full LDS budget) — the adoption criterion, whichever kernel then runs
-        g2.blocked = True
-        plan = g2.plan(_BF16)
-        stats = {"lds_fraction": plan.lds_fraction, "staged_rows_per_node": plan.staged_rows / max(g.n, 1),
-                 "rows_per_block": plan.rows_per_block, "lds_rows": plan.lds_rows}
-        if plan.lds_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
-            return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
-        # Which kernel multiplies with the re-ordered CSR: the flattened stream kernels (k_spmm_seg*) by default —
-        # on MI355X they beat the LDS-staged row blocks even at 76 % LDS-served entries (3.3 vs 4.1 ms at
-        # ogbn-products scale, profiles/r02_spmm_structured.md); SGF_SPMM_BLOCKED=1 selects the row-block kernel.
         import os
+        perm, inv, comm = K.reorder(g.edge_index, g.n, *REORDER_ITERS)
+        g2 = CSRGraph(inv.long()[g.edge_index], g.n, validate=False)
+        # how much neighbour sharing the new order exposes: the share of stored entries that fall into the dense
+        # tiles of community-aligned row blocks — the adoption criterion, whichever kernel then runs
+        _, _, max_rows = _tile_params()
+        g2.blk_row = K.tile_blocks(comm[perm.long()].contiguous(), g.n, max_rows, g.device)
+        tp = g2.tile_plan(False)
+        stats = {"lds_fraction": tp.tile_fraction, "tile_density": tp.tile_density, "blocks": tp.nb,
+                 "staged_rows_per_node": tp.staged_rows / max(g.n, 1), "plan_bytes": tp.bytes}
+        if tp.tile_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
+            return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
+        # Which kernel multiplies with the re-ordered CSR: dense matrix-core tiles + gather remainder (sgf_spmm_tile)
+        # for bf16 rows of 128 / 256 features; the flattened stream kernel (sgf_spmm_stream) otherwise and under
+        # SGF_SPMM_TILED=0; SGF_SPMM_BLOCKED=1 selects r02's LDS-staged row blocks (profiles/r02_spmm_structured.md).
         g2.locality = True        # its gathers mostly hit in L2: ops.spmm_on picks sgf_spmm_stream
         g2.blocked = os.environ.get("SGF_SPMM_BLOCKED", "0") == "1"
-        if not g2.blocked:
-            g2._plans.clear()
-        stats["kernel"] = "row-block (LDS-staged)" if g2.blocked else "stream"
+        g2.tiled = os.environ.get("SGF_SPMM_TILED", "1") == "1" and not g2.blocked
+        if not g2.tiled:
+            g2._tile_plans.clear()
+        stats["kernel"] = ("row-block (LDS-staged)" if g2.blocked else
+                           "tiles (matrix cores) + gather remainder" if g2.tiled else "stream")
         return GraphView(g2, perm, inv, {**stats, "reordered": True})
 
 
@@ -994,6 +1113,10 @@ def spmm_on(graph, x: torch.Tensor, transposed: bool, out=None) -> torch.Tensor:
     plan = graph.plan(x.dtype, transposed) if (getattr(graph, "blocked", False) and x.shape[1] <= 256) else None
     if plan is not None:
         return K.spmm_blocked(rp, plan, x, graph.n, out=out, long_segments=segs)
+    if (getattr(graph, "tiled", False) and K.tile_supported(x.shape[1], x.dtype)
+            and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32
+            and (out is None or (out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0))):
+        return K.spmm_tile(graph.tile_plan(transposed), x, graph.n, out=out)
     if getattr(graph, "locality", False):
         return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs, stream_hint=True)
     return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs)

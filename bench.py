@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                   the launch stream inside the timed region, against 8 TB/s; `gather_bytes` is the no-reuse
                   traffic of the same launch (each stored entry fetching a d-wide row), the bound for a
                   uniform random graph (profiles/r02_gather_probe.md).  `traffic` = HBM bytes per launch
-                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r02_spmm_pmc.json,
+                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r03_spmm_pmc.json,
                   written by scripts/pmc_passes.sh; null when no pass has been recorded).
   structured    — the same training step and the same SpMM roofline on a graph of the same size WITH
                   community structure and RANDOMLY PERMUTED node ids (synth.synthetic_graph_community): the
@@ -56,16 +56,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 # scripts/spmm_pmc_target.py; FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM).  PMC
 # counters cannot be collected from inside this process, so the figures live in a tracked file written
 # from those passes, keyed on graph kind / dtype / kernel.
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_spmm_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_spmm_pmc.json")
+SPMM_SOURCES = ("spmm.hip", "spmm_tile.hip", "spmm_plan.hip", "spmm_shared.h")
+
+
+def spmm_source_sha16() -> str:
+    """sha256 (first 16 hex digits) of the SpMM sources the PMC passes were taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SPMM_SOURCES:
+        with open(os.path.join(ROOT, "sgformer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
+    """(HBM bytes per launch, source) — or (None, why) when no pass exists or the passes are STALE: the file records
+    the hash of the kernel sources it was measured with, and a number measured on other code is not reported."""
     try:
         table = json.load(open(PMC_FILE))
     except (OSError, ValueError):
         return None, None
+    if table.get("_source_sha16") != spmm_source_sha16():
+        return None, "profiles/r03_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
     e = table.get(f"{graph_kind}/{dtype}/{kernel}/{'reordered' if reordered else 'given'}")
-    return (e["hbm_bytes_per_launch"], "profiles/r02_spmm_pmc.json") if e else (None, None)
+    return (e["hbm_bytes_per_launch"], "profiles/r03_spmm_pmc.json") if e else (None, None)
 
 
 def parse():
@@ -143,7 +158,7 @@ class SpmmTimer:
 
     def __init__(self):
         self.pairs, self.bytes_alg, self.bytes_gather, self.active, self.kernels = [], [], [], False, []
-        self._orig = (ops.K.spmm, ops.K.spmm_blocked)
+        self._orig = (ops.K.spmm, ops.K.spmm_blocked, ops.K.spmm_tile)
 
     def _wrap(self, orig, blocked):
         timer = self
@@ -172,12 +187,32 @@ class SpmmTimer:
 
         return timed
 
+    def _wrap_tile(self, orig):
+        timer = self
+
+        def timed(plan, x, n_rows, *rest, **kw):
+            if not timer.active:
+                return orig(plan, x, n_rows, *rest, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(plan, x, n_rows, *rest, **kw)
+            e1.record()
+            s, d, nnz = x.element_size(), x.shape[1], int(plan.nnz)
+            timer.kernels.append("k_spmm_tile_bf16")
+            timer.pairs.append((e0, e1))
+            timer.bytes_alg.append(nnz * 8 + (n_rows + 1) * 8 + x.shape[0] * d * s + n_rows * d * s)
+            timer.bytes_gather.append(nnz * (8 + d * s) + (n_rows + 1) * 8 + n_rows * d * s)
+            return y
+
+        return timed
+
     def install(self):
         ops.K.spmm = self._wrap(self._orig[0], False)
         ops.K.spmm_blocked = self._wrap(self._orig[1], True)
+        ops.K.spmm_tile = self._wrap_tile(self._orig[2])
 
     def uninstall(self):
-        ops.K.spmm, ops.K.spmm_blocked = self._orig
+        ops.K.spmm, ops.K.spmm_blocked, ops.K.spmm_tile = self._orig
 
     def reset(self):
         self.pairs, self.bytes_alg, self.bytes_gather, self.kernels = [], [], [], []
@@ -191,7 +226,8 @@ class SpmmTimer:
         gat = sum(self.bytes_gather) / len(self.bytes_gather)
         achieved = alg / (mean_ms * 1e-3) / 1e9
         kern = max(set(self.kernels), key=self.kernels.count)
-        entry = {"k_spmm_blk": "sgf_spmm_blocked", "k_spmm_seg_bf16x2": "sgf_spmm_stream"}.get(kern, "sgf_spmm")
+        entry = {"k_spmm_blk": "sgf_spmm_blocked", "k_spmm_seg_bf16x2": "sgf_spmm_stream",
+                 "k_spmm_tile_bf16": "sgf_spmm_tile"}.get(kern, "sgf_spmm")
         return {"kernel": f"{kern} ({entry})", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "launches": len(ms), "mean_launch_ms": round(mean_ms, 4),

@@ -208,7 +208,7 @@ int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* e
  * T2 on a re-ordered graph, the matrix-core form (csrc/spmm_tile.hip).   Same product as sgf_spmm
  * (large/ours.py:34, torch_sparse.matmul, sum-reduce); bf16 storage, d = 128 or 256.
  * After sgf_reorder a community is a run of consecutive rows whose entries mostly point back into
- * the run: the diagonal blocks of A are 15-60 % dense.  Per block of <= 128 rows the sources that at
+ * the run: the diagonal blocks of A are 15-60 % dense.  Per block of <= 256 rows the sources that at
  * least `min_count` of the block's entries reference are STAGED (their rows of X pass once per block
  * through LDS) and the block's entries towards them are multiplied as a dense tile on the matrix
  * cores (value = hi + lo bf16, relative error <= 2^-17; products of bf16 values are exact in fp32,
@@ -219,7 +219,7 @@ int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* e
  * sgf_spmm_tile_blocks — block boundaries from the level-1 communities of sgf_reorder:
  *   comm_sorted[p] = community of the row at NEW position p (device; NULL = fixed blocks of max_rows).
  *   Runs of one community are packed greedily: consecutive runs share a block while they fit
- *   max_rows (32, 64, 96 or 128); a longer run is cut into ceil(len / max_rows) pieces of
+ *   max_rows (a multiple of 32, <= 256); a longer run is cut into ceil(len / max_rows) pieces of
  *   min(max_rows, round_up(ceil(len / pieces), 32)) rows.  blk_row (device, int32[blk_cap + 1]) gets
  *   nb + 1 boundaries, *nb_out (host) the count (SGF_E_WORKSPACE with *nb_out set when blk_cap is too
  *   small; 4 n / max_rows + 4 always suffices).  Synchronises the stream (one device -> host copy of n ints).
@@ -233,13 +233,14 @@ int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* e
  *   padding repeats the row's last source with value 0: the kernel fetches two rows of X per instruction
  *   and no pair straddles two target rows).  Rows longer than long_len stay entirely on it.
  *   stats (int64[8], device): tile entries, staged rows incl. padding, distinct (block, source) pairs,
- *   nnz, fragments, gathered entries incl. padding, 0, 1 if a block has 0 or more than 128 rows (plan unusable).
+ *   nnz, fragments, gathered entries incl. padding, 0, 1 if a block has 0 or more than 256 rows (plan unusable).
  * sgf_spmm_tile_fill — the arrays whose size the plan determines: tiles (n_frag * 2048 bytes; fragment
  *   of chunk q = slot / 32, row tile t, k-step s = (slot / 16) % 2 at tile_ptr[b] + (q * T + t) * 2 + s;
  *   inside: [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16], lane = (row % 32) + 32 * ((slot % 16) / 8),
  *   element slot % 8 — the A operand of v_mfma_f32_32x32x16_bf16; duplicate edges are summed in fp32 in
  *   stored order), rem_col / rem_val (stats[5] entries, stored order + padding).
- * sgf_spmm_tile — Y = A X with that plan.  x: [n_cols, d] bf16, n_cols * ldx * 2 < 2^32; ldx, ldy
+ * sgf_spmm_tile — Y = A X with that plan; block_rows = the max_rows the blocks were made with (<= 128: four
+ *   waves per block and two blocks per CU, else eight waves and one).  x: [n_cols, d] bf16, n_cols * ldx * 2 < 2^32; ldx, ldy
  *   multiples of 8, x / y 16-byte aligned.  long_len / long_segments / workspace as for sgf_spmm_split,
  *   counted on the REMAINDER row lengths (0 segments = no row is split).
  * ------------------------------------------------------------------------------------------ */
@@ -256,7 +257,7 @@ int sgf_spmm_tile_fill(const int64_t* rowptr, const int32_t* ecode, const float*
                        int64_t n, int64_t nnz, const int32_t* blk_row, int64_t nb, const int64_t* tile_ptr,
                        int64_t n_frag, const int64_t* rem_rowptr, void* tiles, int32_t* rem_col, float* rem_val,
                        void* stream);
-int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, const int32_t* sh_ptr, const int32_t* sh_cols,
+int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const int32_t* sh_ptr, const int32_t* sh_cols,
                   const int64_t* tile_ptr, const void* tiles, const int64_t* rem_rowptr, const int32_t* rem_col,
                   const float* rem_val, const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy,
                   int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,

@@ -3,7 +3,7 @@
 
 Dispatches of one SpMM kernel are grouped by launch order (the target launches each variant `reps` times in a
 row), counters are averaged per group, durations come from the kernel-trace pass.  Prints a markdown table and,
-with --json, the entries of profiles/r02_spmm_pmc.json: HBM bytes per launch = 2 x FETCH_SIZE (KiB; the gfx950
+with --json, the entries of profiles/r03_spmm_pmc.json: HBM bytes per launch = 2 x FETCH_SIZE (KiB; the gfx950
 correction of MI355X_MICROARCH.md §HBM: wide coalesced reads are tallied at half their bytes) + WRITE_SIZE (KiB)."""
 import glob
 import json
@@ -84,6 +84,9 @@ def main(out, as_json=None, key_prefix=""):
                     "fetch_size_kib": float(res.loc["FETCH_SIZE", n]), "write_size_kib": float(res.loc["WRITE_SIZE", n]),
                     "l2_hit_rate": float(res.loc["L2_hit_rate", n]) if "L2_hit_rate" in res.index else None,
                     "launch_ms": float(tg.get(n, float("nan")))}
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench                                      # the hash bench.py checks the passes against
+        table["_source_sha16"] = bench.spmm_source_sha16()
         json.dump(table, open(as_json, "w"), indent=1, sort_keys=True)
 
 

@@ -52,7 +52,7 @@ SIGNATURES = {
     "sgf_spmm_tile_plan": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_spmm_tile_fill": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
-    "sgf_spmm_tile": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
+    "sgf_spmm_tile": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                 c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
     "sgf_gather_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                   c_int32, _P]),

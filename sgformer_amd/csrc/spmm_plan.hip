@@ -264,7 +264,7 @@ __global__ void k_row_block(const int32_t* __restrict__ blk_row, int64_t nb, int
 }
 
 // staged rows per block rounded up to whole 32-source chunks; fragments per block = row tiles x k-steps;
-// *bad = 1 if a block has no rows or more than kTileMaxRows
+// *bad = 1 if a block has no rows or more than 256
 __global__ void k_pad_counts(const int32_t* __restrict__ nsh, const int32_t* __restrict__ blk_row, int64_t nb,
                              int32_t pad, int32_t* __restrict__ nshp, int64_t* __restrict__ frags,
                              int32_t* __restrict__ bad) {
@@ -273,7 +273,7 @@ __global__ void k_pad_counts(const int32_t* __restrict__ nsh, const int32_t* __r
   for (; b <= nb; b += stride) {
     if (b == nb) { nshp[b] = 0; frags[b] = 0; continue; }
     const int32_t rows = blk_row[b + 1] - blk_row[b];
-    if (rows <= 0 || rows > 128) *bad = 1;
+    if (rows <= 0 || rows > 256) *bad = 1;
     const int32_t s = (nsh[b] + pad - 1) / pad * pad;
     nshp[b] = s;
     frags[b] = static_cast<int64_t>((rows + 31) / 32) * (s / 16);
@@ -558,8 +558,8 @@ extern "C" int sgf_spmm_plan(const int64_t* rowptr, const int32_t* colind, const
 extern "C" int sgf_spmm_tile_blocks(const int32_t* comm_sorted, int64_t n, int32_t max_rows, int32_t* blk_row,
                                     int64_t blk_cap, int64_t* nb_out, void* stream) {
   const char* fn = "sgf_spmm_tile_blocks";
-  SGF_REQUIRE(n >= 0 && max_rows >= 32 && max_rows <= 128 && max_rows % 32 == 0 && blk_cap >= 0 && nb_out && blk_row,
-              SGF_E_INVALID, "%s: bad argument (max_rows must be 32, 64, 96 or 128)", fn);
+  SGF_REQUIRE(n >= 0 && max_rows >= 32 && max_rows <= 256 && max_rows % 32 == 0 && blk_cap >= 0 && nb_out && blk_row,
+              SGF_E_INVALID, "%s: bad argument (max_rows must be a multiple of 32 in [32, 256])", fn);
   SGF_REQUIRE(n < (static_cast<int64_t>(1) << 31) - 1, SGF_E_UNSUPPORTED, "%s: n too large", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
   std::vector<int32_t> out;

@@ -116,6 +116,12 @@ class ShardedGraph:
         n_g, dev = ctx.n_global, edge_index.device
         self.device = dev
         src, dst = edge_index[0], edge_index[1]
+        # every rank holds the same list, so every rank raises (or none does) — an id outside [0, n) would otherwise
+        # reach dinv[...] / colind as an out-of-bounds gather (the blocks below are built without validation)
+        if edge_index.numel() > 0:
+            lo, hi = torch.aminmax(edge_index)
+            if int(lo) < 0 or int(hi) >= n_g:
+                raise IndexError(f"edge_index has node ids outside [0, {n_g})")
         deg = torch.bincount(dst, minlength=n_g).to(torch.int32)
         fwd, bwd = src * n_g + dst, dst * n_g + src
         self.symmetric = bool(_mix64(fwd, 0).sum() == _mix64(bwd, 0).sum()) and \

@@ -71,15 +71,33 @@ def patch_subgraph():
     return tgu
 
 
-def patch_prologue():
+def patch_prologue(keep_input_device: bool = False):
     """Serve the trainer prologue — to_undirected / remove_self_loops / add_self_loops at
     large/main.py:75-79 and 100M/nb-sample.py:79-80 — from the GPU (sgformer_amd.batching,
-    sgf_graph_prologue_*).  The edge_index the trainer then moves `.to(device)` is
-    already there."""
+    sgf_graph_prologue_*).  For large/main*.py the edge_index the trainer then moves
+    `.to(device)` is already there.  keep_input_device=True (the 100M trainer): the result goes back to the
+    device of the tensor that came in — 100M/nb-sample.py:81-133 puts edge_index into a HOST `Data` object and
+    hands it to NeighborLoader workers, which must not receive a CUDA tensor (nor should 52 GB of
+    papers100M edges stay in HBM for the whole run)."""
     import importlib as _il
     tgu = _il.import_module("torch_geometric.utils")
     b = _il.import_module("sgformer_amd.batching")
-    tgu.to_undirected, tgu.remove_self_loops, tgu.add_self_loops = b.to_undirected, b.remove_self_loops, b.add_self_loops
+    if not keep_input_device:
+        tgu.to_undirected, tgu.remove_self_loops, tgu.add_self_loops = b.to_undirected, b.remove_self_loops, b.add_self_loops
+        return tgu
+
+    def _back(fn):
+        def wrapped(edge_index, *args, **kwargs):
+            out = fn(edge_index, *args, **kwargs)
+            dev = edge_index.device
+            if isinstance(out, tuple):
+                return tuple(o.to(dev) if hasattr(o, "to") else o for o in out)
+            return out.to(dev)
+        wrapped.__name__ = fn.__name__
+        return wrapped
+
+    tgu.to_undirected, tgu.remove_self_loops, tgu.add_self_loops = (_back(b.to_undirected), _back(b.remove_self_loops),
+                                                                    _back(b.add_self_loops))
     return tgu
 
 
@@ -144,6 +162,18 @@ def limit_host_threads():
         torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
+def _select_device(argv):
+    """The trainers take `--device N` (large/parse.py, default 0) and build torch.device('cuda:N'); the launcher's
+    patches place data on the CURRENT device, so make N current before the trainer runs."""
+    import torch
+    for i, a in enumerate(argv):
+        v = argv[i + 1] if a == "--device" and i + 1 < len(argv) else (a.split("=", 1)[1] if a.startswith("--device=") else None)
+        if v is not None and v.isdigit() and torch.cuda.is_available() and int(v) < torch.cuda.device_count():
+            torch.cuda.set_device(int(v))
+            return int(v)
+    return None
+
+
 def _pop_option(argv, name):
     for i, a in enumerate(argv):
         if a == name and i + 1 < len(argv):
@@ -183,10 +213,13 @@ def main(argv=None):
     sys.path.insert(0, tdir)
     if variant == "medium":
         patch_medium_gcn()
+    _select_device(argv)
     if host_subgraph is None and os.path.basename(trainer) == "main-batch.py":
         patch_subgraph()
-    if host_prologue is None and variant != "medium":
-        patch_prologue()
+    # --sgf-host-subgraph implies the host prologue: PyG's host subgraph() indexes a CPU mask with edge_index[0],
+    # which must then be a host tensor too
+    if host_prologue is None and host_subgraph is None and variant != "medium":
+        patch_prologue(keep_input_device=(variant == "100M"))
     if aten_loss is None:
         patch_nll_loss()
     if os.path.basename(trainer) == "main-batch.py":

@@ -275,7 +275,7 @@ class HipKernels:
             st = [int(v) for v in stats.tolist()]                      # one host sync, once per plan
             del ws
             if st[7]:
-                raise ValueError("tile_plan: a row block is empty or longer than 128 rows")
+                raise ValueError("tile_plan: a row block is empty or longer than 256 rows")
             n_frag, n_rem = st[4], st[5]
             tiles = torch.empty(max(n_frag, 1) * 512, dtype=torch.int32, device=dev)     # 2 KiB per fragment
             rem_col = torch.empty(max(n_rem, 1), dtype=torch.int32, device=dev)
@@ -296,7 +296,7 @@ class HipKernels:
             ws = None
             if segs > 0:
                 ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(segs, d))
-            _lib.call("sgf_spmm_tile", _ptr(plan.blk_row), plan.nb, _ptr(plan.sh_ptr), _ptr(plan.sh_cols),
+            _lib.call("sgf_spmm_tile", _ptr(plan.blk_row), plan.nb, plan.block_rows, _ptr(plan.sh_ptr), _ptr(plan.sh_cols),
                       _ptr(plan.tile_ptr), _ptr(plan.tiles), _ptr(plan.rem_rowptr), _ptr(plan.rem_col),
                       _ptr(plan.rem_val), _ptr(x), x.stride(0), x.shape[0], _ptr(y), y.stride(0), n_rows, d, _code(x),
                       LONG_ROW, segs, _ptr(ws), 0 if ws is None else ws.numel(), _stream(x.device))
@@ -915,9 +915,10 @@ class BlockedPlan:
 
 # Tile plan parameters: at most TILE_CAP staged sources per block (whole 32-source chunks), a source is staged when at
 # least TILE_MIN_COUNT of the block's entries reference it (a staged source costs one 512-byte row of X plus one
-# 512-byte tile column per block, a gathered entry 520 bytes each time), blocks of at most TILE_MAX_ROWS rows.
+# 512-byte tile column per block, a gathered entry 520 bytes each time; measured at ogbn-products scale: 2 -> 2.55 ms,
+# 3 -> 2.43 ms), blocks of at most TILE_MAX_ROWS rows (256-row blocks of 8 waves, one per CU: 2.75 ms; 64: 4.4 ms).
 TILE_CAP = 512
-TILE_MIN_COUNT = 2
+TILE_MIN_COUNT = 3
 TILE_MAX_ROWS = 128
 
 
@@ -937,6 +938,7 @@ class TilePlan:
     def __init__(self, rowptr, colind, val, n: int, blk_row: torch.Tensor, cap=None, min_count=None):
         c, m, _ = _tile_params()
         self.blk_row, self.nb = blk_row, int(blk_row.numel()) - 1
+        self.block_rows = int((blk_row[1:] - blk_row[:-1]).max()) if self.nb > 0 else 1
         self.cap, self.min_count = int(cap or c), int(min_count or m)
         (self.sh_ptr, self.sh_cols, self.tile_ptr, self.tiles, self.rem_rowptr, self.rem_col, self.rem_val,
          st) = K.tile_plan(rowptr, colind, val, n, blk_row, self.cap, self.min_count, LONG_ROW)
@@ -1604,7 +1606,7 @@ class _CombineFC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, w, bias, a: float, b: float):
         K.check(x1, x2)
-        x1, x2 = _rows(x1), _rows(x2)
+        x1, x2 = _rows16(x1), _rows16(x2)        # sgf_combine_fc_* read 16-byte matrix-core fragments
         w32 = w.detach().float().contiguous()
         b32 = bias.detach().float().contiguous()
         ctx.save_for_backward(x1, x2, w32)

@@ -139,6 +139,56 @@ def synthetic_graph_community(n: int, avg_deg: float, seed: int = 123, comm_size
     return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
 
 
+def synthetic_graph_community_powerlaw(n: int, avg_deg: float, seed: int = 123, size_range=(16, 4096), alpha: float = 1.5,
+                                       comms_per_super: int = 32, p_comm: float = 0.75, p_super: float = 0.15,
+                                       p_hub: float = 0.03, hub_gamma: float = 3.0, shuffle_ids: bool = True,
+                                       device="cpu") -> torch.Tensor:
+    """`synthetic_graph_community` with the skew of a real co-purchase / social graph (SURVEY.md §8d input class (b)):
+
+      * community sizes follow a truncated power law (density ~ size^-(alpha+1) on `size_range`): many small
+        communities, a few of thousands of nodes (longer than any row block);
+      * inside a community the far endpoint is drawn with a heavy tail (index = size * u^2): local hubs;
+      * a fraction `p_hub` of the pairs ends at a GLOBAL hub (id = n * u^hub_gamma): a handful of rows collect
+        tens of thousands of entries — the long-row path (ogbn-products' largest row has ~17 k entries);
+      * ids renamed by a random permutation, as in `synthetic_graph_community`."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lo, hi = size_range
+    u = torch.rand(int(n / lo) + 8, generator=g, dtype=torch.float64)
+    # inverse CDF of the truncated Pareto on [lo, hi]
+    sizes = (lo * (1.0 - u * (1.0 - (lo / hi) ** alpha)) ** (-1.0 / alpha)).long().clamp_(lo, hi)
+    bounds = torch.cumsum(sizes, 0)
+    nc = int((bounds < n).sum()) + 1
+    starts = torch.cat([torch.zeros(1, dtype=torch.long), bounds[: nc - 1]])
+    ends = torch.cat([bounds[: nc - 1], torch.tensor([n])])
+    comm = torch.repeat_interleave(torch.arange(nc), ends - starts)
+    sup_of_comm = torch.arange(nc) // comms_per_super
+    sup_start = starts[torch.arange(0, nc, comms_per_super)]
+    sup_end = torch.cat([sup_start[1:], torch.tensor([n])])
+    m = int(n * avg_deg / 2)
+    src = torch.randint(0, n, (m,), generator=g)
+    sel = torch.rand(m, generator=g)
+    r = torch.rand(m, generator=g, dtype=torch.float64)
+    c = comm[src]
+    sc = sup_of_comm[c]
+    d1 = starts[c] + (r * r * (ends[c] - starts[c])).long()
+    d2 = sup_start[sc] + (r * (sup_end[sc] - sup_start[sc])).long()
+    d3 = (r * n).long().clamp_(max=n - 1)
+    d4 = (r ** hub_gamma * n).long().clamp_(max=n - 1)
+    dst = torch.where(sel < p_comm, d1, torch.where(sel < p_comm + p_super, d2,
+                                                   torch.where(sel < 1.0 - p_hub, d3, d4)))
+    del sel, r, c, sc, d1, d2, d3, d4
+    if shuffle_ids:
+        perm = torch.randperm(n, generator=g)
+        src, dst = perm[src], perm[dst]
+    src, dst = src.to(device), dst.to(device)
+    src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
 def synthetic_graph_skewed(n: int, avg_deg: float, gamma: float = 2.0, seed: int = 123, device="cpu") -> torch.Tensor:
     """Same prologue as `synthetic_graph`, but one endpoint of every pair is drawn from a heavy-tailed
     distribution (id = floor(n * u^gamma)): a few hub nodes collect a large share of the edges — node 0

@@ -39,6 +39,7 @@ split = {"train": perm[: n // 2], "valid": perm[n // 2: 3 * n // 4], "test": per
 edge_index = to_undirected(raw)
 edge_index, _ = remove_self_loops(edge_index)
 edge_index, _ = add_self_loops(edge_index, num_nodes=n)
+print("STANDIN_PROLOGUE_DEVICE", edge_index.device.type)   # where the (possibly patched) prologue left its result
 edge_index, x = edge_index.to(device), x.to(device)
 
 model = SGFormer(f, args.hidden_channels, c, trans_num_layers=1, trans_num_heads=1, trans_dropout=0.0,   # noqa: F405

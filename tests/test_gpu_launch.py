@@ -29,7 +29,7 @@ def test_launcher_drives_a_trainer_on_the_hip_path(cuda, tmp_path):
     p = subprocess.run([sys.executable, "-m", "sgformer_amd.launch", TRAINER, "--epochs", "4", "--dump", dump],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "STANDIN_EDGE_DEVICE cuda" in p.stdout                  # the prologue ran on the device (launch.patch_prologue)
+    assert "STANDIN_PROLOGUE_DEVICE cuda" in p.stdout              # the prologue ran on the device (launch.patch_prologue)
     log = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("STANDIN_LOG ")][0][12:])
     assert len(log) == 4
 
@@ -86,3 +86,25 @@ def test_launcher_bf16_and_loss_switches(cuda, tmp_path):
         assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(a["loss"])), (a, b)
     for a, b in zip(f32, bf16):
         assert abs(a["loss"] - b["loss"]) <= 3e-2 * max(1.0, abs(a["loss"])), (a, b)
+
+
+def test_launcher_host_fallbacks_and_100m_prologue(cuda, tmp_path):
+    """`--sgf-host-subgraph 1` must leave the prologue on the host too (PyG's host subgraph() indexes a CPU
+    mask with edge_index), and for the 100M trainer the device prologue hands its result back on the INPUT tensor's
+    device (100M/nb-sample.py:81-133 builds a host Data object for NeighborLoader workers).  Same loss curve either way."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(HERE, "standins"), ROOT]))
+
+    def run(*extra):
+        p = subprocess.run([sys.executable, "-m", "sgformer_amd.launch", *extra, TRAINER, "--epochs", "2"], cwd=ROOT,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        dev = [ln for ln in p.stdout.splitlines() if ln.startswith("STANDIN_PROLOGUE_DEVICE ")][0].split()[1]
+        return dev, json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("STANDIN_LOG ")][0][12:])
+
+    d0, base = run()
+    d1, host = run("--sgf-host-subgraph", "1")
+    d2, m100 = run("--sgf-variant", "100M")
+    assert (d0, d1, d2) == ("cuda", "cpu", "cpu")
+    for a, b in zip(base, host):
+        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(a["loss"])), (a, b)
+    assert all(torch.isfinite(torch.tensor(e["loss"])) for e in m100)

@@ -37,7 +37,7 @@ def _reordered(name, cuda):
     return ops.CSRGraph(ei2.to(cuda), n), n, comm[perm], ei2
 
 
-@pytest.mark.parametrize("name,max_rows", [("community", 128), ("community", 64), ("hub_dups_isolated", 128),
+@pytest.mark.parametrize("name,max_rows", [("community", 128), ("community", 64), ("community", 256), ("hub_dups_isolated", 128),
                                            ("uniform", 96), ("directed", 32)])
 def test_tile_blocks_match_oracle(cuda, name, max_rows):
     from sgformer_amd import ops
@@ -52,6 +52,7 @@ def test_tile_blocks_match_oracle(cuda, name, max_rows):
 
 
 @pytest.mark.parametrize("name,max_rows,cap,min_count", [("community", 128, 512, 2), ("community", 64, 64, 3),
+                                                         ("community", 256, 512, 3), ("hub_dups_isolated", 256, 256, 2),
                                                          ("hub_dups_isolated", 128, 256, 2), ("uniform", 128, 128, 2),
                                                          ("directed", 32, 32, 1)])
 def test_tile_plan_matches_oracle(cuda, name, max_rows, cap, min_count):
@@ -94,6 +95,8 @@ def _oracle_product(ei2, n, xs):
 @pytest.mark.parametrize("d", [256, 128])
 @pytest.mark.parametrize("name,max_rows,cap,min_count", [("community", 128, 512, 2), ("community", 64, 64, 3),
                                                          ("community", 96, 32, 2), ("hub_dups_isolated", 128, 256, 2),
+                                                         ("community", 256, 512, 3), ("hub_dups_isolated", 256, 128, 2),
+                                                         ("uniform", 224, 64, 2),
                                                          ("uniform", 128, 128, 2), ("directed", 32, 32, 1),
                                                          ("directed", 128, 1024, 1)])
 def test_spmm_tile_vs_oracle(cuda, name, max_rows, cap, min_count, d):

@@ -263,6 +263,34 @@ int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const 
                   int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * N2 — layer-wise neighbour sampling on the device.   Replaces NeighborLoader(data,
+ * num_neighbors=[15, 10, 5], ...) of 100M/nb-sample.py:125-151 (third-party pyg-lib / torch_sparse
+ * neighbor_sample, replace=False, directed=True).  Hop h gives every node that ENTERED the batch in
+ * hop h-1 (the seeds for h = 0) min(in-degree, fanout) of its in-neighbours, drawn without
+ * replacement (fanout < 0: all of them; fanout <= 32 otherwise); a neighbour not yet in the batch gets
+ * the next local id in order of first appearance (so the seeds are rows [0, batch_size): the trainer
+ * slices [:batch_size], 100M/nb-sample.py:29-30); sampled edges point neighbour -> node, in local ids.
+ * The reference's random stream cannot be matched; the draw is a counter-based hash of
+ * (seed, batch, hop, node id): reproducible and independent of the launch geometry.
+ *   rowptr / colind : CSR over TARGET nodes (sgf_csr_build): colind[rowptr[v] .. rowptr[v+1]) = the
+ *                     in-neighbours of v
+ *   local_of        : int32[n_nodes] state, -1 = node not in the batch; sgf_neighbor_sample_mark
+ *                     sets local_of[ids[j]] = base + j (seeds: base 0) or -1 (base < 0: reset after the batch)
+ *   frontier        : the m nodes that entered in the previous hop, global ids, local ids
+ *                     frontier_local0 .. frontier_local0 + m - 1;  n_known = nodes in the batch so far
+ *   out             : edge_src_local / edge_dst_local / src_global [edge_cap >= m * fanout], new_nodes
+ *                     (global ids of the nodes that entered, in local-id order), counts (device int64[2]:
+ *                     edges, new nodes).  Synchronises the stream once (the edge count sizes the launches).
+ * ------------------------------------------------------------------------------------------ */
+size_t sgf_neighbor_sample_workspace_bytes(int64_t m, int64_t edge_cap);
+int sgf_neighbor_sample_mark(int32_t* local_of, const int32_t* ids, int64_t count, int32_t base, void* stream);
+int sgf_neighbor_sample_hop(const int64_t* rowptr, const int32_t* colind, const int32_t* frontier, int64_t m,
+                            int32_t frontier_local0, int32_t fanout, uint64_t seed, uint64_t batch, int32_t hop,
+                            int32_t* local_of, int32_t n_known, int64_t edge_cap, int32_t* edge_src_local,
+                            int32_t* edge_dst_local, int32_t* src_global, int32_t* new_nodes, int64_t* counts,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* dst[i, :] = src[idx[i], :] with an optional fp32 <-> bf16 storage change.  Replaces the row
  * gathers at the module boundary: x[idx_i] of a mini-batch (large/main-batch.py:138) and the
  * x[perm] / logits[inv] pair around a re-ordered graph.  idx: int32 or int64 (idx_is_int64) device

@@ -275,8 +275,9 @@ int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const 
  * (seed, batch, hop, node id): reproducible and independent of the launch geometry.
  *   rowptr / colind : CSR over TARGET nodes (sgf_csr_build): colind[rowptr[v] .. rowptr[v+1]) = the
  *                     in-neighbours of v
- *   local_of        : int32[n_nodes] state, -1 = node not in the batch; sgf_neighbor_sample_mark
- *                     sets local_of[ids[j]] = base + j (seeds: base 0) or -1 (base < 0: reset after the batch)
+ *   local_of        : int32[n_nodes] state, INT32_MIN = node not in the batch (fill it once);
+ *                     sgf_neighbor_sample_mark sets local_of[ids[j]] = base + j (seeds: base 0) or INT32_MIN
+ *                     (base < 0: reset after the batch)
  *   frontier        : the m nodes that entered in the previous hop, global ids, local ids
  *                     frontier_local0 .. frontier_local0 + m - 1;  n_known = nodes in the batch so far
  *   out             : edge_src_local / edge_dst_local / src_global [edge_cap >= m * fanout], new_nodes

@@ -10,6 +10,8 @@ equals the plain one (the product the reference computes) on the same inputs.
   reorder(ei, n, iters1, iters2)             == sgf_reorder        (csrc/reorder.hip)
   spmm_plan(rowptr, colind, val, n, R, ...)  == sgf_spmm_plan      (csrc/spmm_plan.hip)
   tile_blocks / tile_plan                    == sgf_spmm_tile_blocks / _plan / _fill (csrc/spmm_plan.hip)
+  neighbor_sample(rowptr, colind, seeds, ...) == sgf_neighbor_sample_* (csrc/sampler.hip; NeighborLoader semantics of
+                                                100M/nb-sample.py:125-151, this library's own random stream)
   graph_prologue(ei, n)                      == sgf_graph_prologue (csrc/prologue.hip; the trainer prologue
                                                 large/main.py:75-79)
 """
@@ -268,6 +270,58 @@ def spmm_blocked(rowptr, ecode, eval_, nlds, sh_ptr, sh_cols, x, rows_per_block)
                 c = int(sh_cols[sh_ptr[b] + (c & 0x7FFFFFFF)])
             y[r] += float(eval_[e]) * x[c]
     return y
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """splitmix64 finaliser on Python ints (csrc/sampler.hip mix64)."""
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def neighbor_sample(rowptr, colind, seeds, fanouts, seed, batch):
+    """n_id, edge_src_local, edge_dst_local — sgf_neighbor_sample_* (csrc/sampler.hip), the draw included: hop h gives
+    every node that entered in hop h - 1 min(in-degree, fanout) in-neighbours by Floyd's subset sampling with the
+    counter-based hash of (seed, batch, hop, node); new nodes get local ids in order of first appearance."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colind = np.asarray(colind, dtype=np.int64)
+    n_id = [int(v) for v in seeds]
+    local_of = {g: i for i, g in enumerate(n_id)}
+    frontier, local0 = list(n_id), 0
+    e_src, e_dst = [], []
+    for hop, k in enumerate(fanouts):
+        key = _mix64((seed & _M64) ^ _mix64((batch * 0x9E3779B97F4A7C15 + hop) & _M64))
+        s_glob, dst = [], []
+        for i, f in enumerate(frontier):
+            base, deg = int(rowptr[f]), int(rowptr[f + 1] - rowptr[f])
+            if k < 0 or deg <= k:
+                picks = list(range(deg))
+            else:
+                nk = _mix64(key ^ ((f * 0xD6E8FEB86659FD93) & _M64))
+                picks = []
+                for j, t in enumerate(range(deg - k, deg)):
+                    r = _mix64((nk + j) & _M64) % (t + 1)
+                    if r in picks:
+                        r = t
+                    picks.append(r)
+            s_glob += [int(colind[base + r]) for r in picks]
+            dst += [local0 + i] * len(picks)
+        new = []
+        for g in s_glob:
+            if g not in local_of:
+                local_of[g] = len(n_id) + len(new)
+                new.append(g)
+        e_src += [local_of[g] for g in s_glob]
+        e_dst += dst
+        frontier, local0 = new, len(n_id)
+        n_id += new
+        if not frontier:
+            break
+    return (np.asarray(n_id, dtype=np.int64), np.asarray(e_src, dtype=np.int64), np.asarray(e_dst, dtype=np.int64))
 
 
 def graph_prologue(edge_index, n, undirected=True):

@@ -12,14 +12,17 @@
 // oracle/graph_oracle.py::neighbor_sample.
 //
 // Graph: the CSR over TARGET nodes sgf_csr_build makes (rowptr int64, colind int32 = the in-neighbours of a node).
-// State: local_of int32[n_nodes], -1 = not in the batch (444 MB at papers100M scale; reset per batch by the ids the
-// batch touched, not by a full fill).
+// State: local_of int32[n_nodes], INT32_MIN = not in the batch (444 MB at papers100M scale; reset per batch by the ids
+// the batch touched, not by a full fill).  The order  not-in-batch < claim of a later position < claim of an earlier
+// position < local id  is what lets ONE atomicMax per sampled entry elect the first appearance of every new node.
 // One hop = counts -> scan -> draw (one thread per frontier node, Floyd's subset sampling, fanout <= 32) -> claim
 // (atomicMax of -(position + 2): the FIRST position of every new id wins, whatever order threads run in) -> flag ->
 // scan -> assign -> edges.  Deterministic.
 #include "common.h"
 
 #include <rocprim/rocprim.hpp>
+
+#include <climits>
 
 namespace sgf {
 namespace {
@@ -130,7 +133,7 @@ __global__ void k_edges(const int32_t* __restrict__ src_global, int64_t total, c
 __global__ void k_mark(int32_t* __restrict__ local_of, const int32_t* __restrict__ ids, int64_t count, int32_t base) {
   int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (; j < count; j += stride) local_of[ids[j]] = base < 0 ? -1 : base + static_cast<int32_t>(j);
+  for (; j < count; j += stride) local_of[ids[j]] = base < 0 ? INT32_MIN : base + static_cast<int32_t>(j);
 }
 
 struct Layout {

@@ -101,6 +101,26 @@ def patch_prologue(keep_input_device: bool = False):
     return tgu
 
 
+def patch_neighbor_loader():
+    """100M/nb-sample.py:11 `from torch_geometric.loader import NeighborLoader` -> sgformer_amd.sampling.NeighborLoader:
+    the graph, features and labels stay in HBM and every batch is sampled / relabelled / gathered on the device
+    (`--sgf-host-sampler 1` keeps PyG's host workers).  Creates the `torch_geometric.loader` module
+    when the installed torch_geometric predates it."""
+    import importlib as _il
+    import types
+    samp = _il.import_module("sgformer_amd.sampling")
+    try:
+        loader = _il.import_module("torch_geometric.loader")
+    except ImportError:
+        loader = types.ModuleType("torch_geometric.loader")
+        sys.modules["torch_geometric.loader"] = loader
+        tg = sys.modules.get("torch_geometric")
+        if tg is not None:
+            tg.loader = loader
+    loader.NeighborLoader = samp.NeighborLoader
+    return loader
+
+
 def patch_resident_features():
     """Keep the node features of the mini-batch trainer on the GPU: wrap the trainer's own
     `dataset.load_dataset` so that `dataset.graph['node_feat']` is a device tensor.  The per-batch
@@ -194,6 +214,7 @@ def main(argv=None):
     host_prologue = _pop_option(argv, "--sgf-host-prologue")   # any value: keep PyG's host to_undirected & co.
     host_features = _pop_option(argv, "--sgf-host-features")   # any value: keep node features on the host
     aten_loss = _pop_option(argv, "--sgf-aten-loss")           # any value: keep ATen's nll_loss kernels
+    host_sampler = _pop_option(argv, "--sgf-host-sampler")     # any value: keep PyG's host NeighborLoader (100M)
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -220,6 +241,8 @@ def main(argv=None):
     # which must then be a host tensor too
     if host_prologue is None and host_subgraph is None and variant != "medium":
         patch_prologue(keep_input_device=(variant == "100M"))
+    if variant == "100M" and host_sampler is None:
+        patch_neighbor_loader()
     if aten_loss is None:
         patch_nll_loss()
     if os.path.basename(trainer) == "main-batch.py":

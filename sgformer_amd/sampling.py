@@ -58,7 +58,7 @@ class NeighborSampler:
         if any(k > 32 for k in self.fanouts):
             raise ValueError("NeighborSampler: fan-outs above 32 are not supported (use -1 for all neighbours)")
         self.seed = int(seed) & (2 ** 64 - 1)
-        self.local_of = torch.full((self.n,), -1, dtype=torch.int32, device=dev)
+        self.local_of = torch.full((self.n,), torch.iinfo(torch.int32).min, dtype=torch.int32, device=dev)   # not in the batch
         self.batches = 0
         self.max_deg = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.n > 0 else 0
 

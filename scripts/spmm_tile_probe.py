@@ -99,7 +99,10 @@ def main():
             os.environ.pop("SGF_SPMM_TILE_CHUNK")
         if a.ablate:
             for dbg, what in ((1, "no tile phase (gathers + stores only)"), (2, "no gathers (tiles + stores only)"),
-                              (3, "neither (skeleton)")):
+                              (3, "neither (skeleton)"), (16, "gathers clamped to 4096 rows (all L2 hits)"),
+                              (17, "no tile phase + gathers clamped (L2 hits)"), (32, "no multiply-adds in the gather loop"),
+                              (33, "no tile phase, no multiply-adds"), (49, "no tile phase, L2-hit gathers, no multiply-adds"),
+                              (128, "tile phase without matrix-core work"), (130, "no gathers, tile phase without MFMA")):
                 os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg)
                 report(f"  ablation [{what}]", timed(lambda: ops.K.spmm_tile(plan, x, n)))
             os.environ.pop("SGF_SPMM_TILE_DEBUG")

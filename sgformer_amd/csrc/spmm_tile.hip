@@ -55,6 +55,8 @@ __device__ __forceinline__ float other_half(float v) {
 
 constexpr int kChunk = 32;                    // staged sources per ring slot
 constexpr int kRingPairs = 8;                 // epilogue: 1 KiB gather slots per wave (two rows of X each)
+constexpr int kStashPad = 64;                 // register-set epilogue: positions of padding behind an epoch (>= 8 kRingPairs)
+constexpr uint32_t kOobOffset = 0xfffffc00u;  // a gather offset beyond any x (x_bytes < 2^32 - 2048): the load returns zeros
 constexpr int kStash = 256;                   // epilogue: {source, value} pairs parked in LDS per epoch
 constexpr int kMaxStaged = 1024;
 
@@ -78,13 +80,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   constexpr int D = 32 * NCT;
   constexpr int kRowBytes = D * 2;                       // one staged row
   constexpr int kSlotBytes = kChunk * kRowBytes;         // one ring slot (16 KiB at d = 256)
-  constexpr int kPatchBytes = 8 * D * 4;                 // per wave: 8 rows of fp32 partial sums
-  constexpr int kRingBytesW = kRingPairs * 1024;         // per wave: the gather ring
+  constexpr bool kRegRing = SETS == 0;                   // epilogue variant: gathers consumed straight from registers
+  constexpr int kPatchRows = kRegRing ? 16 : 8;          // rows of fp32 partial sums parked per wave
+  constexpr int kPatchBytes = kPatchRows * D * 4;
+  constexpr int kRingBytesW = kRegRing ? 0 : kRingPairs * 1024;   // per wave: the LDS gather ring (not for the register ring)
+  constexpr int kStashW = kStash + (kRegRing ? kStashPad : 0);
   constexpr int kRingBytes = 2 * kSlotBytes;
   // [ K-loop ring, later the 4 patches ][ 4 gather rings ][ 4 stashes ]: only the patches alias the K-loop ring, so the
   // stash can be filled while the tile phase runs
   constexpr int kBase = NW * kPatchBytes > kRingBytes ? NW * kPatchBytes : kRingBytes;
-  constexpr int kDataBytes = kBase + NW * (kRingBytesW + kStash * 8);
+  constexpr int kDataBytes = kBase + NW * (kRingBytesW + kStashW * 8);
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kDataBytes];
   __shared__ int32_t cols_lds[kMaxStaged];
 
@@ -166,8 +171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   const int64_t r_base = mine ? static_cast<int64_t>(row0) + 32 * wid : static_cast<int64_t>(row0);
   float* patch = reinterpret_cast<float*>(smem + wid * kPatchBytes);                // 8 rows x D fp32
   unsigned char* ring = smem + kBase + wid * kRingBytesW;                          // kRingPairs x 1 KiB
-  int32_t* stash_col = reinterpret_cast<int32_t*>(smem + kBase + NW * kRingBytesW + wid * (kStash * 8));
-  float* stash_val = reinterpret_cast<float*>(stash_col + kStash);
+  int32_t* stash_col = reinterpret_cast<int32_t*>(smem + kBase + NW * kRingBytesW + wid * (kStashW * 8));
+  float* stash_val = reinterpret_cast<float*>(stash_col + kStashW);
+  uint32_t* stash_off = reinterpret_cast<uint32_t*>(stash_col);    // register-set epilogue: byte offsets instead of ids
   const int half = lane >> 5;
   const bool hi = lane >= 32;
   const int fc = (lane & 31) * 8;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     if (DMA) stage(0, 0); else stage_load(0, sreg);
     if (mine) load_a(0, a_cur);
   }
-  if (mine && !slow_path && total > 0) fill_stash(0);
+  if (!kRegRing && mine && !slow_path && total > 0) fill_stash(0);
   if (tiles_on) {
     if (!DMA) stage_write(0, sreg);
     for (int q = 0; q < NQ; ++q) {
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
         for (int s = 0; s < 2; ++s) {
           const bf16x8 ah = __builtin_bit_cast(bf16x8, a_cur[2 * s]);
           const bf16x8 al = __builtin_bit_cast(bf16x8, a_cur[2 * s + 1]);
+          if (dbg & 128) continue;                         // timing experiment: staging + fragment loads only
 #pragma unroll
           for (int t = 0; t < NCT; ++t) {
             const unsigned char* p = slot + (2 * s * NCT + t) * 512;
@@ -274,20 +281,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   // row-finish site (an unrolled register ring needs one per pair: 390 KiB of code in the first version of this kernel).
   // {source, value} of up to kStash stream positions are parked in LDS first (coalesced loads, requested before the tile
   // phase); longer streams take several such epochs.
-  // the tile's partial sums of rows 8 q .. 8 q + 7: accumulator register i holds row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  // the tile's partial sums of rows kPatchRows q ..: accumulator register i holds row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
   auto refill_q = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
+    constexpr int kRegs = kPatchRows / 2;                // accumulator registers per column tile and group
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
-      for (int i = 4 * q; i < 4 * q + 4; ++i)
-        patch[((i & 3) + 4 * (lane >> 5)) * D + 32 * t + (lane & 31)] = acc[t][i];
+      for (int i = kRegs * q; i < kRegs * q + kRegs; ++i)
+        patch[(((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) & (kPatchRows - 1)) * D + 32 * t + (lane & 31)] = acc[t][i];
   };
   auto refill = [&](int q) {
     if (q == 0) refill_q(std::integral_constant<int, 0>{});
     else if (q == 1) refill_q(std::integral_constant<int, 1>{});
-    else if (q == 2) refill_q(std::integral_constant<int, 2>{});
-    else refill_q(std::integral_constant<int, 3>{});
+    else if (kPatchRows == 8 && q == 2) refill_q(std::integral_constant<int, (kPatchRows == 8 ? 2 : 0)>{});
+    else if (kPatchRows == 8) refill_q(std::integral_constant<int, (kPatchRows == 8 ? 3 : 0)>{});
   };
 
   float racc[8];
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   uint16_t* __restrict__ yl = y + r_base * ldy + (active ? fc : 0);
   // row finished: (even + odd stream positions) + the tile's partial sum, one rounding; lanes 0-31 write 8 bf16 each
   auto flush_row = [&](int local_row) {
-    const float* pr = patch + (local_row & 7) * D + (active ? fc : 0);
+    const float* pr = patch + (local_row & (kPatchRows - 1)) * D + (active ? fc : 0);
     const float4 p0 = *reinterpret_cast<const float4*>(pr);
     const float4 p1 = *reinterpret_cast<const float4*>(pr + 4);
     float t[8];
@@ -327,12 +335,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     for (int k = 0; k < 8; ++k) racc[k] = 0.f;
   };
 
-  refill(0);
+  if (!kRegRing || slow_path) refill(0);
   if (slow_path) {
     // rare: a hub row among these 32 (its tile part is empty by construction: the plan leaves long rows alone)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
     for (int r = 0; r < nr; ++r) {
-      if (r > 0 && (r & 7) == 0) refill(r >> 3);
+      if (r > 0 && (r & (kPatchRows - 1)) == 0) refill(r / kPatchRows);
       const int64_t re = lane64(end_abs, r);
       const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
       if (re - rb > lq.long_len) {
@@ -358,12 +366,131 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
       flush_row(row);
       ++row;
       if (row < nr) {
-        if ((row & 7) == 0) refill(row >> 3);
+        if ((row & (kPatchRows - 1)) == 0) refill(row / kPatchRows);
         row_end = (dbg & 2) ? 0 : __builtin_amdgcn_readlane(rel_v, row);
       }
     }
   };
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+  if constexpr (kRegRing) {
+    // ---- gathers consumed straight from registers ---------------------------------------------------------------------
+    // Two register sets of B pair loads each: while set A is consumed, set B is in flight, and A is re-issued as soon as
+    // its last pair is consumed.  Steps are unrolled, registers and LDS offsets static: per pair one ds_read_b32 of the
+    // source (for the re-issue), one of the value, the multiply-adds, and a wave-uniform compare for a row end.
+    // A row end COMMITS the row — (even + odd positions) added into the row's slot of the patch, which already holds the
+    // tile's partial sum: ~35 instructions, no vector-memory operation, so the unrolled steps stay small (the first
+    // version inlined rounding, the store and the patch refill at every step: 100-390 KiB of code).  Rounding to bf16 and
+    // the stores are a compact pass over the patch afterwards, 16 rows at a time: two halves per wave.
+    constexpr int B = kRingPairs;
+    auto run_half = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      const int nrh = nr - 16 * h < 16 ? nr - 16 * h : 16;
+      refill_q(hc);
+      const int start = h == 0 ? 0 : __builtin_amdgcn_readlane(rel_v, 15);     // stream positions of this half
+      const int stop = __builtin_amdgcn_readlane(rel_v, 16 * h + nrh - 1);
+      const int tot = (dbg & 2) ? 0 : stop - start;
+      const int32_t* __restrict__ cih = ci + start;
+      const float* __restrict__ vah = va + start;
+      int row = 16 * h;                                    // first row of the half; rows without entries are skipped
+      int row_end = __builtin_amdgcn_readlane(rel_v, row) - start;
+      auto commit = [&](int pos) {                         // the row that ends at `pos` (relative to the half)
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = racc[k] + other_half(racc[k]);
+        if (active && !hi) {
+          float* pr = patch + (row & 15) * D + fc;
+          float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+          p0.x += t[0]; p0.y += t[1]; p0.z += t[2]; p0.w += t[3];
+          p1.x += t[4]; p1.y += t[5]; p1.z += t[6]; p1.w += t[7];
+          *reinterpret_cast<float4*>(pr) = p0;
+          *reinterpret_cast<float4*>(pr + 4) = p1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) racc[k] = 0.f;
+        do {
+          ++row;
+          row_end = row < 16 * h + nrh ? __builtin_amdgcn_readlane(rel_v, row) - start : 0x7fffffff;
+        } while (row_end == pos);
+      };
+      while (row_end == 0) {                               // leading rows without entries
+        ++row;
+        row_end = row < 16 * h + nrh ? __builtin_amdgcn_readlane(rel_v, row) - start : 0x7fffffff;
+      }
+      for (int base = 0; base < tot; base += kStash) {
+        const int ne = tot - base < kStash ? tot - base : kStash;     // stream positions of this epoch (even)
+        const int np = ne >> 1;
+        // the epoch's {byte offset of the source row, value}, followed by kStashPad positions of {out-of-range offset, 0}:
+        // the unrolled steps below read up to 4 B pairs past the epoch's end without a bound test (such a gather
+        // returns zeros without touching memory: buffer range check)
+#pragma unroll
+        for (int i = 0; i < (kStash + kStashPad) / 64; ++i) {
+          const int idx = 64 * i + lane;
+          const bool ok = idx < ne;
+          stash_off[idx] = ok ? static_cast<uint32_t>(cih[base + idx]) * pitch : kOobOffset;
+          stash_val[idx] = ok ? vah[base + idx] : 0.f;
+        }
+        // pairs b0 .. b0 + B - 1 of the epoch: per pair one LDS read, one add, one load
+        auto issue = [&](int b0, u32x4 (&rg)[B]) {
+          const uint32_t* so = stash_off + 2 * b0 + half;
+#pragma unroll
+          for (int j = 0; j < B; ++j)
+            rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
+        };
+        // distance (in stream positions) from the end of pair b0's first position to the current row's end
+        // (a row end beyond this epoch must not be matched by the padding positions)
+        auto rel_end = [&]() -> int { return row_end - base <= ne ? row_end - base : 0x3fffffff; };
+        int to_end = rel_end();
+        auto consume = [&](int b0, const u32x4 (&rg)[B]) {
+          const float* sv = stash_val + 2 * b0 + half;
+          float vv[B];
+#pragma unroll
+          for (int j = 0; j < B; ++j) vv[j] = sv[2 * j];
+          int d0 = to_end - 2 * b0;
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            fma8(vv[j], rg[j]);
+            if (d0 == 2 * j + 2) {                           // wave-uniform: this pair closes its row
+              commit(row_end);
+              to_end = rel_end();
+              d0 = to_end - 2 * b0;
+            }
+          }
+        };
+        // set A crosses the loop's back edge in flight, set B is issued and consumed inside one iteration: the queue
+        // hipcc's wait-count pass sees at the loop header is the same on entry and on the back edge (B loads of set A,
+        // oldest first) — with both sets crossing the back edge it ordered the header wait as vmcnt(0)
+        u32x4 ra[B], rb[B];
+        issue(0, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int b0 = 0; b0 < np; b0 += 2 * B) {
+          issue(b0 + B, rb);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(b0, ra);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(b0 + 2 * B, ra);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(b0 + B, rb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // rounding + store of the half's rows (a row without gathered entries holds the tile's partial sum as it is)
+      for (int lr = 0; lr < nrh; ++lr) {
+        if (active && !hi) {
+          const float* pr = patch + lr * D + fc;
+          const float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+          uint4 o;
+          o.x = pack_bf16(p0.x, p0.y);
+          o.y = pack_bf16(p0.z, p0.w);
+          o.z = pack_bf16(p1.x, p1.y);
+          o.w = pack_bf16(p1.z, p1.w);
+          *reinterpret_cast<uint4*>(yl + (16 * h + lr) * ldy) = o;
+        }
+      }
+    };
+    run_half(std::integral_constant<int, 0>{});
+    if (nr > 16) run_half(std::integral_constant<int, 1>{});
+    return;
+  }
   u32x4 rga[kRingPairs], rgb[kRingPairs];              // two batches of pair loads in flight
   for (int base = 0; base < total; base += kStash) {
     const int ne = total - base < kStash ? total - base : kStash;     // stream positions of this epoch (even)
@@ -374,7 +501,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
 #pragma unroll
       for (int j = 0; j < kRingPairs; ++j) {
         const int kk = b8 + j < np ? b8 + j : np - 1;
-        const uint32_t c = static_cast<uint32_t>(stash_col[2 * kk + half]);
+        uint32_t c = static_cast<uint32_t>(stash_col[2 * kk + half]);
+        if (dbg & 16) c &= 4095u;                        // timing experiment: every gather hits in L2
         rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(lanebase + c * pitch), 0, 0);
       }
     };
@@ -401,7 +529,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
           if (j + u < nj) {
             const int pos = base + 2 * (b8 + j + u);
             if (pos == row_end) boundary(pos);
-            fma8(vv[u], raw[u]);
+            if (!(dbg & 32)) fma8(vv[u], raw[u]);
+            else racc[0] += __uint_as_float(raw[u].x & 1u);   // timing experiment: no multiply-adds
           }
         }
       }
@@ -443,7 +572,7 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
                   reinterpret_cast<uintptr_t>(y) % 16 == 0,
               SGF_E_INVALID, "%s: x / y rows must be 16-byte aligned (ld %% 8 == 0)", fn);
   const uint64_t x_bytes = static_cast<uint64_t>(n_cols) * static_cast<uint64_t>(ldx) * 2;
-  SGF_REQUIRE(x_bytes < (static_cast<uint64_t>(1) << 32), SGF_E_UNSUPPORTED, "%s: x beyond 4 GiB (32-bit gather offsets)", fn);
+  SGF_REQUIRE(x_bytes < (static_cast<uint64_t>(1) << 32) - 2048, SGF_E_UNSUPPORTED, "%s: x beyond 4 GiB (32-bit gather offsets)", fn);
   SGF_REQUIRE(long_len >= 1 && long_segments >= 0 && long_segments < (static_cast<int64_t>(1) << 31), SGF_E_INVALID,
               "%s: bad long_len / long_segments", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -461,7 +590,9 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
     SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
   }
   TilePlanArgs P{blk_row, sh_ptr, sh_cols, tile_ptr, static_cast<const uint4*>(tiles), rem_rowptr, rem_col, rem_val};
-  // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers
+  // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers,
+  // 4 / 8 = nt fragment loads / y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
+  // loop, 128 = no matrix-core work in the tile phase
   const char* dbg_env = getenv("SGF_SPMM_TILE_DEBUG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   int chunk = 64;                                        // an XCD walks 64 consecutive blocks (<= 8192 rows) at a time
@@ -470,8 +601,9 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   uint16_t* ys = static_cast<uint16_t*>(y);
   const char* dma_env = getenv("SGF_SPMM_TILE_DMA");     // "1": stage X through LDS-DMA instead of registers (A/B)
   const bool dma = dma_env && dma_env[0] == '1';
-  const char* sets_env = getenv("SGF_SPMM_TILE_SETS");   // "1": one batch of gathers in flight per wave, consumed 4 at a time (A/B)
-  const bool one_set = sets_env && sets_env[0] == '1';
+  // epilogue variant (A/B): 0 = register ring (default), 1 / 2 = one / two batches of gathers parked in an LDS ring
+  const char* sets_env = getenv("SGF_SPMM_TILE_SETS");
+  const int sets = sets_env ? atoi(sets_env) : 0;
 #define SGF_TILE_LAUNCH(NCT_, DMA_, SETS_, CONS_, NW_)                                                                 \
   hipLaunchKernelGGL((k_spmm_tile_bf16<NCT_, DMA_, SETS_, CONS_, NW_>), dim3(static_cast<unsigned>(nb)), dim3(NW_ * 64), 0, \
                      st, P, xs, static_cast<uint32_t>(ldx * 2), static_cast<uint32_t>(x_bytes), ys, ldy,                \
@@ -479,9 +611,13 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
 #define SGF_TILE_LAUNCH2(NCT_, DMA_)                                                      \
   do {                                                                                    \
     if (block_rows > 128) {                                                               \
-      if (one_set) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 8); else SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 8); \
+      if (sets == 1) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 8);                                \
+      else if (sets == 2) SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 8);                           \
+      else SGF_TILE_LAUNCH(NCT_, DMA_, 0, 2, 8);                                          \
     } else {                                                                              \
-      if (one_set) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 4); else SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 4); \
+      if (sets == 1) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 4);                                \
+      else if (sets == 2) SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 4);                           \
+      else SGF_TILE_LAUNCH(NCT_, DMA_, 0, 2, 4);                                          \
     }                                                                                     \
   } while (0)
   if (d == 256) {

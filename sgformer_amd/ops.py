@@ -915,10 +915,10 @@ class BlockedPlan:
 
 # Tile plan parameters: at most TILE_CAP staged sources per block (whole 32-source chunks), a source is staged when at
 # least TILE_MIN_COUNT of the block's entries reference it (a staged source costs one 512-byte row of X plus one
-# 512-byte tile column per block, a gathered entry 520 bytes each time; measured at ogbn-products scale: 2 -> 2.55 ms,
-# 3 -> 2.43 ms), blocks of at most TILE_MAX_ROWS rows (256-row blocks of 8 waves, one per CU: 2.75 ms; 64: 4.4 ms).
+# 512-byte tile column per block, a gathered entry 520 bytes each time; measured at ogbn-products scale: 2 -> 2.16 ms,
+# 3 -> 2.21 ms), blocks of at most TILE_MAX_ROWS rows (256-row blocks of 8 waves, one per CU: 2.75 ms; 64: 4.4 ms).
 TILE_CAP = 512
-TILE_MIN_COUNT = 3
+TILE_MIN_COUNT = 2
 TILE_MAX_ROWS = 128
 
 

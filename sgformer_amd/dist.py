@@ -122,11 +122,18 @@ class ShardedGraph:
             lo, hi = torch.aminmax(edge_index)
             if int(lo) < 0 or int(hi) >= n_g:
                 raise IndexError(f"edge_index has node ids outside [0, {n_g})")
-        deg = torch.bincount(dst, minlength=n_g).to(torch.int32)
-        fwd, bwd = src * n_g + dst, dst * n_g + src
-        self.symmetric = bool(_mix64(fwd, 0).sum() == _mix64(bwd, 0).sum()) and \
-            bool(_mix64(fwd, 1).sum() == _mix64(bwd, 1).sum())
+        # in-degrees and the symmetry test: every rank works on ITS 1/P slice of the (replicated) edge list and one
+        # all-reduce makes both global — O(E/P) per rank instead of an O(E) histogram + two 64-bit hashes everywhere
+        e_all = int(src.numel())
+        e0, e1 = ctx.rank * e_all // ctx.world, (ctx.rank + 1) * e_all // ctx.world
+        deg = torch.bincount(dst[e0:e1], minlength=n_g)
+        fwd, bwd = src[e0:e1] * n_g + dst[e0:e1], dst[e0:e1] * n_g + src[e0:e1]
+        chk = torch.stack([_mix64(fwd, 0).sum(), _mix64(bwd, 0).sum(), _mix64(fwd, 1).sum(), _mix64(bwd, 1).sum()])
         del fwd, bwd
+        ctx.all_reduce_exact(deg)
+        ctx.all_reduce_exact(chk)                                     # sums wrap mod 2^64 on every rank alike
+        deg = deg.to(torch.int32)
+        self.symmetric = bool(chk[0] == chk[1]) and bool(chk[2] == chk[3])
         own_t = (dst >= ctx.r0) & (dst < ctx.r1)
         self.rowptr, self.colind, self.val = self._block(edge_index[:, own_t], deg, ctx, transposed=False)
         self.long_segments = ops.long_row_segments(self.rowptr)
@@ -219,6 +226,105 @@ class ShardedGraph:
         return self._halo[key]
 
 
+class RowExchange:
+    """Moves node rows between two contiguous partitions of the same P ranks: rank r owns `want` = the (global,
+    old-numbering) rows it needs, in the order it wants them.  One plan serves both directions: forward() gathers the
+    wanted rows from their owners, backward() returns rows (or their gradients) to the owners.  Built with two
+    collectives; every exchange is one pack (sgf_gather_rows) + one all_to_all_single + one placement gather."""
+
+    def __init__(self, want: torch.Tensor, ctx: "ShardContext"):
+        dev = want.device
+        want = want.long()
+        owner = torch.div(want, ctx.n_max, rounding_mode="floor")
+        order = torch.argsort(owner, stable=True)                 # receive buffer position j  <-  wanted row order[j]
+        self.place = torch.empty_like(order)
+        self.place[order] = torch.arange(order.numel(), device=dev)   # wanted row i sits at recv position place[i]
+        self.order = order
+        need_counts = torch.bincount(owner, minlength=ctx.world)[: ctx.world]
+        send_counts = torch.empty_like(need_counts)
+        dist.all_to_all_single(send_counts, need_counts, group=ctx.group)
+        self.recv_counts = [int(v) for v in need_counts.tolist()]
+        self.send_counts = [int(v) for v in send_counts.tolist()]
+        asked = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(asked, want[order].contiguous(), self.send_counts, self.recv_counts, group=ctx.group)
+        if asked.numel() and (int(asked.min()) < ctx.r0 or int(asked.max()) >= ctx.r1):
+            raise RuntimeError("row exchange: a peer asked for a row this rank does not own")
+        self.send_idx = asked - ctx.r0                           # local rows to pack, grouped by destination
+        self.n_want, self.n_own, self.ctx = int(want.numel()), ctx.n_local, ctx
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        """rows of the OLD partition (this rank's [n_local, ...]) -> the rows this rank wants, in `want` order."""
+        send = t[self.send_idx].contiguous()
+        recv = t.new_empty((self.n_want,) + tuple(t.shape[1:]))
+        dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts, group=self.ctx.group)
+        self.ctx.bytes_repartition += send.numel() * send.element_size()
+        return recv[self.place]
+
+    def backward(self, t: torch.Tensor) -> torch.Tensor:
+        """the reverse move: rows in `want` order -> back to their owners' local positions (every owned row is wanted
+        by exactly one rank when `want` is a permutation of all nodes)."""
+        send = t[self.order].contiguous()
+        recv = t.new_empty((int(self.send_idx.numel()),) + tuple(t.shape[1:]))
+        dist.all_to_all_single(recv, send, self.send_counts, self.recv_counts, group=self.ctx.group)
+        self.ctx.bytes_repartition += send.numel() * send.element_size()
+        out = t.new_zeros((self.n_own,) + tuple(t.shape[1:]))
+        out[self.send_idx] = recv
+        return out
+
+
+class _Exchange(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, plan, reverse: bool):
+        ctx.plan, ctx.reverse = plan, reverse
+        return plan.backward(t) if reverse else plan.forward(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (ctx.plan.forward(g) if ctx.reverse else ctx.plan.backward(g)), None, None
+
+
+class Repartition:
+    """A locality-restoring node order ACROSS ranks (the halo exchange only engaged when the caller's
+    ids already carried the locality).  Every rank holds the global edge list (replicated mode), so every rank
+    computes the same sgf_reorder permutation on it (deterministic), relabels the edges and takes the contiguous
+    range [r0, r1) of the NEW numbering; features enter and logits leave through one all-to-all each
+    (`to_new` / `to_old`, differentiable), so the caller keeps its own numbering.  Adopted only if the halo of the
+    re-partitioned graph is small enough for the halo path (HaloPlan.enabled) — a uniform random graph keeps its
+    order and the all-gather fallback."""
+
+    def __init__(self, edge_index: torch.Tensor, ctx: "ShardContext"):
+        n = ctx.n_global
+        perm, inv, _ = ops.K.reorder(edge_index, n, *ops.REORDER_ITERS)
+        ei2 = inv.long()[edge_index]
+        ei2._sgf_trusted = True
+        graph = ShardedGraph(ei2, ctx)
+        self.adopted = graph.halo(ctx, False).enabled
+        self.stats = {"halo_fraction": graph.halo(ctx, False).max_fraction, "adopted": self.adopted}
+        if not self.adopted:
+            return
+        self.edge_index, self.graph = ei2, graph
+        ei2._sgf_sharded_graph = graph
+        self.perm, self.inv = perm, inv
+        self.plan = RowExchange(perm[ctx.r0:ctx.r1], ctx)        # new row p of this rank = old node perm[p]
+        self._cache = None
+
+    def to_new(self, t: torch.Tensor) -> torch.Tensor:
+        """[n_local, ...] in the caller's partition -> this rank's rows of the re-ordered partition.  A tensor that
+        does not require grad and is passed again (full-graph training: the same x every step) is moved once."""
+        if not t.requires_grad:
+            key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+            if self._cache is not None and self._cache[0] == key:
+                return self._cache[1]
+            out = self.plan.forward(t)
+            self._cache = (key, out, t)
+            return out
+        return _Exchange.apply(t, self.plan, False)
+
+    def to_old(self, t: torch.Tensor) -> torch.Tensor:
+        return _Exchange.apply(t, self.plan, True)
+
+
 class ShardContext:
     """Partition + collectives of one rank.  `group=None` uses the default process group."""
 
@@ -240,6 +346,48 @@ class ShardContext:
         self.bytes_all_reduced = 0
         self.bytes_all_gathered = 0
         self.bytes_halo_sent = 0
+        self.bytes_repartition = 0
+        # SGF_DIST_REORDER=0 keeps the caller's node order across ranks (default: try sgf_reorder once per graph)
+        self.reorder = os.environ.get("SGF_DIST_REORDER", "1") == "1" and not self.local_edges
+        self.local_graph = False        # batch mode: the SpMM multiplies with this rank's own edges only (no halo)
+
+    @classmethod
+    def for_batch(cls, n_local_rows: int, group=None) -> "ShardContext":
+        """BASELINE.json config 5, 'mini-batch + 8-GPU node-shard' (SURVEY.md §8e): every rank draws a mini-batch from
+        ITS node shard; the union of the ranks' batches is the attention set (the N of large/ours.py:133-148 is the
+        GLOBAL batch size, the K^T V / BatchNorm partials are all-reduced), while the GCN branch multiplies with the
+        rank's own induced subgraph — edges inside the local batch only, no halo.  Batches may differ in size: ranges
+        follow an all-gather of the local counts.  Parity is defined against ONE process running the concatenated
+        batch with the block-diagonal union of the ranks' subgraphs (tests/test_dist.py)."""
+        ctx = cls.__new__(cls)
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        ctx.group = group
+        ctx.rank, ctx.world = dist.get_rank(group), dist.get_world_size(group)
+        counts = [None] * ctx.world
+        dist.all_gather_object(counts, int(n_local_rows), group=group)
+        ctx.n_global = int(sum(counts))
+        ctx.n_max = max(max(counts), 1)
+        ctx.r0 = int(sum(counts[: ctx.rank]))
+        ctx.r1 = ctx.r0 + int(n_local_rows)
+        ctx.n_local = int(n_local_rows)
+        ctx.local_edges, ctx.local_graph, ctx.reorder = False, True, False
+        ctx.halo_max = 0.0
+        ctx.bytes_all_reduced = ctx.bytes_all_gathered = ctx.bytes_halo_sent = ctx.bytes_repartition = 0
+        return ctx
+
+    def repartition_for(self, edge_index: torch.Tensor):
+        """The Repartition of this (replicated) edge list, or None when disabled / not adopted; decided once per
+        edge_index, at the same point of the step on every rank."""
+        if not self.reorder or not hasattr(ops.K, "reorder"):
+            return None
+        cache = self.__dict__.setdefault("_repart", {})
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+        if key not in cache:
+            cache.clear()
+            rp = Repartition(edge_index, self)
+            cache[key] = (rp if rp.adopted else None, edge_index)
+        return cache[key][0]
 
     # ---- partition helpers ----
     def shard_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -250,6 +398,9 @@ class ShardContext:
         return global_idx[m] - self.r0
 
     def graph_for(self, edge_index: torch.Tensor) -> ShardedGraph:
+        g = getattr(edge_index, "_sgf_sharded_graph", None)       # the relabelled list of a Repartition carries its graph
+        if g is not None:
+            return g
         return ops.graph_cache.get(edge_index, -self.n_global - self.rank - 1,
                                    factory=lambda ei, _n: ShardedGraph(ei, self))
 

@@ -821,7 +821,8 @@ class CSRGraph:
                 transposed = False
         if transposed not in self._tile_plans:
             rp, ci, va = self.transposed() if transposed else (self.rowptr, self.colind, self.val)
-            self._tile_plans[transposed] = TilePlan(rp, ci, va, self.n, self.blk_row)
+            self._tile_plans[transposed] = TilePlan(rp, ci, va, self.n, self.blk_row,
+                                                   min_count=getattr(self, "tile_min_count", None))
         return self._tile_plans[transposed]
 
     def view(self, now: bool = False) -> "GraphView":
@@ -920,6 +921,7 @@ class BlockedPlan:
 TILE_CAP = 512
 TILE_MIN_COUNT = 2
 TILE_MAX_ROWS = 128
+TILE_SPARSE_DENSITY = 0.12
 
 
 def _tile_params():
@@ -1003,8 +1005,15 @@ class GraphView:
         _, _, max_rows = _tile_params()
         g2.blk_row = K.tile_blocks(comm[perm.long()].contiguous(), g.n, max_rows, g.device)
         tp = g2.tile_plan(False)
+        if tp.tile_density < TILE_SPARSE_DENSITY and tp.min_count == TILE_MIN_COUNT and not os.environ.get("SGF_SPMM_TILE"):
+            # tiles this sparse (a skewed graph: many sources referenced just twice per block) move more fragment bytes
+            # than the gathers they replace: stage only sources with one more reference (power-law community graph at
+            # ogbn-products scale: density 0.08 -> 0.11, 3.08 -> 2.92 ms; profiles/r03_spmm_tile.md)
+            g2.tile_min_count = TILE_MIN_COUNT + 1
+            g2._tile_plans.clear()
+            tp = g2.tile_plan(False)
         stats = {"lds_fraction": tp.tile_fraction, "tile_density": tp.tile_density, "blocks": tp.nb,
-                 "staged_rows_per_node": tp.staged_rows / max(g.n, 1), "plan_bytes": tp.bytes}
+                 "staged_rows_per_node": tp.staged_rows / max(g.n, 1), "plan_bytes": tp.bytes, "min_count": tp.min_count}
         if tp.tile_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
             return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
         # Which kernel multiplies with the re-ordered CSR: dense matrix-core tiles + gather remainder (sgf_spmm_tile)

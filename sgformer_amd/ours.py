@@ -154,11 +154,13 @@ class GraphConvLayer(nn.Module):
         shard = self._shard
         if isinstance(edge_index, ops.CSRGraph):   # SGFormer.forward resolved (and maybe re-ordered) it already
             graph = edge_index
-        elif shard is not None:
+        elif shard is not None and not shard.local_graph:
             graph = shard.graph_for(edge_index)
         else:
+            # one GPU — or the batch mode of a sharded run (ShardContext.for_batch): this rank's own induced
+            # subgraph, no halo; only the attention / BatchNorm partial sums cross ranks
             graph = ops.graph_cache.get(edge_index, x.shape[0])
-        y = ops.spmm(graph, x, shard)
+        y = ops.spmm(graph, x, None if (shard is not None and shard.local_graph) else shard)
         if self.use_init:
             # W [y | x0] + b without materialising the concatenation
             if bn_stats:
@@ -480,6 +482,15 @@ class SGFormer(nn.Module):
         if self.use_graph and self.graph_conv._shard is None and ops.K.name == "hip":
             view = ops.graph_cache.get(edge_index, x.shape[0]).view()
             edge_index = view.graph
+        # Node-sharded run on a replicated edge list: partition in sgf_reorder order ACROSS ranks when that makes the
+        # cut small enough for the halo exchange (dist.Repartition) — features enter and logits leave through one
+        # all-to-all each, the caller keeps its own numbering and partition.
+        repart = None
+        shard = self.graph_conv._shard if self.use_graph else None
+        if shard is not None and not shard.local_edges and not shard.local_graph:
+            repart = shard.repartition_for(edge_index)
+            if repart is not None:
+                x, edge_index = repart.to_new(x), repart.edge_index
         if view is not None and view.perm is not None:
             x = ops.permute_rows(x, view.perm, view.inv, cdt)
         elif x.dtype != cdt:
@@ -532,6 +543,8 @@ class SGFormer(nn.Module):
             out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
         if view is not None and view.perm is not None:
             out = ops.permute_rows(out, view.inv, view.perm)       # back to the caller's node order
+        if repart is not None:
+            out = repart.to_old(out)                               # back to the caller's partition
         return out
 
     def get_attentions(self, x):

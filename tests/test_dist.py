@@ -110,7 +110,7 @@ def _worker_halo(rank, world, port, directed, ret):
     """A graph whose contiguous node ranges cut few edges (planted communities, ids NOT shuffled): the
     SpMM exchange must take the halo path (no all-gather at all) and match the full-graph oracle."""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_REORDER="0")   # the caller's order HAS the locality
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
@@ -419,3 +419,157 @@ def test_sharded_bf16_streaming_paths_match_single_process():
         assert e["logits"] <= 3e-2 * max(1.0, e["scale"]), e
         assert e["grad"] <= 0.2, e
         assert e["running_var"] <= 2e-2, e
+
+
+def _worker_repartition(rank, world, port, reorder, directed, ret):
+    """A community graph whose ids are SHUFFLED: contiguous ranges of the caller's numbering cut almost every edge.
+    With SGF_DIST_REORDER=1 (default) every rank computes the same sgf_reorder permutation, the ranks re-partition in
+    that order (features in / logits out through one all-to-all each) and the SpMM takes the halo path; with 0 it falls
+    back to the all-gather.  Either way the result is the full-graph oracle's in the CALLER's order."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_REORDER=reorder, SGF_DIST_CHUNK_COLS="64")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import sgformer_oracle as O
+        from sgformer_amd import ops, synth
+        from sgformer_amd.dist import ShardContext, shard_model, sharded_nll_loss
+        from sgformer_amd.ours import SGFormer
+        from tests.cpu_kernels import CpuKernels
+        from tests.test_host import CONFIGS
+
+        ops.set_kernels(CpuKernels())
+        cfg = CONFIGS["products"]
+        n, f, d, c = 611, 10, 16, 4
+        torch.manual_seed(5)
+        x = torch.randn(n, f)
+        ei = synth.synthetic_graph_community(n, 8.0, seed=3, comm_size=(20, 40), comms_per_super=4, p_comm=0.92,
+                                             p_super=0.07, shuffle_ids=True)
+        if directed:
+            keep = (ei[0] <= ei[1]) | (torch.arange(ei.shape[1]) % 3 != 0)
+            ei = ei[:, keep]
+        y = torch.randint(0, c, (n,))
+        idx = torch.randperm(n)[: n // 2]
+        p = O.init_params(cfg, f, d, c, seed=6)
+        ctx = ShardContext(n)
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        shard_model(m, ctx)
+        m.train()
+        xl = ctx.shard_rows(x).contiguous()
+        for _ in range(2):                                 # second step: the re-partitioned features are reused
+            m.zero_grad(set_to_none=True)
+            logits = m(xl, ei)
+            loss = sharded_nll_loss(logits, ctx.shard_rows(y), ctx.local_index(idx), idx.numel())
+            loss.backward()
+        ctx.sync_grads(m.parameters())
+        p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+        ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True)
+        O.nll_loss(ref, y, idx).backward()
+        gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+        gerr = 0.0
+        for k, prm in m.named_parameters():
+            if p64[k].grad is not None:
+                e = float((prm.grad.double() - p64[k].grad).norm())
+                gerr = max(gerr, e / (float(p64[k].grad.norm()) + 1e-3 * gmax))
+        rp = ctx.repartition_for(ei)
+        ret[rank] = {"logits": float((logits.detach().double() - ref.detach()[ctx.r0:ctx.r1]).abs().max()), "grad": gerr,
+                     "halo_sent": ctx.bytes_halo_sent, "gathered": ctx.bytes_all_gathered,
+                     "repartition": ctx.bytes_repartition, "adopted": rp is not None,
+                     "fraction": rp.stats["halo_fraction"] if rp is not None else None}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,reorder,directed", [(2, "1", False), (3, "1", False), (2, "1", True), (2, "0", False)])
+def test_repartition_in_reorder_order_engages_the_halo_path(world, reorder, directed):
+    """a locality order across ranks, so that the halo exchange serves graphs whose given ids
+    carry no locality (large/ours.py:34 sharded by rows)."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_repartition, args=(world, port, reorder, directed, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        e = ret[rank]
+        assert e["logits"] < 5e-5 and e["grad"] < 2e-3, e
+        if reorder == "1":
+            assert e["adopted"] and e["fraction"] <= 0.5, e
+            assert e["gathered"] == 0 and e["halo_sent"] > 0 and e["repartition"] > 0, e
+        else:
+            assert not e["adopted"] and e["gathered"] > 0 and e["repartition"] == 0, e
+
+
+def _worker_batch(rank, world, port, ret):
+    """BASELINE.json config 5's mode (SURVEY.md §8e last row): every rank trains on a mini-batch drawn from ITS node
+    shard — own induced subgraph, no halo — while the attention set is the union of the ranks' batches (N = the global
+    batch size in num / den, K^T V and BatchNorm partial sums all-reduced).  Reference: ONE process on the concatenated
+    batch with the block-diagonal union of the subgraphs."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import sgformer_oracle as O
+        from sgformer_amd import ops
+        from sgformer_amd.dist import ShardContext, shard_model, sharded_nll_loss
+        from sgformer_amd.ours_100m import SGFormer
+        from tests.cpu_kernels import CpuKernels
+
+        ops.set_kernels(CpuKernels())
+        cfg = dict(alpha=0.5, trans_num_layers=1, gnn_num_layers=2, gnn_use_init=True, graph_weight=0.8)
+        f, d, c = 10, 16, 5
+        sizes = [57, 44, 63][:world]                        # ragged batches
+        xs, eis, ys, idxs = [], [], [], []
+        for r, nb in enumerate(sizes):                       # every rank builds ALL batches: the reference needs them
+            g = torch.Generator().manual_seed(100 + r)
+            xs.append(torch.randn(nb, f, generator=g))
+            eis.append(O.synthetic_graph(nb, 4.0, seed=20 + r, directed=True))       # sampled batches are directed
+            ys.append(torch.randint(0, c, (nb,), generator=g))
+            idxs.append(torch.randperm(nb, generator=g)[: nb // 2])
+        p = O.init_params(cfg, f, d, c, seed=6)
+        ctx = ShardContext.for_batch(sizes[rank])
+        assert ctx.n_global == sum(sizes) and ctx.r0 == sum(sizes[:rank]) and ctx.local_graph
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        shard_model(m, ctx)
+        m.train()
+        n_train = sum(int(i.numel()) for i in idxs)
+        logits = m(xs[rank], eis[rank])
+        loss = sharded_nll_loss(logits, ys[rank], idxs[rank], n_train)
+        loss.backward()
+        ctx.sync_grads(m.parameters())
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        # reference: one process, concatenated batch, block-diagonal graph
+        off = [sum(sizes[:r]) for r in range(world)]
+        xa, ya = torch.cat(xs), torch.cat(ys)
+        eia = torch.cat([e + o for e, o in zip(eis, off)], dim=1)
+        ida = torch.cat([i + o for i, o in zip(idxs, off)])
+        p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+        ref = O.sgformer_forward(p64, xa.double(), eia, cfg, training=True)
+        lref = O.nll_loss(ref, ya, ida)
+        lref.backward()
+        gmax = max(float(v.grad.norm()) for v in p64.values() if v.grad is not None)
+        gerr = 0.0
+        for k, prm in m.named_parameters():
+            if p64[k].grad is not None:
+                e = float((prm.grad.double() - p64[k].grad).norm())
+                gerr = max(gerr, e / (float(p64[k].grad.norm()) + 1e-3 * gmax))
+        ret[rank] = {"logits": float((logits.detach().double() - ref.detach()[ctx.r0:ctx.r1]).abs().max()),
+                     "loss": abs(float(total) - float(lref)), "grad": gerr, "gathered": ctx.bytes_all_gathered,
+                     "halo": ctx.bytes_halo_sent, "reduced": ctx.bytes_all_reduced}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_minibatch_per_rank_with_global_attention_set(world):
+    """SURVEY.md §8e 'mini-batch + 8 GPU (cfg 5)': 100M/nb-sample.py:27-45 per rank, attention over the union batch."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_batch, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        e = ret[rank]
+        assert e["logits"] < 5e-5 and e["loss"] < 1e-5 and e["grad"] < 2e-3, e
+        assert e["gathered"] == 0 and e["halo"] == 0 and e["reduced"] > 0, e      # no operand crosses ranks

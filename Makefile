@@ -1,4 +1,4 @@
-# Builds libsgf.so (the gfx950 C-ABI library) and the C oracle.  hipcc cross-compiles without a GPU.
+# Builds libsgf.so (the gfx950 C-ABI library).  hipcc cross-compiles without a GPU.  (The oracle is Python / numpy.)
 HIPCC ?= hipcc
 ARCH ?= gfx950
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function \
@@ -8,7 +8,7 @@ SRCS := $(CSRC)/capi.hip $(CSRC)/csr.hip $(CSRC)/spmm.hip $(CSRC)/attn.hip $(CSR
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB  := sgformer_amd/lib/libsgf.so
 
-all: $(LIB) oracle
+all: $(LIB)
 
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
@@ -18,10 +18,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/spmm_shared.h include/sgf.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-oracle:
-	$(MAKE) -C oracle
-
 clean:
 	rm -rf build $(LIB) oracle/_build oracle/_ref
 
-.PHONY: all oracle clean
+.PHONY: all clean

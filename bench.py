@@ -95,9 +95,14 @@ def parse():
     ap.add_argument("--cpu-sample-nodes", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--aten-loss", action="store_true",
-                    help="time the step with the trainer's own F.log_softmax + F.nll_loss (5 ATen kernels) "
-                         "instead of sgformer_amd.loss.log_softmax_nll")
+    ap.add_argument("--loss", default="trainer", choices=["trainer", "fused", "aten"],
+                    help="what the HEADLINE step computes its loss with: 'trainer' (default) = the three loss lines of "
+                         "large/main.py:139-141 exactly as an unchanged trainer runs them under sgformer_amd.launch "
+                         "(nn.NLLLoss served by the gather form, launch.patch_nll_loss); 'fused' = "
+                         "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass); 'aten' = the same three lines "
+                         "on ATen's own nll_loss kernels.  The other two are timed on a few extra steps and reported "
+                         "in config.")
+    ap.add_argument("--aten-loss", action="store_true", help="(older spelling of --loss aten)")
     ap.add_argument("--no-structured", action="store_true",
                     help="skip the second measurement on the community-structured graph with shuffled node ids")
     ap.add_argument("--graph", default="uniform", choices=["uniform", "community"],
@@ -297,17 +302,19 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
         torch.cuda.synchronize()
         t_prep = time.perf_counter() - t0
 
-    state = {"aten": args.aten_loss}
+    from sgformer_amd import launch as _launch
+    state = {"mode": "aten" if args.aten_loss else args.loss}
 
     def step():
         opt.zero_grad(set_to_none=True)
         logits = model(x, ei)
         if ctx is not None:
             loss = sharded_nll_loss(logits, y, train_idx, n_train)
-        elif state["aten"]:   # the three lines of large/main.py:139-141 as the trainer writes them
-            loss = F.nll_loss(F.log_softmax(logits.float(), dim=1)[train_idx], y[train_idx])
-        else:             # the same arithmetic in one pass (sgf_nll_fwd / sgf_nll_bwd)
+        elif state["mode"] == "fused":   # the same arithmetic in one pass (sgf_nll_fwd / sgf_nll_bwd)
             loss = log_softmax_nll(logits, y, train_idx)
+        else:   # the three lines of large/main.py:139-141 as the trainer writes them ('trainer': F.nll_loss is the
+            # launcher's gather form while the step runs, 'aten': ATen's kernels)
+            loss = F.nll_loss(F.log_softmax(logits.float(), dim=1)[train_idx], y[train_idx])
         loss.backward()
         if ctx is not None:
             ctx.sync_grads(model.parameters())
@@ -316,6 +323,8 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
 
     timer = SpmmTimer()
     timer.install()
+    if state["mode"] == "trainer" and ctx is None:
+        _launch.patch_nll_loss()
     try:
         for _ in range(warmup):
             step()
@@ -342,32 +351,29 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
             lt = torch.tensor([loss_val], device=dev, dtype=torch.float64)
             dist.all_reduce(lt)
             loss_val = float(lt)
-        ms_aten = ms_launcher = None
-        if with_aten and world == 1 and not state["aten"]:
-            # transparency: the same step with the trainer's own ATen loss ops
-            state["aten"] = True
-            step()
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(min(steps, 5)):
-                step()
-            fence()
-            ms_aten = (time.perf_counter() - t1) / min(steps, 5) * 1e3
-            # ... and what the UNCHANGED trainer gets under sgformer_amd.launch: its own three loss lines with
-            # nn.NLLLoss served by the gather form (launch.patch_nll_loss)
-            from sgformer_amd import launch as _launch
-            _launch.patch_nll_loss()
-            try:
+        ms_aten = ms_fused = None
+        if with_aten and world == 1:
+            # transparency: the same step with the other two loss forms
+            headline = state["mode"]
+            _launch.unpatch_nll_loss()
+
+            def extra(mode):
+                state["mode"] = mode
                 step()
                 fence()
-                t2 = time.perf_counter()
+                t1 = time.perf_counter()
                 for _ in range(min(steps, 5)):
                     step()
                 fence()
-                ms_launcher = (time.perf_counter() - t2) / min(steps, 5) * 1e3
-            finally:
-                _launch.unpatch_nll_loss()
+                return (time.perf_counter() - t1) / min(steps, 5) * 1e3
+
+            if headline != "aten":
+                ms_aten = extra("aten")
+            if headline != "fused":
+                ms_fused = extra("fused")
+            state["mode"] = headline
     finally:
+        _launch.unpatch_nll_loss()
         timer.uninstall()
     roof = timer.summary()
     if roof is not None and world == 1 and not args.nodes:
@@ -382,7 +388,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                      "all_gather_bytes_per_step": ctx.bytes_all_gathered // max(warmup + steps, 1),
                      "all_reduce_bytes_per_step": ctx.bytes_all_reduced // max(warmup + steps, 1),
                      "repartition_bytes_per_step": ctx.bytes_repartition // max(warmup + steps, 1)}
-    out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_launcher=ms_launcher,
+    out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_fused=ms_fused, loss_mode=state["mode"],
                roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
                peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
     del model, opt, x, y
@@ -440,11 +446,12 @@ def main():
                                    f"training step (fwd + log_softmax/NLL on the training rows + bwd + Adam), "
                                    f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout 0"
                                    + (f"; {n // world:,} nodes per rank, rows generated per rank" if weak else ""),
-                       "loss": "F.log_softmax + F.nll_loss (ATen, as large/main.py:139-141 writes it)" if args.aten_loss
-                               else "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
+                       "loss": {"trainer": "the trainer's own lines (large/main.py:139-141: log_softmax, row indexing, "
+                                           "nn.NLLLoss) as they run under sgformer_amd.launch",
+                                "fused": "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
+                                "aten": "F.log_softmax + F.nll_loss on ATen's kernels"}[r["loss_mode"]],
                        "ms_per_step_with_aten_loss": None if r["ms_aten"] is None else round(r["ms_aten"], 3),
-                       "ms_per_step_with_trainer_loss_lines_under_launcher":
-                           None if r["ms_launcher"] is None else round(r["ms_launcher"], 3),
+                       "ms_per_step_with_fused_loss": None if r["ms_fused"] is None else round(r["ms_fused"], 3),
                        "nodes": n, ("nnz_per_rank" if weak else "nnz"): r["nnz"], "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
                        "graph_view": r["view"],

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 210 /* 0.2.1 */
+#define SGF_VERSION 300 /* 0.3.0: sgf_spmm_tile_*, sgf_neighbor_sample_* */
 
 #define SGF_F32 0
 #define SGF_BF16 1

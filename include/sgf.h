@@ -549,6 +549,7 @@ int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const 
                            const float* beta, const void* res, int64_t ldr, int32_t relu, int64_t n, int32_t d,
                            int32_t dtype, void* out, int64_t ldo, void* stream);
 size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out);
+size_t sgf_gcn_epilogue_dtype_partial_bytes(int64_t n, int32_t d_out, int32_t dtype);   /* fp32 storage: n * d_out * 4 */
 int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t n,
                              int32_t d_in, int32_t d_out, int32_t dtype, void* partial, size_t partial_bytes,
                              void* stream);

@@ -124,6 +124,7 @@ SIGNATURES = {
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
     "sgf_gcn_epilogue_partial_bytes": (c_size_t, [c_int64, c_int32]),
+    "sgf_gcn_epilogue_dtype_partial_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sgf_gcn_epilogue_partial": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, _P,
                                            c_size_t, _P]),
     "sgf_gcn_epilogue_stats_add": (c_int32, [_P, c_int64, _P, c_int64, _P, c_size_t, c_int64, c_int32, c_int32,

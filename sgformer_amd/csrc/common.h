@@ -137,4 +137,11 @@ int hrow_bwd(const void* h, int64_t ldh, const void* g, int64_t ldg, const void*
              int64_t n, int d, const float* M, const float* w, const float* Dm, const float* ds, void* dh, int64_t lddh,
              void* partial, hipStream_t st);
 
+// ---- fp32-storage Linear layers on the exact-fp32 matrix cores (csrc/linear_f32.hip), used by csrc/rowgemm.hip ----
+bool linear_f32_supported(int d_in, int d_out);
+int linear_f32_blocks(int64_t n);
+int linear_f32(const float* a, int64_t lda, int64_t n, int dk, int dj, const float* w, int64_t ldw, int trans_w,
+               const float* bias, const float* addend, int64_t ldadd, const float* shift, float* out, int64_t ldo,
+               float* spart, hipStream_t st);
+
 }  // namespace sgf

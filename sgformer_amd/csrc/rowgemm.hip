@@ -780,6 +780,7 @@ int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
 }
 
 bool supported(int32_t d_in, int32_t d_out, int32_t dtype) {
+  if (dtype == SGF_F32) return linear_f32_supported(d_in, d_out);   // fp32 storage: csrc/linear_f32.hip
   return dtype == SGF_BF16 && d_in == d_out && (d_in == 64 || d_in == 128 || d_in == 256);
 }
 
@@ -787,10 +788,16 @@ int check_common(const char* who, const void* a, int64_t lda, const void* w, int
                  int32_t d_out, int32_t dtype, const void* y, int64_t ldy) {
   SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", who);
   SGF_REQUIRE(supported(d_in, d_out, dtype), SGF_E_UNSUPPORTED,
-              "%s: only bf16 storage with d_in == d_out in {64, 128, 256} (got %d -> %d, dtype %d)", who, d_in, d_out,
-              dtype);
+              "%s: bf16 storage with d_in == d_out in {64, 128, 256}, or fp32 storage with widths %% 4 == 0 up to 256 "
+              "(got %d -> %d, dtype %d)", who, d_in, d_out, dtype);
   if (n == 0) return SGF_OK;
   SGF_REQUIRE(a && w && y, SGF_E_INVALID, "%s: null pointer", who);
+  if (dtype == SGF_F32) {
+    SGF_REQUIRE(lda >= d_in && ldy >= d_out && lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0,
+                SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 4 elements)", who);
+    return SGF_OK;
+  }
   SGF_REQUIRE(lda >= d_in && ldy >= d_out && ldw >= (d_in > d_out ? d_in : d_out), SGF_E_INVALID,
               "%s: leading dimension smaller than the width", who);
   SGF_REQUIRE(lda % 8 == 0 && ldy % 8 == 0 && ldw % 8 == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
@@ -868,7 +875,8 @@ extern "C" int32_t sgf_gcn_epilogue_supported(int32_t d_in, int32_t d_out, int32
 
 extern "C" size_t sgf_gcn_epilogue_workspace_bytes(int64_t n, int32_t d_out) {
   if (n < 0 || d_out <= 0) return 0;
-  return static_cast<size_t>(grid_blocks(n)) * 2 * static_cast<size_t>(d_out) * sizeof(float);
+  const int b = grid_blocks(n) > linear_f32_blocks(n) ? grid_blocks(n) : linear_f32_blocks(n);
+  return static_cast<size_t>(b) * 2 * static_cast<size_t>(d_out) * sizeof(float);
 }
 
 extern "C" int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
@@ -880,6 +888,21 @@ extern "C" int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n == 0) {
     if (stats) SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * static_cast<size_t>(d_out) * sizeof(float), st));
+    return SGF_OK;
+  }
+  if (dtype == SGF_F32) {
+    float* spart = nullptr;
+    if (stats) {
+      SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
+                  "sgf_gcn_epilogue_stats: workspace %zu < %zu", workspace_bytes, sgf_gcn_epilogue_workspace_bytes(n, d_out));
+      spart = static_cast<float*>(workspace);
+    }
+    rc = linear_f32(static_cast<const float*>(a), lda, n, d_in, d_out, static_cast<const float*>(w), ldw, 1, bias, nullptr,
+                    0, shift, static_cast<float*>(y), ldy, spart, st);
+    if (rc != SGF_OK || !stats) return rc;
+    hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, spart, linear_f32_blocks(n),
+                       2 * d_out, stats);
+    SGF_LAUNCH_CHECK();
     return SGF_OK;
   }
   const int blocks = grid_blocks(n);
@@ -903,6 +926,9 @@ extern "C" int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, 
   int rc = check_common("sgf_gcn_epilogue_dx", dy, lddy, w, ldw, n, d_out, d_in, dtype, dx, lddx);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
+  if (dtype == SGF_F32)
+    return linear_f32(static_cast<const float*>(dy), lddy, n, d_out, d_in, static_cast<const float*>(w), ldw, 0, nullptr,
+                      nullptr, 0, nullptr, static_cast<float*>(dx), lddx, nullptr, static_cast<hipStream_t>(stream));
   RowGemmArgs args{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(w), ldw, 1, nullptr, nullptr,
                    nullptr, static_cast<uint16_t*>(dx), lddx, n, nullptr};
   return launch_rowgemm<false, 0>(args, d_in, grid_blocks(n), static_cast<hipStream_t>(stream));
@@ -914,15 +940,24 @@ extern "C" size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out) {
   return static_cast<size_t>((n + 31) / 32) * 32 * static_cast<size_t>(d_out) * 2;
 }
 
+// fp32 storage parks the first operand's product as a plain [n, d_out] fp32 matrix
+extern "C" size_t sgf_gcn_epilogue_dtype_partial_bytes(int64_t n, int32_t d_out, int32_t dtype) {
+  if (dtype == SGF_F32) return n < 0 || d_out <= 0 ? 0 : static_cast<size_t>(n) * static_cast<size_t>(d_out) * 4;
+  return sgf_gcn_epilogue_partial_bytes(n, d_out);
+}
+
 extern "C" int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
                                         int64_t n, int32_t d_in, int32_t d_out, int32_t dtype, void* partial,
                                         size_t partial_bytes, void* stream) {
   int rc = check_common("sgf_gcn_epilogue_partial", a, lda, w, ldw, n, d_in, d_out, dtype, partial, d_out);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
-  SGF_REQUIRE(partial_bytes >= sgf_gcn_epilogue_partial_bytes(n, d_out), SGF_E_WORKSPACE,
+  SGF_REQUIRE(partial_bytes >= sgf_gcn_epilogue_dtype_partial_bytes(n, d_out, dtype), SGF_E_WORKSPACE,
               "sgf_gcn_epilogue_partial: partial buffer %zu < %zu", partial_bytes,
-              sgf_gcn_epilogue_partial_bytes(n, d_out));
+              sgf_gcn_epilogue_dtype_partial_bytes(n, d_out, dtype));
+  if (dtype == SGF_F32)
+    return linear_f32(static_cast<const float*>(a), lda, n, d_in, d_out, static_cast<const float*>(w), ldw, 1, bias, nullptr,
+                      0, nullptr, static_cast<float*>(partial), d_out, nullptr, static_cast<hipStream_t>(stream));
   RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, bias, nullptr,
                    nullptr, nullptr, 0, n, static_cast<uint4*>(partial)};
   return launch_rowgemm<false, 1>(args, d_out, grid_blocks(n), static_cast<hipStream_t>(stream));
@@ -940,8 +975,23 @@ extern "C" int sgf_gcn_epilogue_stats_add(const void* a, int64_t lda, const void
     return SGF_OK;
   }
   SGF_REQUIRE(partial && reinterpret_cast<uintptr_t>(partial) % 16 == 0 &&
-                  partial_bytes >= sgf_gcn_epilogue_partial_bytes(n, d_out),
+                  partial_bytes >= sgf_gcn_epilogue_dtype_partial_bytes(n, d_out, dtype),
               SGF_E_INVALID, "sgf_gcn_epilogue_stats_add: partial buffer missing, misaligned or too small");
+  if (dtype == SGF_F32) {
+    float* spart = nullptr;
+    if (stats) {
+      SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d_out), SGF_E_WORKSPACE,
+                  "sgf_gcn_epilogue_stats_add: workspace too small");
+      spart = static_cast<float*>(workspace);
+    }
+    rc = linear_f32(static_cast<const float*>(a), lda, n, d_in, d_out, static_cast<const float*>(w), ldw, 1, nullptr,
+                    static_cast<const float*>(partial), d_out, shift, static_cast<float*>(y), ldy, spart, st);
+    if (rc != SGF_OK || !stats) return rc;
+    hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d_out + 63) / 64), dim3(256), 0, st, spart, linear_f32_blocks(n),
+                       2 * d_out, stats);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int blocks = grid_blocks(n);
   RowGemmArgs args{static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(w), ldw, 0, nullptr, shift,
                    nullptr, static_cast<uint16_t*>(y), ldy, n,

@@ -625,7 +625,11 @@ class HipKernels:
     # ---- T6 / K8: Linear (+ BatchNorm statistics) as one streaming pass ----
     @staticmethod
     def gcn_epilogue_supported(d_in: int, d_out: int, dtype) -> bool:
-        return dtype == _BF16 and bool(_lib.load().sgf_gcn_epilogue_supported(d_in, d_out, _lib.SGF_BF16))
+        """bf16 storage: square layers of 64 / 128 / 256 (csrc/rowgemm.hip); fp32 storage: any widths % 4 == 0 up to
+        256 (csrc/linear_f32.hip, exact-fp32 matrix cores)."""
+        if dtype not in (_BF16, _F32):
+            return False
+        return bool(_lib.load().sgf_gcn_epilogue_supported(d_in, d_out, _lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32))
 
     @staticmethod
     def gcn_epilogue_stats(a, w, bias, shift=None, want_stats=False):
@@ -648,19 +652,20 @@ class HipKernels:
     def gcn_epilogue_cat(a1, a2, w, bias, shift=None, want_stats=False):
         """y = [a1 | a2] w^T + bias (w [d, 2 d]) in two streaming passes: a1's product stays in the matrix cores'
         accumulator layout (an opaque scratch buffer) and is added, unrounded-sum-wise, in a2's pass."""
-        n, d = a1.shape
+        n, d1 = a1.shape
+        d2, d = a2.shape[1], w.shape[0]
         dev = a1.device
         lib = _lib.load()
-        part = _workspace(dev, "gcn_part", lib.sgf_gcn_epilogue_partial_bytes(n, d))
+        part = _workspace(dev, "gcn_part", lib.sgf_gcn_epilogue_dtype_partial_bytes(n, d, _code(a1)))
         y = torch.empty((n, d), dtype=a1.dtype, device=dev)
         stats = torch.empty(2 * d, dtype=_F32, device=dev) if want_stats else None
         ws = _workspace(dev, "gcn_epi", lib.sgf_gcn_epilogue_workspace_bytes(n, d)) if want_stats else None
-        w1, w2 = w[:, :d], w[:, d:]
+        w1, w2 = w[:, :d1], w[:, d1:]
         with torch.cuda.device(dev):
-            _lib.call("sgf_gcn_epilogue_partial", _ptr(a1), _ld(a1), _ptr(w1), w.stride(0), _ptr(bias), n, d, d,
+            _lib.call("sgf_gcn_epilogue_partial", _ptr(a1), _ld(a1), _ptr(w1), w.stride(0), _ptr(bias), n, d1, d,
                       _code(a1), _ptr(part), part.numel(), _stream(dev))
             _lib.call("sgf_gcn_epilogue_stats_add", _ptr(a2), _ld(a2), _ptr(w2), w.stride(0), _ptr(part),
-                      part.numel(), n, d, d, _code(a2), _ptr(y), _ld(y), _ptr(shift), _ptr(stats), _ptr(ws),
+                      part.numel(), n, d2, d, _code(a2), _ptr(y), _ld(y), _ptr(shift), _ptr(stats), _ptr(ws),
                       0 if ws is None else ws.numel(), _stream(dev))
         return y, stats
 
@@ -1674,9 +1679,8 @@ class _Linear(torch.autograd.Function):
         widths = [x.shape[1] for x in xs]
         if sum(widths) != w.shape[1]:
             raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
-        d_out = wc.shape[0]
-        fused = (len(xs) <= 2 and all(k == d_out for k in widths)
-                 and all(_streaming_linear_ok(x, wc[:, i * d_out:(i + 1) * d_out]) for i, x in enumerate(xs)))
+        offs = [sum(widths[:i]) for i in range(len(widths))]
+        fused = (len(xs) <= 2 and all(_streaming_linear_ok(x, wc[:, o:o + k]) for x, o, k in zip(xs, offs, widths)))
         if fused:
             # streaming passes with W resident in LDS (sgf_gcn_epilogue_*); the BatchNorm that follows gets its
             # column sums from the same pass
@@ -1712,7 +1716,7 @@ class _Linear(torch.autograd.Function):
         for i, k in enumerate(widths):
             if not ctx.needs_input_grad[3 + i]:
                 dxs.append(None)
-            elif k == wc.shape[0] and _streaming_linear_ok(g, wc[:, off:off + k]):
+            elif _streaming_linear_ok(g, wc[:, off:off + k], dx=True):
                 dxs.append(K.gcn_epilogue_dx(_rows16(g), wc[:, off:off + k]))
             else:
                 dxs.append(g @ wc[:, off:off + k])
@@ -1816,9 +1820,11 @@ def _rows16(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _streaming_linear_ok(x: torch.Tensor, wc: torch.Tensor) -> bool:
+def _streaming_linear_ok(x: torch.Tensor, wc: torch.Tensor, dx: bool = False) -> bool:
+    """x wc^T (or, dx=True, x wc) on the streaming kernels: bf16 square layers, fp32 layers of widths % 4 up to 256."""
     return (x.dim() == 2 and x.shape[0] > 0 and wc.stride(-1) == 1 and (wc.stride(0) * wc.element_size()) % 16 == 0
-            and wc.data_ptr() % 16 == 0 and K.gcn_epilogue_supported(wc.shape[1], wc.shape[0], x.dtype))
+            and wc.data_ptr() % 16 == 0 and x.shape[1] == (wc.shape[0] if dx else wc.shape[1])
+            and K.gcn_epilogue_supported(wc.shape[1], wc.shape[0], x.dtype))
 
 
 def _streaming_linear(xr, wc, b32, shift=None, want_stats=False, rows=None):

@@ -239,6 +239,16 @@ int sgf_spmm_blocked(const int64_t* rowptr, const int32_t* ecode, const float* e
  *   inside: [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16], lane = (row % 32) + 32 * ((slot % 16) / 8),
  *   element slot % 8 — the A operand of v_mfma_f32_32x32x16_bf16; duplicate edges are summed in fp32 in
  *   stored order), rem_col / rem_val (stats[5] entries, stored order + padding).
+ * sgf_spmm_tile_pack_layout / sgf_spmm_tile_pack — the fragments in the form the kernel streams them (the kernel is
+ *   bound by fabric traffic, and a 2 KiB fragment costs its 2 KiB whether 5 or 500 of its 512 cells are occupied;
+ *   on a community graph 10-25 % are).  A GROUP = the two fragments (k-steps) one wave multiplies per chunk, numbered
+ *   wave-major: g = tile_ptr[b] / 2 + t * Q_b + q (row tile t, chunk q, Q_b chunks in block b).  grp[2 g + 1] = its
+ *   occupied cells if there are at most sgf_spmm_tile_sparse_len() (sparse), else -1 (dense); grp[2 g] = its offset
+ *   in the pool in 16-byte units.  Sparse: the occupied cells as 8-byte entries {byte offset of the cell's hi element
+ *   in the 4 KiB [k-step][hi, lo][lane][8] image, hi | lo << 16}, in image order, padded with a zero entry to an even
+ *   count; dense: the 4 KiB image.  _layout writes grp and *pool_units (device); the caller allocates
+ *   pool_units * 16 + 4096 bytes (the kernel fetches whole KiB) and calls _pack.  n_frag = tile_ptr[nb].
+ *   The dense fragments are not needed afterwards.
  * sgf_spmm_tile — Y = A X with that plan; block_rows = the max_rows the blocks were made with (<= 128: four
  *   waves per block and two blocks per CU, else eight waves and one).  x: [n_cols, d] bf16, n_cols * ldx * 2 < 2^32; ldx, ldy
  *   multiples of 8, x / y 16-byte aligned.  long_len / long_segments / workspace as for sgf_spmm_split,
@@ -257,9 +267,16 @@ int sgf_spmm_tile_fill(const int64_t* rowptr, const int32_t* ecode, const float*
                        int64_t n, int64_t nnz, const int32_t* blk_row, int64_t nb, const int64_t* tile_ptr,
                        int64_t n_frag, const int64_t* rem_rowptr, void* tiles, int32_t* rem_col, float* rem_val,
                        void* stream);
+int32_t sgf_spmm_tile_sparse_len(void);
+size_t sgf_spmm_tile_pack_workspace_bytes(int64_t n_frag);
+int sgf_spmm_tile_pack_layout(const int32_t* blk_row, int64_t nb, const int64_t* tile_ptr, const void* tiles,
+                              int64_t n_frag, int32_t* grp, int64_t* pool_units, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int sgf_spmm_tile_pack(const int32_t* blk_row, int64_t nb, const int64_t* tile_ptr, const void* tiles, int64_t n_frag,
+                       const int32_t* grp, void* pool, int64_t pool_units, void* stream);
 int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const int32_t* sh_ptr, const int32_t* sh_cols,
-                  const int64_t* tile_ptr, const void* tiles, const int64_t* rem_rowptr, const int32_t* rem_col,
-                  const float* rem_val, const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy,
+                  const int64_t* tile_ptr, const int32_t* grp, const void* pool, const int64_t* rem_rowptr,
+                  const int32_t* rem_col, const float* rem_val, const void* x, int64_t ldx, int64_t n_cols, void* y, int64_t ldy,
                   int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len, int64_t long_segments,
                   void* workspace, size_t workspace_bytes, void* stream);
 

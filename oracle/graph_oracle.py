@@ -225,6 +225,78 @@ def tile_plan(rowptr, colind, val, n, blk_row, cap, min_count, long_len):
     return (sh_ptr.astype(np.int32), sh_cols, tile_ptr, tiles.reshape(-1), rem_rowptr, rem_col, rem_val, stats)
 
 
+TILE_SPARSE_MAX = 384      # csrc/spmm_pack.hip kSparseMax
+
+
+def tile_pack(blk_row, tile_ptr, tiles):
+    """(grp int32 [groups, 2], pool uint8 [units * 16]) — the fragments of tile_plan in the form the kernel streams them
+    (restates csrc/spmm_pack.hip; include/sgf.h, sgf_spmm_tile_pack*).  Group g = tile_ptr[b] / 2 + t * Q_b + q holds the
+    two fragments (k-steps) of (block b, row tile t, chunk q), stored by the plan at tile_ptr[b] + (q * T_b + t) * 2.
+    <= TILE_SPARSE_MAX occupied cells (hi or lo != 0): the cells in image order ([k-step][lane][j]) as entries
+    {uint32 byte offset of the hi element in the 4 KiB [k-step][hi, lo][lane][8] image, uint32 hi | lo << 16}, padded
+    with a zero entry to an even count; otherwise the 4 KiB image, grp[g, 1] = -1.  grp[g, 0] = offset / 16."""
+    blk_row = np.asarray(blk_row, dtype=np.int64)
+    tile_ptr = np.asarray(tile_ptr, dtype=np.int64)
+    t = np.asarray(tiles, dtype=np.uint16).reshape(-1, 2, 64, 8)       # [fragment][hi, lo][lane][j]
+    ng = int(tile_ptr[-1]) // 2
+    grp = np.zeros((max(ng, 1), 2), dtype=np.int32)
+    chunks, units = [], 0
+    for b in range(len(blk_row) - 1):
+        rt = (int(blk_row[b + 1] - blk_row[b]) + 31) // 32
+        base = int(tile_ptr[b])
+        ngb = (int(tile_ptr[b + 1]) - base) // 2
+        nq = ngb // rt if rt else 0
+        for l in range(ngb):
+            w, q = divmod(l, nq)
+            f0 = base + (q * rt + w) * 2
+            img = t[f0:f0 + 2]                                           # [k-step][hi, lo][lane][j]
+            occ = (img[:, 0] | img[:, 1]) != 0                           # [k-step][lane][j]
+            cells = int(occ.sum())
+            g = base // 2 + l
+            grp[g, 0] = units
+            if cells > TILE_SPARSE_MAX:
+                grp[g, 1] = -1
+                chunks.append(np.ascontiguousarray(img).view(np.uint8).reshape(-1))
+                units += 256
+                continue
+            grp[g, 1] = cells
+            s, lane, j = np.nonzero(occ)                                 # image order
+            ent = np.zeros((cells + (cells & 1), 2), dtype=np.uint32)
+            ent[:cells, 0] = s * 2048 + lane * 16 + j * 2
+            ent[:cells, 1] = img[s, 0, lane, j].astype(np.uint32) | (img[s, 1, lane, j].astype(np.uint32) << 16)
+            chunks.append(ent.view(np.uint8).reshape(-1))
+            units += ent.shape[0] // 2
+    pool = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    return grp, pool
+
+
+def tile_unpack(grp, pool, n_frag, blk_row, tile_ptr):
+    """Inverse of tile_pack: the dense fragments (uint16 [n_frag * 1024]) rebuilt the way the kernel does — a cleared
+    4 KiB image + the entries scattered (hi at the offset, lo 1024 bytes behind), or the copied image."""
+    blk_row = np.asarray(blk_row, dtype=np.int64)
+    tile_ptr = np.asarray(tile_ptr, dtype=np.int64)
+    out = np.zeros((n_frag, 2048), dtype=np.uint8)
+    pool = np.asarray(pool, dtype=np.uint8)
+    for b in range(len(blk_row) - 1):
+        rt = (int(blk_row[b + 1] - blk_row[b]) + 31) // 32
+        base = int(tile_ptr[b])
+        ngb = (int(tile_ptr[b + 1]) - base) // 2
+        nq = ngb // rt if rt else 0
+        for l in range(ngb):
+            w, q = divmod(l, nq)
+            f0 = base + (q * rt + w) * 2
+            off, cells = int(np.uint32(grp[base // 2 + l, 0])) * 16, int(grp[base // 2 + l, 1])
+            if cells < 0:
+                out[f0:f0 + 2] = pool[off:off + 4096].reshape(2, 2048)
+                continue
+            img = np.zeros(4096, dtype=np.uint8).view(np.uint16)
+            ent = pool[off:off + cells * 8].view(np.uint32).reshape(-1, 2)
+            img[ent[:, 0] // 2] = (ent[:, 1] & 0xffff).astype(np.uint16)
+            img[ent[:, 0] // 2 + 512] = (ent[:, 1] >> 16).astype(np.uint16)
+            out[f0:f0 + 2] = img.view(np.uint8).reshape(2, 2048)
+    return out.view(np.uint16).reshape(-1)
+
+
 def spmm_tile(blk_row, sh_ptr, sh_cols, tile_ptr, tiles, rem_rowptr, rem_col, rem_val, x):
     """Y = A X evaluated THROUGH the tile plan (fragment cell -> slot -> staged source; remainder CSR), float64."""
     blk_row = np.asarray(blk_row, dtype=np.int64)

@@ -41,24 +41,33 @@ def main():
     ap.add_argument("--params", nargs="*", default=["512,2,128"])
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--order", default="reorder", choices=["reorder", "planted"],
+                    help="planted: the generator's own numbering and community labels (community graph only) — "
+                         "the bound a perfect sgf_reorder would reach")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n = a.n
     gen = {"community": synth.synthetic_graph_community, "uniform": synth.synthetic_graph,
            "powerlaw": getattr(synth, "synthetic_graph_community_powerlaw", None)}[a.graph]
-    ei = gen(n, a.deg, seed=123, device=dev)
-    torch.cuda.synchronize()
     t0 = time.time()
-    perm, inv, comm = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
-    torch.cuda.synchronize()
+    if a.order == "planted":
+        ei, lab = gen(n, a.deg, seed=123, device=dev, shuffle_ids=False, return_labels=True)
+        cs, comm = lab.int().contiguous(), lab
+        g = ops.CSRGraph(ei, n, validate=False)
+    else:
+        ei = gen(n, a.deg, seed=123, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        perm, inv, comm = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
+        torch.cuda.synchronize()
+        cs = comm[perm.long()].contiguous()
+        g = ops.CSRGraph(inv.long()[ei], n, validate=False)
     t_reorder = time.time() - t0
-    cs = comm[perm.long()].contiguous()
-    g = ops.CSRGraph(inv.long()[ei], n, validate=False)
     del ei
     nnz = g.nnz
     x = torch.randn(n, a.d, device=dev).to(torch.bfloat16)
     alg = nnz * 8 + (n + 1) * 8 + 2 * n * a.d * 2
-    out = {"graph": a.graph, "n": n, "nnz": nnz, "d": a.d, "algorithmic_bytes": alg, "reorder_s": round(t_reorder, 3),
+    out = {"graph": a.graph, "n": n, "nnz": nnz, "d": a.d, "order": a.order, "algorithmic_bytes": alg, "reorder_s": round(t_reorder, 3),
            "communities": int(comm.max()) + 1}
     print(json.dumps(out), flush=True)
 
@@ -84,7 +93,7 @@ def main():
         report(f"k_spmm_tile cap={cap} min_count={mc} max_rows={mr}", ms, blocks=plan.nb,
                tile_fraction=round(plan.tile_fraction, 4), tile_density=round(plan.tile_density, 4),
                staged_rows_per_node=round(plan.staged_rows / n, 3), fragments=plan.fragments,
-               tile_bytes=plan.fragments * 2048, rem_entries=plan.rem_entries, long_segments=plan.long_segments,
+               tile_bytes=plan.tile_bytes, dense_tile_bytes=plan.fragments * 2048, rem_entries=plan.rem_entries, long_segments=plan.long_segments,
                plan_s=round(t_plan, 3), rel_diff_vs_stream=rel)
         if a.sweep:
             for dbg in (4, 8, 12):
@@ -102,7 +111,8 @@ def main():
                               (3, "neither (skeleton)"), (16, "gathers clamped to 4096 rows (all L2 hits)"),
                               (17, "no tile phase + gathers clamped (L2 hits)"), (32, "no multiply-adds in the gather loop"),
                               (33, "no tile phase, no multiply-adds"), (49, "no tile phase, L2-hit gathers, no multiply-adds"),
-                              (128, "tile phase without matrix-core work"), (130, "no gathers, tile phase without MFMA")):
+                              (128, "tile phase without matrix-core work"), (130, "no gathers, tile phase without MFMA"),
+                              ):
                 os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg)
                 report(f"  ablation [{what}]", timed(lambda: ops.K.spmm_tile(plan, x, n)))
             os.environ.pop("SGF_SPMM_TILE_DEBUG")

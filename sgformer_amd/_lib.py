@@ -52,8 +52,12 @@ SIGNATURES = {
     "sgf_spmm_tile_plan": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_int32, c_int32, c_int64, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_spmm_tile_fill": (c_int32, [_P, _P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
-    "sgf_spmm_tile": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
-                                c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
+    "sgf_spmm_tile_sparse_len": (c_int32, []),
+    "sgf_spmm_tile_pack_workspace_bytes": (c_size_t, [c_int64]),
+    "sgf_spmm_tile_pack_layout": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "sgf_spmm_tile_pack": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
+    "sgf_spmm_tile": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64,
+                                c_int64, c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
     "sgf_neighbor_sample_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_neighbor_sample_mark": (c_int32, [_P, _P, c_int64, c_int32, _P]),
     "sgf_neighbor_sample_hop": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_uint64, c_uint64, c_int32, _P, c_int32,

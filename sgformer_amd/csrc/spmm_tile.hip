@@ -46,26 +46,27 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2));
 }
 
-// the value lane (l ^ 32) holds: one v_permlane32_swap instead of an LDS round trip (ds_bpermute)
-__device__ __forceinline__ float other_half(float v) {
+// lane l and lane l ^ 32 added (lower half first): one v_permlane32_swap instead of an LDS round trip (ds_bpermute)
+__device__ __forceinline__ float sum_halves(float v) {
   const uint32_t u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);   // r[0] = {lo, lo}, r[1] = {hi, hi}
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = {lo, lo}, r[1] = {hi, hi}
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 constexpr int kChunk = 32;                    // staged sources per ring slot
 constexpr int kRingPairs = 8;                 // epilogue: 1 KiB gather slots per wave (two rows of X each)
-constexpr int kStashPad = 64;                 // register-set epilogue: positions of padding behind an epoch (>= 8 kRingPairs)
+constexpr int kStashPad = 96;                 // positions of padding behind an epoch (>= 10 kRingPairs: see the gather loop)
 constexpr uint32_t kOobOffset = 0xfffffc00u;  // a gather offset beyond any x (x_bytes < 2^32 - 2048): the load returns zeros
-constexpr int kStash = 256;                   // epilogue: {source, value} pairs parked in LDS per epoch
+constexpr int kStash = 224;                   // epilogue: {source, value} pairs parked in LDS per epoch
 constexpr int kMaxStaged = 1024;
 
 struct TilePlanArgs {
   const int32_t* blk_row;        // [nb + 1]
   const int32_t* sh_ptr;         // [nb + 1], multiples of 32
   const int32_t* sh_cols;        // staged source ids
-  const int64_t* tile_ptr;       // [nb + 1], in 2 KiB fragments
-  const uint4* tiles;            // fragments: [chunk][row tile][k-step] x {hi 64 x 16 B, lo 64 x 16 B}
+  const int64_t* tile_ptr;       // [nb + 1], in 2 KiB fragments (two per group)
+  const int32_t* grp;            // packed tiles (spmm_pack.hip): per group {pool offset in 16-byte units, cells or -1}
+  const uint4* pool;
   const int64_t* rem_rowptr;     // [n + 1]
   const int32_t* rem_col;
   const float* rem_val;
@@ -73,23 +74,31 @@ struct TilePlanArgs {
 
 // NCT column tiles of 32 features: d = 32 * NCT
 // NW waves per block (one 32-row tile each): 4 (blocks of <= 128 rows, two blocks per CU) or 8 (<= 256 rows, one)
-template <int NCT, bool DMA, int SETS, int kConsume, int NW>
+template <int NCT, int NW, bool kDebug>
 __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     TilePlanArgs P, const uint16_t* __restrict__ x, uint32_t pitch, uint32_t x_bytes, uint16_t* __restrict__ y,
-    int64_t ldy, int32_t nb, int32_t chunk_blocks, LongQueue lq, int dbg) {
+    int64_t ldy, int32_t nb, int32_t chunk_blocks, LongQueue lq, int dbg_arg) {
+  const int dbg = kDebug ? dbg_arg : 0;                  // timing experiments (SGF_SPMM_TILE_DEBUG) compile away otherwise
   constexpr int D = 32 * NCT;
   constexpr int kRowBytes = D * 2;                       // one staged row
   constexpr int kSlotBytes = kChunk * kRowBytes;         // one ring slot (16 KiB at d = 256)
-  constexpr bool kRegRing = SETS == 0;                   // epilogue variant: gathers consumed straight from registers
-  constexpr int kPatchRows = kRegRing ? 16 : 8;          // rows of fp32 partial sums parked per wave
+  constexpr int kPatchRows = 16;                         // rows of fp32 partial sums parked per wave
   constexpr int kPatchBytes = kPatchRows * D * 4;
-  constexpr int kRingBytesW = kRegRing ? 0 : kRingPairs * 1024;   // per wave: the LDS gather ring (not for the register ring)
-  constexpr int kStashW = kStash + (kRegRing ? kStashPad : 0);
-  constexpr int kRingBytes = 2 * kSlotBytes;
-  // [ K-loop ring, later the 4 patches ][ 4 gather rings ][ 4 stashes ]: only the patches alias the K-loop ring, so the
-  // stash can be filled while the tile phase runs
-  constexpr int kBase = NW * kPatchBytes > kRingBytes ? NW * kPatchBytes : kRingBytes;
-  constexpr int kDataBytes = kBase + NW * (kRingBytesW + kStashW * 8);
+  constexpr int kStashW = kStash + kStashPad;
+  // (three ring slots and X chunks staged two iterations ahead measured the same as two slots and one: the tile phase
+  // is bound by the fabric's bandwidth, not by its latency)
+  constexpr int kSlots = 2;
+  constexpr int kRingBytes = kSlots * kSlotBytes;
+  constexpr int kFragBytes = 4096;                       // a wave's A fragments of one chunk: 2 k-steps x {hi, lo} x 1 KiB
+  // [ K-loop ring | the waves' A fragments | their packed entries, later the NW patches ][ NW stashes ]: only the patches
+  // alias the K-loop buffers, so the first stash is filled before the tile phase runs.  The packed entries of chunk 0 land
+  // in ring slot 1 (free until chunk 1 is staged) when the buffers leave no room for a second entry area.
+  constexpr int kRawBase = kRingBytes + NW * kFragBytes;
+  constexpr bool kRaw0InRing = NW * kFragBytes <= kSlotBytes;
+  constexpr int kLoopBytes = kRawBase + NW * kFragBytes * (kRaw0InRing ? 1 : 2);
+  constexpr int kRaw0Base = kRaw0InRing ? kSlotBytes : kRawBase + NW * kFragBytes;
+  constexpr int kBase = NW * kPatchBytes > kLoopBytes ? NW * kPatchBytes : kLoopBytes;
+  constexpr int kDataBytes = kBase + NW * (kStashW * 8);
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kDataBytes];
   __shared__ int32_t cols_lds[kMaxStaged];
 
@@ -102,11 +111,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   const int s0 = P.sh_ptr[b];
   const int S = P.sh_ptr[b + 1] - s0;
   const int NQ = S / kChunk;
-  const uint4* __restrict__ tb = P.tiles + P.tile_ptr[b] * 128;
+  const int64_t g0 = (P.tile_ptr[b] >> 1) + static_cast<int64_t>(wid) * NQ;   // this wave's first group
   const bool mine = wid < RT;                            // this wave owns rows [row0 + 32 wid, ...)
 
-  for (int i = threadIdx.x; i < S; i += NW * 64) cols_lds[i] = P.sh_cols[s0 + i];
-  __syncthreads();
 
   // ---- staging: chunk q -> ring slot ------------------------------------------------------------------------------
   // Image of a chunk (32 sources x D features): 512-byte UNITS [k-step s][read r][column tile t], each the four
@@ -146,34 +153,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     }
   };
 
-  // the same image through registers (DMA == false): 16-byte-per-lane loads, written to LDS one chunk later
-  constexpr int kStageRegs = kPiecesPerWave;
-  typedef uint32_t sreg_t __attribute__((ext_vector_type(4 * kStageRegs)));   // a VALUE: never an alloca
-  sreg_t sreg;
-  auto stage_load = [&](int q, sreg_t& sr) {
-    const int32_t src = cols_lds[q * kChunk + src_slot];
-    const unsigned char* g = reinterpret_cast<const unsigned char*>(x) + static_cast<size_t>(src) * pitch + col_byte;
-#pragma unroll
-    for (int i = 0; i < kStageRegs; ++i) {
-      const uint4 t = *reinterpret_cast<const uint4*>(g + i * 128);
-      sr[4 * i] = t.x; sr[4 * i + 1] = t.y; sr[4 * i + 2] = t.z; sr[4 * i + 3] = t.w;
-    }
-  };
-  auto stage_write = [&](int slot, const sreg_t& sr) {
-    unsigned char* dst = smem + slot * kSlotBytes + unit0_w * 512 + lane * 16;
-#pragma unroll
-    for (int i = 0; i < kStageRegs; ++i)
-      *reinterpret_cast<uint4*>(dst + i * 1024) = make_uint4(sr[4 * i], sr[4 * i + 1], sr[4 * i + 2], sr[4 * i + 3]);
-  };
-
   // ---- this wave's share of the gather stream: requested now, needed after the tile phase ---------------------------
   const int nr = mine ? (nrows - 32 * wid < 32 ? nrows - 32 * wid : 32) : 1;
   const int64_t r_base = mine ? static_cast<int64_t>(row0) + 32 * wid : static_cast<int64_t>(row0);
-  float* patch = reinterpret_cast<float*>(smem + wid * kPatchBytes);                // 8 rows x D fp32
-  unsigned char* ring = smem + kBase + wid * kRingBytesW;                          // kRingPairs x 1 KiB
-  int32_t* stash_col = reinterpret_cast<int32_t*>(smem + kBase + NW * kRingBytesW + wid * (kStashW * 8));
-  float* stash_val = reinterpret_cast<float*>(stash_col + kStashW);
-  uint32_t* stash_off = reinterpret_cast<uint32_t*>(stash_col);    // register-set epilogue: byte offsets instead of ids
+  float* patch = reinterpret_cast<float*>(smem + wid * kPatchBytes);                // 16 rows x D fp32
+  uint32_t* stash_off = reinterpret_cast<uint32_t*>(smem + kBase + wid * (kStashW * 8));   // byte offsets of source rows
+  float* stash_val = reinterpret_cast<float*>(stash_off + kStashW);
   const int half = lane >> 5;
   const bool hi = lane >= 32;
   const int fc = (lane & 31) * 8;
@@ -186,6 +171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   };
   const int64_t e_first = P.rem_rowptr[r_base];
   const int64_t end_abs = P.rem_rowptr[r_base + 1 + (lane < nr ? lane : nr - 1)];
+  // (the row pointers above are requested before the staged list: one round trip for both)
+  for (int i = threadIdx.x; i < S; i += NW * 64) cols_lds[i] = P.sh_cols[s0 + i];
+  __syncthreads();
   const int64_t begin_abs = __shfl_up(end_abs, 1, 64);
   const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);
   const bool long_i = lane < nr && len_i > lq.long_len;
@@ -193,18 +181,43 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   const int32_t* __restrict__ ci = P.rem_col + e_first;
   const float* __restrict__ va = P.rem_val + e_first;
   const bool slow_path = __ballot(long_i) != 0 || total64 >= (static_cast<int64_t>(1) << 31);
-  const int total = (dbg & 2) ? 0 : static_cast<int>(total64);
-  auto fill_stash = [&](int base) {
-    const int ne = total - base < kStash ? total - base : kStash;
+  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
+
+  // The first kStash stream positions of a half (16 rows): {byte offset of the source row, value}, followed by kStashPad
+  // positions of {out-of-range offset, 0} — the unrolled steps of the gather loop read up to 3 batches past the end without
+  // a bound test (such a gather returns zeros without touching memory: buffer range check).  Loaded into registers
+  // (coalesced) and parked in LDS later, so that the loads' latency is hidden: half 0 behind the first X chunk, half 1
+  // behind the rounding + store pass of half 0.
+  constexpr int kStashRegs = (kStash + kStashPad) / 64;
+  struct StashRegs {
+    int32_t col[kStashRegs];
+    float val[kStashRegs];
+  };
+  auto stash_load = [&](const int32_t* __restrict__ cih, const float* __restrict__ vah, int ne, StashRegs& sr) {
+    // range-checked loads (positions >= ne return 0 without touching memory): unconditional, so all of them are in
+    // flight before the first is used
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(cih), 0, ne * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vah), 0, ne * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < kStash / 64; ++i) {
-      const int idx = 64 * i + lane;
-      if (idx < ne) {
-        stash_col[idx] = ci[base + idx];
-        stash_val[idx] = va[base + idx];
-      }
+    for (int i = 0; i < kStashRegs; ++i) {
+      sr.col[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, (64 * i + lane) * 4, 0, 0);
+      sr.val[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, (64 * i + lane) * 4, 0, 0));
     }
   };
+  auto stash_park = [&](const StashRegs& sr, int ne) {
+    __builtin_amdgcn_sched_barrier(0);                     // the first use of the loads stays behind what was issued since
+#pragma unroll
+    for (int i = 0; i < kStashRegs; ++i) {
+      int32_t c = sr.col[i];
+      if (dbg & 16) c &= 4095;                             // timing experiment: every gather an L2 hit
+      stash_off[64 * i + lane] = 64 * i + lane < ne ? static_cast<uint32_t>(c) * pitch : kOobOffset;
+      stash_val[64 * i + lane] = sr.val[i];
+    }
+  };
+  auto half_rows = [&](int h) { return nr - 16 * h < 16 ? nr - 16 * h : 16; };
+  // stream positions [start, stop) of half h
+  auto half_start = [&](int h) { return h == 0 ? 0 : __builtin_amdgcn_readlane(rel_v, 15); };
+  auto half_stop = [&](int h) { return __builtin_amdgcn_readlane(rel_v, 16 * h + half_rows(h) - 1); };
 
   f32x16 acc[NCT];
 #pragma unroll
@@ -212,36 +225,103 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // A fragments of chunk q for this wave's row tile: k-steps 0, 1 x {hi, lo}
-  auto load_a = [&](int q, uint4 (&a)[4]) {
-    const u32x4* f = reinterpret_cast<const u32x4*>(tb + (static_cast<int64_t>(q) * RT + wid) * 256 + lane);
-    if (dbg & 4) {                                       // A/B: the fragments are read once — streaming (nt) loads
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(f + 64 * i));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(uint4, f[64 * i]);
+  // A fragments of chunk q for this wave's row tile (k-steps 0, 1 x {hi, lo}) live in the wave's own 4 KiB of LDS and are
+  // read from there (lane l: 16 bytes at l * 16 of every 1 KiB fragment half).  A dense group is copied there by LDS-DMA;
+  // a sparse one arrives as 8-byte entries {offset in the area, hi | lo << 16} in the wave's entry area, ONE chunk
+  // earlier, and is scattered over the cleared area (spmm_pack.hip).  Nothing in the loop is loaded into registers from
+  // global memory: hipcc's wait counts do not see the DMA, so its wait for a register load would be a wait for every
+  // DMA requested before it — the only waits are the explicit ones at the top of the chunk loop.
+  const uint32_t frag_lds = smem_lds + static_cast<uint32_t>(kRingBytes + wid * kFragBytes);
+  const uint32_t raw_lds = smem_lds + static_cast<uint32_t>(kRawBase + wid * kFragBytes);
+  const uint32_t raw0_lds = smem_lds + static_cast<uint32_t>(kRaw0Base + wid * kFragBytes);
+  unsigned char* frag = smem + kRingBytes + wid * kFragBytes;
+  // lane q: {pool offset, cells} of this wave's group of chunk q (NQ <= 32)
+  int32_t grp_off = 0, grp_cnt = 0;
+  if (mine && lane < NQ && !(dbg & 1)) {
+    const int2 gv = *reinterpret_cast<const int2*>(P.grp + 2 * (g0 + lane));
+    grp_off = gv.x;
+    grp_cnt = gv.y;
+  }
+  auto group_cells = [&](int q) { return __builtin_amdgcn_readlane(grp_cnt, q); };
+  // n_ops x 1 KiB from the pool into LDS at `dst`
+  auto dma_pool = [&](int q, uint32_t dst, int n_ops) {
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(
+        P.pool + static_cast<uint32_t>(__builtin_amdgcn_readlane(grp_off, q)) + lane);
+    for (int i = 0; i < n_ops; ++i) {
+      const uint32_t d = dst + static_cast<uint32_t>(i * 1024);
+      const unsigned char* gp = g + i * 1024;
+      uint32_t keep;
+      asm volatile(                                        // (LDS reads of what is being replaced have completed)
+          "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gp), "s"(d)
+          : "memory");
     }
+  };
+  // entries of a sparse group of chunk q -> the entry area at `dst`; dense groups are copied when their chunk is next
+  auto fetch_entries = [&](int q, uint32_t dst) {
+    const int c = group_cells(q);
+    if (c > 0) dma_pool(q, dst, (c * 8 + 1023) >> 10);
+  };
+  // the fragment area becomes the fragments of chunk q: entries at `raw` (sparse) or a 4 KiB copy (dense)
+  auto build_a = [&](int q, const unsigned char* raw) {
+    const int c = group_cells(q);
+    if (c < 0) {
+      dma_pool(q, frag_lds, 4);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(frag + i * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int r = 0; r < c; r += 64) {
+      const uint2 e = *reinterpret_cast<const uint2*>(raw + (r + lane) * 8);
+      if (r + lane < c) {
+        *reinterpret_cast<uint16_t*>(frag + e.x) = static_cast<uint16_t>(e.y & 0xffffu);
+        *reinterpret_cast<uint16_t*>(frag + e.x + 1024) = static_cast<uint16_t>(e.y >> 16);
+      }
+    }
+  };
+  auto read_a = [&](uint4 (&a)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(frag + i * 1024 + lane * 16);
   };
   // B fragment address of this lane inside a unit: the 16-lane groups read one [4 keys][16 columns] subtile each
   const uint32_t b_lane = static_cast<uint32_t>(lane * 8);
 
   const bool tiles_on = NQ > 0 && !(dbg & 1);
-  uint4 a_cur[4], a_nxt[4];
-  if (tiles_on) {                                        // chunk 0: requested together with the stash below
-    if (DMA) stage(0, 0); else stage_load(0, sreg);
-    if (mine) load_a(0, a_cur);
+  const bool fast = mine && !slow_path;
+  {
+    // requested together: [stash of half 0] [A of chunk 0: entries or fragments] [entries of chunk 1] [X chunk 0]
+    StashRegs sr;
+    const int tot0 = (fast && !(dbg & 2)) ? half_stop(0) : 0;
+    const int ne0 = tot0 < kStash ? tot0 : kStash;
+    if (fast) stash_load(ci, va, ne0, sr);
+    if (tiles_on) {
+      if (mine) {
+        if (group_cells(0) < 0) build_a(0, nullptr);
+        else fetch_entries(0, raw0_lds);
+        if (NQ > 1) fetch_entries(1, raw_lds);
+      }
+      stage(0, 0);
+    }
+    if (fast) stash_park(sr, ne0);
   }
-  if (!kRegRing && mine && !slow_path && total > 0) fill_stash(0);
   if (tiles_on) {
-    if (!DMA) stage_write(0, sreg);
     for (int q = 0; q < NQ; ++q) {
-      if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's pieces of chunk q have landed
-      __syncthreads();                                   // chunk q is complete and every
-                                                         // wave is done with the slot chunk q + 1 goes into
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): everything this wave requested has landed
+      __syncthreads();                                   // chunk q is complete and every wave is done with chunk q - 1
+      uint4 a_cur[4];
+      if (mine) {
+        if (q == 0 && group_cells(0) >= 0) build_a(0, smem + kRaw0Base + wid * kFragBytes);
+        read_a(a_cur);
+      }
+      if (q == 0 && kRaw0InRing && NQ > 1) __syncthreads();   // slot 1 held the entries of chunk 0 until here
       if (q + 1 < NQ) {
-        if (DMA) stage(q + 1, (q + 1) & 1); else stage_load(q + 1, sreg);
-        if (mine) load_a(q + 1, a_nxt);
+        if (mine) {
+          build_a(q + 1, smem + kRawBase + wid * kFragBytes);
+          if (q + 2 < NQ) fetch_entries(q + 2, raw_lds);
+        }
+        stage(q + 1, (q + 1) & 1);
       }
       if (mine) {
         const unsigned char* slot = smem + (q & 1) * kSlotBytes + b_lane;
@@ -262,10 +342,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb, acc[t], 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
       }
-      if (!DMA && q + 1 < NQ) stage_write((q + 1) & 1, sreg);
     }
   }
   __syncthreads();                                       // the ring is dead: its memory becomes the waves' patches
@@ -276,12 +353,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   // padded to an even count by the plan, so a pair of stream positions never straddles two rows).  Rows of X are fetched
   // two per instruction (lanes 0-31: the row of position 2 k, lanes 32-63: of 2 k + 1; 16 bytes per lane) in batches of
   // kRingPairs loads; TWO batches are in flight per wave (with 128 accumulator registers there are only 8 waves per CU
-  // to cover the gathers' latency, so it has to be covered by loads in flight per wave).  A landed batch is parked in a
-  // per-wave LDS ring and its registers re-issued at once; the consumer is then a compact loop over the ring with ONE
-  // row-finish site (an unrolled register ring needs one per pair: 390 KiB of code in the first version of this kernel).
-  // {source, value} of up to kStash stream positions are parked in LDS first (coalesced loads, requested before the tile
-  // phase); longer streams take several such epochs.
-  // the tile's partial sums of rows kPatchRows q ..: accumulator register i holds row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  // to cover the gathers' latency, so it has to be covered by loads in flight per wave).
+  // the tile's partial sums of rows 16 q ..: accumulator register i holds row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
   auto refill_q = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int kRegs = kPatchRows / 2;                // accumulator registers per column tile and group
@@ -290,12 +363,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
 #pragma unroll
       for (int i = kRegs * q; i < kRegs * q + kRegs; ++i)
         patch[(((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) & (kPatchRows - 1)) * D + 32 * t + (lane & 31)] = acc[t][i];
-  };
-  auto refill = [&](int q) {
-    if (q == 0) refill_q(std::integral_constant<int, 0>{});
-    else if (q == 1) refill_q(std::integral_constant<int, 1>{});
-    else if (kPatchRows == 8 && q == 2) refill_q(std::integral_constant<int, (kPatchRows == 8 ? 2 : 0)>{});
-    else if (kPatchRows == 8) refill_q(std::integral_constant<int, (kPatchRows == 8 ? 3 : 0)>{});
   };
 
   float racc[8];
@@ -312,35 +379,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     racc[7] = fmaf(v, __uint_as_float(r.w & 0xffff0000u), racc[7]);
   };
   uint16_t* __restrict__ yl = y + r_base * ldy + (active ? fc : 0);
-  // row finished: (even + odd stream positions) + the tile's partial sum, one rounding; lanes 0-31 write 8 bf16 each
-  auto flush_row = [&](int local_row) {
-    const float* pr = patch + (local_row & (kPatchRows - 1)) * D + (active ? fc : 0);
-    const float4 p0 = *reinterpret_cast<const float4*>(pr);
-    const float4 p1 = *reinterpret_cast<const float4*>(pr + 4);
-    float t[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = racc[k] + other_half(racc[k]);
-    t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w;
-    t[4] += p1.x; t[5] += p1.y; t[6] += p1.z; t[7] += p1.w;
-    if (active && !hi) {
-      uint4 o;                                           // v_cvt_pk_bf16_f32: round to nearest even, like f32_to_bf16
-      o.x = pack_bf16(t[0], t[1]);
-      o.y = pack_bf16(t[2], t[3]);
-      o.z = pack_bf16(t[4], t[5]);
-      o.w = pack_bf16(t[6], t[7]);
-      if (dbg & 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(yl + local_row * ldy));
-      else *reinterpret_cast<uint4*>(yl + local_row * ldy) = o;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) racc[k] = 0.f;
-  };
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
 
-  if (!kRegRing || slow_path) refill(0);
   if (slow_path) {
     // rare: a hub row among these 32 (its tile part is empty by construction: the plan leaves long rows alone)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+    refill_q(std::integral_constant<int, 0>{});
     for (int r = 0; r < nr; ++r) {
-      if (r > 0 && (r & (kPatchRows - 1)) == 0) refill(r / kPatchRows);
+      if (r == 16) refill_q(std::integral_constant<int, 1>{});
       const int64_t re = lane64(end_abs, r);
       const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
       if (re - rb > lq.long_len) {
@@ -352,198 +397,160 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
         const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(voff), 0, 0);
         if (!hi) fma8(P.rem_val[e], raw);
       }
-      flush_row(r);
+      // row finished: gathered part + the tile's partial sum, one rounding; lanes 0-31 write 8 bf16 each
+      if (active && !hi) {
+        const float* pr = patch + (r & (kPatchRows - 1)) * D + fc;
+        const float4 p0 = *reinterpret_cast<const float4*>(pr);
+        const float4 p1 = *reinterpret_cast<const float4*>(pr + 4);
+        uint4 o;                                           // v_cvt_pk_bf16_f32: round to nearest even, like f32_to_bf16
+        o.x = pack_bf16(racc[0] + p0.x, racc[1] + p0.y);
+        o.y = pack_bf16(racc[2] + p0.z, racc[3] + p0.w);
+        o.z = pack_bf16(racc[4] + p1.x, racc[5] + p1.y);
+        o.w = pack_bf16(racc[6] + p1.z, racc[7] + p1.w);
+        *reinterpret_cast<uint4*>(yl + r * ldy) = o;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) racc[k] = 0.f;
     }
     return;
   }
 
-  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
-  int row = 0;
-  int row_end = (dbg & 2) ? 0 : __builtin_amdgcn_readlane(rel_v, 0);
-  // rows that end at stream position p (rows without gathered entries included)
-  auto boundary = [&](int p) {
-    while (p == row_end && row < nr) {
-      flush_row(row);
-      ++row;
-      if (row < nr) {
-        if ((row & (kPatchRows - 1)) == 0) refill(row / kPatchRows);
-        row_end = (dbg & 2) ? 0 : __builtin_amdgcn_readlane(rel_v, row);
+  // ---- gathers consumed straight from registers -----------------------------------------------------------------------
+  // Two register sets of B pair loads each: while set A is consumed, set B is in flight, and A is re-issued as soon as
+  // its last pair is consumed.  Steps are unrolled, registers and LDS offsets static: per pair one ds_read_b32 of the
+  // source offset (for the re-issue), one of the value, the multiply-adds, and a wave-uniform compare for a row end.
+  // A row end COMMITS the row — (even + odd positions) added into the row's slot of the patch, which already holds the
+  // tile's partial sum: ~35 instructions, no vector-memory operation, so the unrolled steps stay small (the first
+  // version inlined rounding, the store and the patch refill at every step: 100-390 KiB of code).  Rounding to bf16 and
+  // the stores are a compact pass over the patch afterwards, 16 rows at a time: two halves per wave.
+  constexpr int B = kRingPairs;
+  auto run_half = [&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    const int nrh = half_rows(h);
+    const int start = half_start(h);                       // stream positions of this half
+    const int tot = (dbg & 2) ? 0 : half_stop(h) - start;
+    const int32_t* __restrict__ cih = ci + start;
+    const float* __restrict__ vah = va + start;
+    int row = 16 * h;                                      // first row of the half; rows without entries are skipped
+    int row_end = __builtin_amdgcn_readlane(rel_v, row) - start;
+    auto commit = [&](int pos) {                           // the row that ends at `pos` (relative to the half)
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = sum_halves(racc[k]);
+      if (active && !hi) {
+        float* pr = patch + (row & 15) * D + fc;
+        float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+        p0.x += t[0]; p0.y += t[1]; p0.z += t[2]; p0.w += t[3];
+        p1.x += t[4]; p1.y += t[5]; p1.z += t[6]; p1.w += t[7];
+        *reinterpret_cast<float4*>(pr) = p0;
+        *reinterpret_cast<float4*>(pr + 4) = p1;
       }
-    }
-  };
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
-  if constexpr (kRegRing) {
-    // ---- gathers consumed straight from registers ---------------------------------------------------------------------
-    // Two register sets of B pair loads each: while set A is consumed, set B is in flight, and A is re-issued as soon as
-    // its last pair is consumed.  Steps are unrolled, registers and LDS offsets static: per pair one ds_read_b32 of the
-    // source (for the re-issue), one of the value, the multiply-adds, and a wave-uniform compare for a row end.
-    // A row end COMMITS the row — (even + odd positions) added into the row's slot of the patch, which already holds the
-    // tile's partial sum: ~35 instructions, no vector-memory operation, so the unrolled steps stay small (the first
-    // version inlined rounding, the store and the patch refill at every step: 100-390 KiB of code).  Rounding to bf16 and
-    // the stores are a compact pass over the patch afterwards, 16 rows at a time: two halves per wave.
-    constexpr int B = kRingPairs;
-    auto run_half = [&](auto hc) {
-      constexpr int h = decltype(hc)::value;
-      const int nrh = nr - 16 * h < 16 ? nr - 16 * h : 16;
-      refill_q(hc);
-      const int start = h == 0 ? 0 : __builtin_amdgcn_readlane(rel_v, 15);     // stream positions of this half
-      const int stop = __builtin_amdgcn_readlane(rel_v, 16 * h + nrh - 1);
-      const int tot = (dbg & 2) ? 0 : stop - start;
-      const int32_t* __restrict__ cih = ci + start;
-      const float* __restrict__ vah = va + start;
-      int row = 16 * h;                                    // first row of the half; rows without entries are skipped
-      int row_end = __builtin_amdgcn_readlane(rel_v, row) - start;
-      auto commit = [&](int pos) {                         // the row that ends at `pos` (relative to the half)
-        float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = racc[k] + other_half(racc[k]);
-        if (active && !hi) {
-          float* pr = patch + (row & 15) * D + fc;
-          float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
-          p0.x += t[0]; p0.y += t[1]; p0.z += t[2]; p0.w += t[3];
-          p1.x += t[4]; p1.y += t[5]; p1.z += t[6]; p1.w += t[7];
-          *reinterpret_cast<float4*>(pr) = p0;
-          *reinterpret_cast<float4*>(pr + 4) = p1;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) racc[k] = 0.f;
-        do {
-          ++row;
-          row_end = row < 16 * h + nrh ? __builtin_amdgcn_readlane(rel_v, row) - start : 0x7fffffff;
-        } while (row_end == pos);
-      };
-      while (row_end == 0) {                               // leading rows without entries
+      for (int k = 0; k < 8; ++k) racc[k] = 0.f;
+      do {
         ++row;
         row_end = row < 16 * h + nrh ? __builtin_amdgcn_readlane(rel_v, row) - start : 0x7fffffff;
-      }
-      for (int base = 0; base < tot; base += kStash) {
-        const int ne = tot - base < kStash ? tot - base : kStash;     // stream positions of this epoch (even)
-        const int np = ne >> 1;
-        // the epoch's {byte offset of the source row, value}, followed by kStashPad positions of {out-of-range offset, 0}:
-        // the unrolled steps below read up to 4 B pairs past the epoch's end without a bound test (such a gather
-        // returns zeros without touching memory: buffer range check)
-#pragma unroll
-        for (int i = 0; i < (kStash + kStashPad) / 64; ++i) {
-          const int idx = 64 * i + lane;
-          const bool ok = idx < ne;
-          stash_off[idx] = ok ? static_cast<uint32_t>(cih[base + idx]) * pitch : kOobOffset;
-          stash_val[idx] = ok ? vah[base + idx] : 0.f;
-        }
-        // pairs b0 .. b0 + B - 1 of the epoch: per pair one LDS read, one add, one load
-        auto issue = [&](int b0, u32x4 (&rg)[B]) {
-          const uint32_t* so = stash_off + 2 * b0 + half;
-#pragma unroll
-          for (int j = 0; j < B; ++j)
-            rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
-        };
-        // distance (in stream positions) from the end of pair b0's first position to the current row's end
-        // (a row end beyond this epoch must not be matched by the padding positions)
-        auto rel_end = [&]() -> int { return row_end - base <= ne ? row_end - base : 0x3fffffff; };
-        int to_end = rel_end();
-        auto consume = [&](int b0, const u32x4 (&rg)[B]) {
-          const float* sv = stash_val + 2 * b0 + half;
-          float vv[B];
-#pragma unroll
-          for (int j = 0; j < B; ++j) vv[j] = sv[2 * j];
-          int d0 = to_end - 2 * b0;
-#pragma unroll
-          for (int j = 0; j < B; ++j) {
-            fma8(vv[j], rg[j]);
-            if (d0 == 2 * j + 2) {                           // wave-uniform: this pair closes its row
-              commit(row_end);
-              to_end = rel_end();
-              d0 = to_end - 2 * b0;
-            }
-          }
-        };
-        // set A crosses the loop's back edge in flight, set B is issued and consumed inside one iteration: the queue
-        // hipcc's wait-count pass sees at the loop header is the same on entry and on the back edge (B loads of set A,
-        // oldest first) — with both sets crossing the back edge it ordered the header wait as vmcnt(0)
-        u32x4 ra[B], rb[B];
-        issue(0, ra);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int b0 = 0; b0 < np; b0 += 2 * B) {
-          issue(b0 + B, rb);
-          __builtin_amdgcn_sched_barrier(0);
-          consume(b0, ra);
-          __builtin_amdgcn_sched_barrier(0);
-          issue(b0 + 2 * B, ra);
-          __builtin_amdgcn_sched_barrier(0);
-          consume(b0 + B, rb);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // rounding + store of the half's rows (a row without gathered entries holds the tile's partial sum as it is)
-      for (int lr = 0; lr < nrh; ++lr) {
-        if (active && !hi) {
-          const float* pr = patch + lr * D + fc;
-          const float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
-          uint4 o;
-          o.x = pack_bf16(p0.x, p0.y);
-          o.y = pack_bf16(p0.z, p0.w);
-          o.z = pack_bf16(p1.x, p1.y);
-          o.w = pack_bf16(p1.z, p1.w);
-          *reinterpret_cast<uint4*>(yl + (16 * h + lr) * ldy) = o;
-        }
-      }
+      } while (row_end == pos);
     };
-    run_half(std::integral_constant<int, 0>{});
-    if (nr > 16) run_half(std::integral_constant<int, 1>{});
-    return;
-  }
-  u32x4 rga[kRingPairs], rgb[kRingPairs];              // two batches of pair loads in flight
-  for (int base = 0; base < total; base += kStash) {
-    const int ne = total - base < kStash ? total - base : kStash;     // stream positions of this epoch (even)
-    const int np = ne >> 1;
-    if (base > 0) fill_stash(base);                  // (epoch 0 was parked before the tile phase)
-    // pairs b8 .. b8 + 7 (clamped to the epoch's last pair: a valid address, its value is never used)
-    auto issue_batch = [&](int b8, u32x4 (&rg)[kRingPairs]) {
-#pragma unroll
-      for (int j = 0; j < kRingPairs; ++j) {
-        const int kk = b8 + j < np ? b8 + j : np - 1;
-        uint32_t c = static_cast<uint32_t>(stash_col[2 * kk + half]);
-        if (dbg & 16) c &= 4095u;                        // timing experiment: every gather hits in L2
-        rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(lanebase + c * pitch), 0, 0);
-      }
-    };
-    // a landed batch goes through the LDS ring so that the consumer is a compact loop (one row-finish site per batch
-    // set instead of one per pair); its registers are re-issued before the batch is consumed
-    auto drain_batch = [&](int b8, u32x4 (&rg)[kRingPairs]) {
-#pragma unroll
-      for (int j = 0; j < kRingPairs; ++j) *reinterpret_cast<u32x4*>(ring + j * 1024 + lane * 16) = rg[j];
-      if (b8 + SETS * kRingPairs < np) issue_batch(b8 + SETS * kRingPairs, rg);
-      // kConsume pairs per step: their LDS reads are issued together (one LDS latency per step, not per pair); pairs past the
-      // epoch's end read valid LDS and are skipped
-      const int nj = np - b8 < kRingPairs ? np - b8 : kRingPairs;
-      for (int j = 0; j < nj; j += kConsume) {
-        u32x4 raw[kConsume];
-        float vv[kConsume];
-#pragma unroll
-        for (int u = 0; u < kConsume; ++u) {
-          raw[u] = *reinterpret_cast<const u32x4*>(ring + (j + u) * 1024 + lane * 16);
-          const int kk = b8 + j + u < np ? b8 + j + u : np - 1;
-          vv[u] = stash_val[2 * kk + half];
-        }
-#pragma unroll
-        for (int u = 0; u < kConsume; ++u) {
-          if (j + u < nj) {
-            const int pos = base + 2 * (b8 + j + u);
-            if (pos == row_end) boundary(pos);
-            if (!(dbg & 32)) fma8(vv[u], raw[u]);
-            else racc[0] += __uint_as_float(raw[u].x & 1u);   // timing experiment: no multiply-adds
-          }
-        }
-      }
-    };
-    issue_batch(0, rga);
-    if (SETS == 2 && kRingPairs < np) issue_batch(kRingPairs, rgb);
-    for (int b8 = 0; b8 < np; b8 += SETS * kRingPairs) {
-      drain_batch(b8, rga);
-      if (SETS == 2 && b8 + kRingPairs < np) drain_batch(b8 + kRingPairs, rgb);
+    while (row_end == 0) {                                 // leading rows without entries
+      ++row;
+      row_end = row < 16 * h + nrh ? __builtin_amdgcn_readlane(rel_v, row) - start : 0x7fffffff;
     }
-  }
-  // closes the last row with entries and every trailing row without
-  if (dbg & 2) { row_end = 0; boundary(0); } else boundary(total);
+    // pairs b0 .. b0 + B - 1 of the epoch: per pair one LDS read, one add, one load
+    auto issue = [&](int b0, u32x4 (&rg)[B]) {
+      const uint32_t* so = stash_off + 2 * b0 + half;
+#pragma unroll
+      for (int j = 0; j < B; ++j)
+        rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
+    };
+    // THREE register sets of B pair loads: the fabric answers a gather in ~1.3 us under load while a set is consumed in
+    // ~0.45 us, so with two sets (16 KiB in flight per wave, 8 waves per CU) the loop ran at the memory latency:
+    // ~2 sets per (latency + one consumption).  The third set is what the register file has left at two waves per SIMD.
+    u32x4 ra[B], rb[B], rc[B];
+    // epoch 0 is parked already: its first batches are requested before the patch is written (64 LDS stores per lane)
+    if (tot > 0) {
+      issue(0, ra);
+      issue(B, rb);
+    }
+    refill_q(hc);
+    for (int base = 0; base < tot; base += kStash) {
+      const int ne = tot - base < kStash ? tot - base : kStash;     // stream positions of this epoch (even)
+      const int np = ne >> 1;
+      if (base > 0) {                                      // (rare: more than kStash positions in 16 rows)
+        StashRegs sr;
+        stash_load(cih + base, vah + base, ne, sr);
+        stash_park(sr, ne);
+        issue(0, ra);
+        issue(B, rb);
+      }
+      // distance (in stream positions) from the end of pair b0's first position to the current row's end
+      // (a row end beyond this epoch must not be matched by the padding positions)
+      auto rel_end = [&]() -> int { return row_end - base <= ne ? row_end - base : 0x3fffffff; };
+      int to_end = rel_end();
+      auto consume = [&](int b0, const u32x4 (&rg)[B]) {
+        const float* sv = stash_val + 2 * b0 + half;
+        float vv[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) vv[j] = sv[2 * j];
+        int d0 = to_end - 2 * b0;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+          if (!(dbg & 32)) fma8(vv[j], rg[j]);  // (dbg & 32: timing experiment without the multiply-adds)
+          if (d0 == 2 * j + 2) {                           // wave-uniform: this pair closes its row
+            commit(row_end);
+            to_end = rel_end();
+            d0 = to_end - 2 * b0;
+          }
+        }
+      };
+      // Sets A and B cross the loop's back edge in flight, A the older one — the same queue as on entry, so hipcc's
+      // wait-count pass keeps exact counts at the loop header (a queue that differs between entry and back edge makes
+      // it wait for everything there).  The steps read up to 5 B pairs past the epoch's end: kStashPad.
+      __builtin_amdgcn_sched_barrier(0);
+      for (int b0 = 0; b0 < np; b0 += 3 * B) {
+        issue(b0 + 2 * B, rc);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(b0, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(b0 + 3 * B, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(b0 + B, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(b0 + 4 * B, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(b0 + 2 * B, rc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the next half's first epoch: requested now, parked after the stores below
+    StashRegs nx;
+    const bool more = h == 0 && nr > 16;
+    int ne1 = 0;
+    if (more) {
+      const int s1 = half_start(1);
+      const int t1 = (dbg & 2) ? 0 : half_stop(1) - s1;
+      ne1 = t1 < kStash ? t1 : kStash;
+      stash_load(ci + s1, va + s1, ne1, nx);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // rounding + store of the half's rows (a row without gathered entries holds the tile's partial sum as it is)
+    for (int lr = 0; lr < nrh; ++lr) {
+      if (active && !hi) {
+        const float* pr = patch + lr * D + fc;
+        const float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+        uint4 o;
+        o.x = pack_bf16(p0.x, p0.y);
+        o.y = pack_bf16(p0.z, p0.w);
+        o.z = pack_bf16(p1.x, p1.y);
+        o.w = pack_bf16(p1.z, p1.w);
+        if (dbg & 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(yl + (16 * h + lr) * ldy));
+        else *reinterpret_cast<uint4*>(yl + (16 * h + lr) * ldy) = o;
+      }
+    }
+    if (more) stash_park(nx, ne1);
+  };
+  run_half(std::integral_constant<int, 0>{});
+  if (nr > 16) run_half(std::integral_constant<int, 1>{});
 }
 
 }  // namespace
@@ -556,7 +563,7 @@ extern "C" int sgf_spmm_tile_supported(int32_t d, int32_t dtype) {
 }
 
 extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const int32_t* sh_ptr, const int32_t* sh_cols,
-                             const int64_t* tile_ptr, const void* tiles, const int64_t* rem_rowptr,
+                             const int64_t* tile_ptr, const int32_t* grp, const void* pool, const int64_t* rem_rowptr,
                              const int32_t* rem_col, const float* rem_val, const void* x, int64_t ldx, int64_t n_cols,
                              void* y, int64_t ldy, int64_t n_rows, int32_t d, int32_t dtype, int64_t long_len,
                              int64_t long_segments, void* workspace, size_t workspace_bytes, void* stream) {
@@ -566,7 +573,9 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   SGF_REQUIRE(block_rows >= 1 && block_rows <= 256, SGF_E_INVALID, "%s: block_rows outside [1, 256]", fn);
   SGF_REQUIRE(sgf_spmm_tile_supported(d, dtype), SGF_E_UNSUPPORTED, "%s: bf16 storage with d = 128 or 256 only (d=%d dtype=%d)",
               fn, d, dtype);
-  SGF_REQUIRE(blk_row && sh_ptr && sh_cols && tile_ptr && rem_rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(blk_row && sh_ptr && sh_cols && tile_ptr && grp && pool && rem_rowptr && x && y, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(reinterpret_cast<uintptr_t>(pool) % 16 == 0 && reinterpret_cast<uintptr_t>(grp) % 8 == 0, SGF_E_INVALID,
+              "%s: pool / grp alignment", fn);
   SGF_REQUIRE(nb < (static_cast<int64_t>(1) << 31), SGF_E_UNSUPPORTED, "%s: too many blocks", fn);
   SGF_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(y) % 16 == 0,
@@ -589,7 +598,7 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
     partial = reinterpret_cast<float*>(ws + 256 + align_up(static_cast<size_t>(long_segments) * sizeof(LongEntry), 256));
     SGF_CHECK_HIP(hipMemsetAsync(lq.count, 0, sizeof(int32_t), st));
   }
-  TilePlanArgs P{blk_row, sh_ptr, sh_cols, tile_ptr, static_cast<const uint4*>(tiles), rem_rowptr, rem_col, rem_val};
+  TilePlanArgs P{blk_row, sh_ptr, sh_cols, tile_ptr, grp, static_cast<const uint4*>(pool), rem_rowptr, rem_col, rem_val};
   // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers,
   // 4 / 8 = nt fragment loads / y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
   // loop, 128 = no matrix-core work in the tile phase
@@ -599,32 +608,18 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   if (const char* e = getenv("SGF_SPMM_TILE_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
   const uint16_t* xs = static_cast<const uint16_t*>(x);
   uint16_t* ys = static_cast<uint16_t*>(y);
-  // X staging through LDS-DMA (default; 2.27 vs 2.31 ms with register staging on one box) — "0": through registers (A/B)
-  const char* dma_env = getenv("SGF_SPMM_TILE_DMA");
-  const bool dma = !(dma_env && dma_env[0] == '0');
-  // epilogue variant (A/B): 0 = register ring (default), 1 / 2 = one / two batches of gathers parked in an LDS ring
-  const char* sets_env = getenv("SGF_SPMM_TILE_SETS");
-  const int sets = sets_env ? atoi(sets_env) : 0;
-#define SGF_TILE_LAUNCH(NCT_, DMA_, SETS_, CONS_, NW_)                                                                 \
-  hipLaunchKernelGGL((k_spmm_tile_bf16<NCT_, DMA_, SETS_, CONS_, NW_>), dim3(static_cast<unsigned>(nb)), dim3(NW_ * 64), 0, \
-                     st, P, xs, static_cast<uint32_t>(ldx * 2), static_cast<uint32_t>(x_bytes), ys, ldy,                \
-                     static_cast<int32_t>(nb), chunk, lq, dbg)
-#define SGF_TILE_LAUNCH2(NCT_, DMA_)                                                      \
-  do {                                                                                    \
-    if (block_rows > 128) {                                                               \
-      if (sets == 1) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 8);                                \
-      else if (sets == 2) SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 8);                           \
-      else SGF_TILE_LAUNCH(NCT_, DMA_, 0, 2, 8);                                          \
-    } else {                                                                              \
-      if (sets == 1) SGF_TILE_LAUNCH(NCT_, DMA_, 1, 4, 4);                                \
-      else if (sets == 2) SGF_TILE_LAUNCH(NCT_, DMA_, 2, 2, 4);                           \
-      else SGF_TILE_LAUNCH(NCT_, DMA_, 0, 2, 4);                                          \
-    }                                                                                     \
+#define SGF_TILE_LAUNCH(NCT_, NW_, DBG_)                                                                               \
+  hipLaunchKernelGGL((k_spmm_tile_bf16<NCT_, NW_, DBG_>), dim3(static_cast<unsigned>(nb)), dim3(NW_ * 64), 0, st, P, xs, \
+                     static_cast<uint32_t>(ldx * 2), static_cast<uint32_t>(x_bytes), ys, ldy, static_cast<int32_t>(nb), \
+                     chunk, lq, dbg)
+#define SGF_TILE_LAUNCH2(NCT_, NW_)                                               \
+  do {                                                                            \
+    if (dbg) SGF_TILE_LAUNCH(NCT_, NW_, true); else SGF_TILE_LAUNCH(NCT_, NW_, false); \
   } while (0)
   if (d == 256) {
-    if (dma) SGF_TILE_LAUNCH2(8, true); else SGF_TILE_LAUNCH2(8, false);
+    if (block_rows > 128) SGF_TILE_LAUNCH2(8, 8); else SGF_TILE_LAUNCH2(8, 4);
   } else {
-    if (dma) SGF_TILE_LAUNCH2(4, true); else SGF_TILE_LAUNCH2(4, false);
+    if (block_rows > 128) SGF_TILE_LAUNCH2(4, 8); else SGF_TILE_LAUNCH2(4, 4);
   }
 #undef SGF_TILE_LAUNCH2
 #undef SGF_TILE_LAUNCH

@@ -285,6 +285,24 @@ class HipKernels:
         return sh_ptr, sh_cols[: max(st[1], 1)].clone(), tile_ptr, tiles, rem_rowptr, rem_col, rem_val, st
 
     @staticmethod
+    def tile_pack(blk_row: torch.Tensor, tile_ptr: torch.Tensor, tiles: torch.Tensor, n_frag: int):
+        """(grp int32 [n_frag / 2, 2], pool uint8): the fragments as the kernel streams them — sparse groups as 8-byte
+        entries, dense ones as they are (csrc/spmm_pack.hip, include/sgf.h)."""
+        dev, nb = tiles.device, int(blk_row.numel()) - 1
+        ng = n_frag // 2
+        grp = torch.zeros((max(ng, 1), 2), dtype=torch.int32, device=dev)
+        units = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(_lib.load().sgf_spmm_tile_pack_workspace_bytes(n_frag), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_spmm_tile_pack_layout", _ptr(blk_row), nb, _ptr(tile_ptr), _ptr(tiles), n_frag, _ptr(grp),
+                      _ptr(units), _ptr(ws), ws.numel(), _stream(dev))
+            nu = int(units.item())                                      # one host sync, once per plan
+            pool = torch.zeros(nu * 16 + 4096, dtype=torch.uint8, device=dev)   # the kernel fetches whole KiB
+            _lib.call("sgf_spmm_tile_pack", _ptr(blk_row), nb, _ptr(tile_ptr), _ptr(tiles), n_frag, _ptr(grp), _ptr(pool),
+                      nu, _stream(dev))
+        return grp, pool, nu
+
+    @staticmethod
     def spmm_tile(plan, x: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _rows16(x)
         d = x.shape[1]
@@ -297,7 +315,7 @@ class HipKernels:
             if segs > 0:
                 ws = _workspace(x.device, "spmm_long", _lib.load().sgf_spmm_split_workspace_bytes(segs, d))
             _lib.call("sgf_spmm_tile", _ptr(plan.blk_row), plan.nb, plan.block_rows, _ptr(plan.sh_ptr), _ptr(plan.sh_cols),
-                      _ptr(plan.tile_ptr), _ptr(plan.tiles), _ptr(plan.rem_rowptr), _ptr(plan.rem_col),
+                      _ptr(plan.tile_ptr), _ptr(plan.grp), _ptr(plan.pool), _ptr(plan.rem_rowptr), _ptr(plan.rem_col),
                       _ptr(plan.rem_val), _ptr(x), x.stride(0), x.shape[0], _ptr(y), y.stride(0), n_rows, d, _code(x),
                       LONG_ROW, segs, _ptr(ws), 0 if ws is None else ws.numel(), _stream(x.device))
         return y
@@ -940,9 +958,10 @@ def _tile_params():
 
 class TilePlan:
     """Plan of sgf_spmm_tile for one CSR: row blocks, the sources each block stages, the dense tiles as matrix-core
-    fragments (hi + lo bf16) and the CSR of the entries left on the gather path."""
+    fragments (hi + lo bf16; packed: sparse groups as entries, see K.tile_pack) and the CSR of the entries left on the
+    gather path.  keep_dense=True keeps the unpacked fragments as .tiles (tests)."""
 
-    def __init__(self, rowptr, colind, val, n: int, blk_row: torch.Tensor, cap=None, min_count=None):
+    def __init__(self, rowptr, colind, val, n: int, blk_row: torch.Tensor, cap=None, min_count=None, keep_dense=False):
         c, m, _ = _tile_params()
         self.blk_row, self.nb = blk_row, int(blk_row.numel()) - 1
         self.block_rows = int((blk_row[1:] - blk_row[:-1]).max()) if self.nb > 0 else 1
@@ -954,7 +973,11 @@ class TilePlan:
         # stored entries per tile cell: below ~2 % a tile column moves more bytes than the gathers it replaces
         self.tile_density = self.tile_entries / max(self.fragments * 512, 1)
         self.long_segments = long_row_segments(self.rem_rowptr, None)
-        self.bytes = (self.tiles.numel() * 4 + self.rem_col.numel() * 8 + self.rem_rowptr.numel() * 8
+        self.grp, self.pool, units = K.tile_pack(blk_row, self.tile_ptr, self.tiles, self.fragments)
+        self.tile_bytes = units * 16                       # what a launch reads of them (dense: fragments * 2048)
+        if not keep_dense:
+            self.tiles = None
+        self.bytes = (self.pool.numel() + self.grp.numel() * 4 + self.rem_col.numel() * 8 + self.rem_rowptr.numel() * 8
                       + self.sh_cols.numel() * 4)
 
 

@@ -91,7 +91,7 @@ def synthetic_graph_local(n: int, avg_deg: float, locality: float = 0.9, window:
 
 def synthetic_graph_community(n: int, avg_deg: float, seed: int = 123, comm_size=(64, 256), comms_per_super: int = 64,
                               p_comm: float = 0.80, p_super: float = 0.15, shuffle_ids: bool = True,
-                              device="cpu") -> torch.Tensor:
+                              device="cpu", return_labels: bool = False) -> torch.Tensor:
     """Same sizes and prologue as `synthetic_graph`, but with the two-level community structure of a
     co-purchase / social graph, and — `shuffle_ids` — with node ids that carry NO trace of it:
 
@@ -127,16 +127,21 @@ def synthetic_graph_community(n: int, avg_deg: float, seed: int = 123, comm_size
     d3 = (r * n).long().clamp_(max=n - 1)
     dst = torch.where(u < p_comm, d1, torch.where(u < p_comm + p_super, d2, d3))
     del u, r, c, sc, d1, d2, d3
+    labels = comm
     if shuffle_ids:
         perm = torch.randperm(n, generator=g)
         src, dst = perm[src], perm[dst]
+        labels = torch.empty_like(comm)
+        labels[perm] = comm
     src, dst = src.to(device), dst.to(device)
     src, dst = torch.cat([src, dst]), torch.cat([dst, src])
     keep = src != dst
     key = torch.unique(src[keep] * n + dst[keep])
     del src, dst, keep
     loops = torch.arange(n, device=device)
-    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+    ei = torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+    # return_labels: the planted community of every node (probes only: what a perfect sgf_reorder would recover)
+    return (ei, labels.to(device)) if return_labels else ei
 
 
 def synthetic_graph_community_powerlaw(n: int, avg_deg: float, seed: int = 123, size_range=(16, 4096), alpha: float = 1.5,

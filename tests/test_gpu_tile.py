@@ -131,7 +131,7 @@ def test_spmm_tile_follows_the_plan(cuda):
     g, n, cs, _ = _reordered("community", cuda)
     blk = G.tile_blocks(cs, n, 128)
     g.blk_row = torch.from_numpy(blk).to(cuda)
-    plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=512, min_count=2)
+    plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=512, min_count=2, keep_dense=True)
     gen = torch.Generator().manual_seed(3)
     xs = torch.randn(n, 128, generator=gen).to(torch.bfloat16)
     y = ops.K.spmm_tile(plan, xs.to(cuda), n)
@@ -141,6 +141,30 @@ def test_spmm_tile_follows_the_plan(cuda):
                       xs.double().numpy())
     assert _rel(y.float(), torch.from_numpy(ref)) <= 3e-3
     assert _rel(y.float(), torch.from_numpy(ref).to(torch.bfloat16).float()) <= 1e-3
+
+
+@pytest.mark.parametrize("name,max_rows,cap,min_count", [("community", 128, 512, 2), ("community", 64, 128, 3),
+                                                          ("hub_dups_isolated", 128, 512, 2), ("uniform", 128, 256, 2),
+                                                          ("community", 256, 512, 2)])
+def test_tile_pack_matches_oracle(cuda, name, max_rows, cap, min_count):
+    """The packed form of the fragments (sgf_spmm_tile_pack*: sparse groups as 8-byte entries, dense ones copied; what the
+    kernel streams) against the numpy restatement, bit for bit, and unpacked again = the plan's dense fragments."""
+    from sgformer_amd import ops
+    g, n, cs, _ = _reordered(name, cuda)
+    blk = G.tile_blocks(cs, n, max_rows)
+    g.blk_row = torch.from_numpy(blk).to(cuda)
+    plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=cap, min_count=min_count, keep_dense=True)
+    tiles = plan.tiles.cpu().numpy().view(np.uint16)[: plan.fragments * 1024]
+    tile_ptr = plan.tile_ptr.cpu().numpy()
+    grp, pool = G.tile_pack(blk, tile_ptr, tiles)
+    ng = plan.fragments // 2
+    assert np.array_equal(plan.grp.cpu().numpy()[:ng], grp[:ng])
+    assert plan.tile_bytes == pool.size and np.array_equal(plan.pool.cpu().numpy()[: pool.size], pool)
+    assert np.array_equal(G.tile_unpack(grp, pool, plan.fragments, blk, tile_ptr), tiles)
+    if name == "community":
+        assert (grp[:ng, 1] >= 0).any() and plan.tile_bytes < plan.fragments * 2048     # packing pays on this graph
+        from sgformer_amd import _lib
+        assert _lib.load().sgf_spmm_tile_sparse_len() == G.TILE_SPARSE_MAX
 
 
 def test_spmm_tile_exact_on_small_integers(cuda):

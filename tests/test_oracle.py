@@ -220,3 +220,37 @@ def test_csr_oracle_edge_cases():
     assert val[2] == np.float32(np.sqrt(np.float32(1) / np.float32(4))) * np.float32(1.0)
     t_rowptr, t_colind, t_val, sym = O.csr_transpose(ei, 5)
     assert not sym and t_rowptr.tolist() == [0, 2, 2, 4, 5, 5]
+
+
+def test_tile_pack_oracle_round_trip():
+    """oracle/graph_oracle.py tile_pack / tile_unpack (the packed A tiles of csrc/spmm_pack.hip): unpack(pack(tiles)) is
+    the plan's dense fragments bit for bit, sparse and dense groups both occur, entries are in image order, and the
+    product evaluated through the unpacked tiles is the fp64 SpMM of the CSR (large/ours.py:34)."""
+    from oracle import graph_oracle as G
+    n = 3000
+    ei = O.synthetic_graph(n, 10.0, seed=5).numpy()
+    # two planted communities with dense blocks: one beyond the sparse limit, one below it
+    rng = np.random.default_rng(0)
+    a = np.stack(np.nonzero(rng.random((40, 40)) < 0.9)) + 0
+    bq = np.stack(np.nonzero(rng.random((100, 100)) < 0.2)) + 64
+    ei = np.concatenate([ei, a, a[::-1], bq, bq[::-1]], axis=1)
+    rowptr, colind, val, _ = O.csr_build(ei, n)
+    blk = G.tile_blocks(None, n, 128)
+    sh_ptr, sh_cols, tile_ptr, tiles, rem_rowptr, rem_col, rem_val, st = G.tile_plan(rowptr, colind, val, n, blk, 256, 2, 1 << 40)
+    nfrag = int(tile_ptr[-1])
+    grp, pool = G.tile_pack(blk, tile_ptr, tiles)
+    ng = nfrag // 2
+    assert (grp[:ng, 1] == -1).any() and (grp[:ng, 1] >= 0).any() and (grp[:ng, 1] <= G.TILE_SPARSE_MAX).all()
+    sizes = np.where(grp[:ng, 1] < 0, 256, (grp[:ng, 1] + 1) // 2)
+    assert np.array_equal(grp[:ng, 0], np.concatenate([[0], np.cumsum(sizes)[:-1]])) and pool.size == sizes.sum() * 16
+    g = int(np.nonzero(grp[:ng, 1] > 1)[0][0])
+    ent = pool[grp[g, 0] * 16: grp[g, 0] * 16 + grp[g, 1] * 8].view(np.uint32).reshape(-1, 2)
+    order = (ent[:, 0] // 2048) * 2048 + ent[:, 0] % 1024                # k-step, then lane / element
+    assert (np.diff(order.astype(np.int64)) > 0).all() and ((ent[:, 0] % 2048) < 1024).all()
+    back = G.tile_unpack(grp, pool, nfrag, blk, tile_ptr)
+    assert np.array_equal(back, np.asarray(tiles, dtype=np.uint16))
+    x = rng.standard_normal((n, 8))
+    y = G.spmm_tile(blk, sh_ptr, sh_cols, tile_ptr, back, rem_rowptr, rem_col, rem_val, x)
+    ref = np.zeros_like(x)
+    np.add.at(ref, np.repeat(np.arange(n), np.diff(rowptr)), val.astype(np.float64)[:, None] * x[colind])
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()

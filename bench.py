@@ -57,7 +57,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 # counters cannot be collected from inside this process, so the figures live in a tracked file written
 # from those passes, keyed on graph kind / dtype / kernel.
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_spmm_pmc.json")
-SPMM_SOURCES = ("spmm.hip", "spmm_tile.hip", "spmm_plan.hip", "spmm_shared.h")
+SPMM_SOURCES = ("spmm.hip", "spmm_tile.hip", "spmm_pack.hip", "spmm_plan.hip", "spmm_shared.h")
 
 
 def spmm_source_sha16() -> str:

@@ -1,10 +1,11 @@
 #!/bin/bash
-# One GPU-box run that regenerates the round's profile artefacts under gpurun_out/r2_profiles/ :
+# One GPU-box run that regenerates the round's profile artefacts under gpurun_out/<round>_profiles/ :
+#   (ROUND=r3 by default: gpurun_out/r3_profiles)
 #   kernel-trace statistics of bench.py on both graphs, PMC passes of the SpMM kernels on both graphs,
 #   an MFMA / SQ counter pass over one bench run.  Copy the summaries into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r2_profiles
+O=gpurun_out/${ROUND:-r3}_profiles
 cd $R && mkdir -p $O
 for g in uniform community; do
   timeout 500 rocprofv3 --kernel-trace --stats -d $O/bench_$g -o b --output-format csv -- \

@@ -18,7 +18,7 @@ g = ops.CSRGraph(inv.long()[ei], n, validate=False)
 del ei
 x = torch.randn(n, d, device=dev).to(torch.bfloat16)
 g.blk_row = ops.K.tile_blocks(comm[perm.long()].contiguous(), n, 128, dev)
-plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=512, min_count=3)
+plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=512, min_count=int(os.environ.get("MIN_COUNT", "2")))
 for _ in range(int(os.environ.get("REPS", "3"))):
     ops.K.spmm_tile(plan, x, n)
 torch.cuda.synchronize()

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--params", nargs="*", default=["512,2,128"])
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--fixed-blocks", action="store_true", help="blocks of exactly max_rows rows (no community alignment)")
     ap.add_argument("--order", default="reorder", choices=["reorder", "planted"],
                     help="planted: the generator's own numbering and community labels (community graph only) — "
                          "the bound a perfect sgf_reorder would reach")
@@ -83,7 +84,7 @@ def main():
         cap, mc, mr = (int(t) for t in prm.split(","))
         torch.cuda.synchronize()
         t0 = time.time()
-        g.blk_row = ops.K.tile_blocks(cs, n, mr, dev)
+        g.blk_row = ops.K.tile_blocks(None if a.fixed_blocks else cs, n, mr, dev)
         plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, cap=cap, min_count=mc)
         torch.cuda.synchronize()
         t_plan = time.time() - t0

@@ -67,7 +67,7 @@ def reorder(edge_index, n, iters1=6, iters2=6):
     return perm.astype(np.int32), inv.astype(np.int32), cid.astype(np.int32)
 
 
-def _plan_core(rowptr, colind, val, n, blk_of_row, nb, lds_rows, long_len, min_count=2):
+def _plan_core(rowptr, colind, val, n, blk_of_row, nb, lds_rows, long_len, min_count=2, slots_by_id=False):
     """Shared by spmm_plan and tile_plan: per block the `lds_rows` most-referenced sources with at least `min_count`
     references (most-referenced first, ties to the smaller id) get slots; entries towards them get the code
     0x80000000 | slot and move to the front of their row (stable).  Returns ecode, eval, nlds, nsh, cols (list of
@@ -94,6 +94,16 @@ def _plan_core(rowptr, colind, val, n, blk_of_row, nb, lds_rows, long_len, min_c
     ok = (rank < lds_rows) & (cclip[order] >= min_count)
     slot_of_unique = np.full(uk.size, -1, dtype=np.int64)
     slot_of_unique[order[ok]] = rank[ok]
+    if slots_by_id:
+        # tile plans: the SELECTION is by count, the slots are dealt in ascending source id (uniques are sorted by
+        # (block, source)): sibling blocks of one community then stage the same sources in the same order
+        sel = slot_of_unique >= 0
+        pos = np.cumsum(sel) - sel
+        first_u = np.searchsorted(ub, np.arange(nb), side="left")
+        first = np.append(pos, pos[-1] + sel[-1] if pos.size else 0)[np.minimum(first_u, uk.size)]
+        slot_of_unique = np.where(sel, pos - first[ub], -1)
+        rank_s = slot_of_unique[order]
+        rank = np.where(ok, rank_s, rank)
     nsh = np.bincount(ub_s[ok], minlength=nb).astype(np.int64)
     slots = slot_of_unique[inverse]
     hit = slots >= 0
@@ -181,7 +191,7 @@ def tile_plan(rowptr, colind, val, n, blk_row, cap, min_count, long_len):
     nnz = int(np.asarray(colind).size)
     row_block = np.repeat(np.arange(nb, dtype=np.int64), np.diff(blk_row))
     ecode, ev, nlds, nsh, (sb, sr, ss), nflag, nuniq = _plan_core(rowptr, colind, val, n, row_block, nb, cap, long_len,
-                                                                 min_count)
+                                                                 min_count, slots_by_id=True)
     nshp = (nsh + 31) // 32 * 32
     sh_ptr = np.zeros(nb + 1, dtype=np.int64)
     sh_ptr[1:] = np.cumsum(nshp)

@@ -123,6 +123,46 @@ __global__ void k_slots(const uint64_t* __restrict__ keys2, const uint32_t* __re
   }
 }
 
+// Tile plans only: the selected sources of a block take their slots in ASCENDING ID order instead of by count.  The two
+// or three blocks a community is cut into stage nearly the same sources, start within a microsecond of each other on the
+// same XCD and then request them in the same order: the second block's staging hits L2.  (Which sources are selected — the
+// `cap` most-referenced — does not change.)  Uniques are numbered in (block, source) order, so the new slot of unique u is
+// the number of selected uniques of its block before it.
+__global__ void k_reslot_mark(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ jidx, int64_t m, unsigned B,
+                              const int32_t* __restrict__ slot_of_unique, uint32_t* __restrict__ blk_of_unique,
+                              uint32_t* __restrict__ sel) {
+  int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; p < m; p += stride) {
+    const uint64_t k = keys2[p];
+    if (k == ~static_cast<uint64_t>(0)) continue;
+    const uint32_t u = jidx[p];
+    blk_of_unique[u] = static_cast<uint32_t>(k >> (B + kCountBits));
+    sel[u] = slot_of_unique[u] >= 0 ? 1u : 0u;
+  }
+}
+
+__global__ void k_reslot_first(const uint32_t* __restrict__ blk_of_unique, const uint32_t* __restrict__ pos,
+                               const uint32_t* __restrict__ n_unique, uint32_t* __restrict__ first) {
+  const int64_t nu = *n_unique;                          // (the unique of the long rows carries block 0xffffffff: skipped)
+  int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; u < nu; u += stride) {
+    const uint32_t b = blk_of_unique[u];
+    if (b != 0xffffffffu && (u == 0 || blk_of_unique[u - 1] != b)) first[b] = pos[u];
+  }
+}
+
+__global__ void k_reslot_apply(const uint32_t* __restrict__ blk_of_unique, const uint32_t* __restrict__ pos,
+                               const uint32_t* __restrict__ sel, const uint32_t* __restrict__ first,
+                               const uint32_t* __restrict__ n_unique, int32_t* __restrict__ slot_of_unique) {
+  const int64_t nu = *n_unique;
+  int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (; u < nu; u += stride)
+    if (sel[u]) slot_of_unique[u] = static_cast<int32_t>(pos[u] - first[blk_of_unique[u]]);
+}
+
 __global__ void k_sh_cols(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ jidx, int64_t m,
                           unsigned B, const int32_t* __restrict__ slot_of_unique,
                           const int32_t* __restrict__ sh_ptr, int32_t* __restrict__ sh_cols) {
@@ -478,6 +518,19 @@ int plan_core(const int64_t* rowptr, const int32_t* colind, const float* val, in
   SGF_LAUNCH_CHECK();
   const int32_t* counts = nsh;
   if (tiles) {
+    // slots in ascending source order (see k_reslot_*); scratch: idx_a (free since the sort), flag / fscan (cleared again
+    // in step 3), head (free since k_slots)
+    uint32_t* blk_u = ia;
+    SGF_CHECK_HIP(hipMemsetAsync(blk_u, 0xff, m * 4, st));
+    SGF_CHECK_HIP(hipMemsetAsync(flag, 0, (m + 1) * 4, st));
+    hipLaunchKernelGGL(k_reslot_mark, dim3(grid_for(nnz)), dim3(kThreads), 0, st, k2s, j2s, nnz, B, slot, blk_u, flag);
+    SGF_LAUNCH_CHECK();
+    bytes = L.tmp_bytes;
+    SGF_CHECK_HIP(rocprim::exclusive_scan(ws + L.tmp, bytes, flag, fscan, 0u, m + 1, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_reslot_first, dim3(grid_for(nnz)), dim3(kThreads), 0, st, blk_u, fscan, cnt, head);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reslot_apply, dim3(grid_for(nnz)), dim3(kThreads), 0, st, blk_u, fscan, flag, head, cnt, slot);
+    SGF_LAUNCH_CHECK();
     int64_t* frags = reinterpret_cast<int64_t*>(ws + L.i64);
     hipLaunchKernelGGL(k_pad_counts, dim3(grid_for(nb + 1)), dim3(kThreads), 0, st, nsh, blk_row, nb, pad, nshp, frags,
                        bad);

@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line: the contract fields plus
                   community structure and RANDOMLY PERMUTED node ids (synth.synthetic_graph_community): the
                   locality has to be recovered by sgf_reorder and is then exploited by the LDS-staged
                   row-block kernel.  The uniform headline graph is an expander (nothing to recover).
+                  `structured.powerlaw`: three steps of the same on a power-law community graph with global hubs
+                  (synth.synthetic_graph_community_powerlaw: the long-row path and skewed communities).
   cpu_baseline  — the CPU restatement of the reference (oracle/, torch CPU kernels, all host cores) on
                   a bounded sample of the same workload, timed on this box before the GPU run.
 """
@@ -105,7 +107,7 @@ def parse():
     ap.add_argument("--aten-loss", action="store_true", help="(older spelling of --loss aten)")
     ap.add_argument("--no-structured", action="store_true",
                     help="skip the second measurement on the community-structured graph with shuffled node ids")
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "community"],
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "community", "powerlaw"],
                     help="graph generator of the HEADLINE measurement (default: uniform random, the r01 workload)")
     return ap.parse_args()
 
@@ -265,7 +267,8 @@ def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev
         if _sharded(world):
             ctx = ShardContext(n, local_edges=True)
     else:
-        gen = synth.synthetic_graph_community if graph == "community" else synth.synthetic_graph
+        gen = {"community": synth.synthetic_graph_community, "powerlaw": synth.synthetic_graph_community_powerlaw,
+               "uniform": synth.synthetic_graph}[graph]
         ei = gen(n, avg_deg, seed=seed, device=dev)
         x, y, train_idx = synth.synthetic_task(n, f, c, seed=seed)
         n_train = train_idx.numel()
@@ -431,11 +434,20 @@ def main():
             "nnz": q["nnz"], "value": q["n"] * k / q["elapsed"], "unit": "nodes/s", "steps": k,
             "ms_per_step": round(q["elapsed"] / k * 1e3, 3), "loss": q["loss"], "graph_view": q["view"],
             "prepare_graph_s": None if q["prepare_s"] is None else round(q["prepare_s"], 3), "roofline": q["roof"]}
+        # the same once more with a power-law structure: community sizes 16-4096 (truncated Pareto), heavy-tailed
+        # endpoints inside a community, 3 % of the pairs to global hubs (rows of tens of thousands of entries)
+        q = run_workload(args, "powerlaw", rank, world, dev, 3, 1)
+        structured["powerlaw"] = {
+            "graph": "same N / degree; community sizes 16-4096 by a truncated Pareto law, local hubs, 3 % of the pairs "
+                     "to global hubs, node ids randomly permuted (synth.synthetic_graph_community_powerlaw)",
+            "nnz": q["nnz"], "value": q["n"] * 3 / q["elapsed"], "unit": "nodes/s", "steps": 3,
+            "ms_per_step": round(q["elapsed"] / 3 * 1e3, 3), "graph_view": q["view"], "roofline": q["roof"]}
 
     if rank == 0:
         n, f, c, d, weak = r["n"], r["f"], r["c"], r["d"], r["weak"]
         ms = r["elapsed"] / args.steps * 1e3
-        gname = "uniform random graph" if args.graph == "uniform" else "community graph with shuffled node ids"
+        gname = {"uniform": "uniform random graph", "community": "community graph with shuffled node ids",
+                 "powerlaw": "power-law community graph with global hubs and shuffled node ids"}[args.graph]
         line = {
             "metric": f"SGFormer fwd+bwd nodes/sec on {args.workload} full-graph",
             "value": n * args.steps / r["elapsed"], "unit": "nodes/s", "n_gpus": world, "steps": args.steps,

@@ -175,13 +175,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   for (int i = threadIdx.x; i < S; i += NW * 64) cols_lds[i] = P.sh_cols[s0 + i];
   __syncthreads();
   const int64_t begin_abs = __shfl_up(end_abs, 1, 64);
-  const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);
+  const int64_t len_i = end_abs - (lane == 0 ? e_first : begin_abs);       // (0 for lanes >= nr)
+  // Rows longer than long_len (hubs) are reduced by whole workgroups afterwards (the long-row queue of sgf_spmm_split);
+  // here they count as rows WITHOUT gathered entries: stream positions are numbered over the other rows only, and the
+  // loads of the stash skip the hubs' entries.  (A first version walked such a wave's rows one entry at a time: on a
+  // power-law graph, where rows just below the threshold sit next to the hubs, a few waves then took 3 ms.)
   const bool long_i = lane < nr && len_i > lq.long_len;
-  const int64_t total64 = lane64(end_abs, nr - 1) - e_first;
+  const uint64_t long_mask = __ballot(long_i);
   const int32_t* __restrict__ ci = P.rem_col + e_first;
   const float* __restrict__ va = P.rem_val + e_first;
-  const bool slow_path = __ballot(long_i) != 0 || total64 >= (static_cast<int64_t>(1) << 31);
-  const int rel_v = static_cast<int>(end_abs - e_first);       // lane i: end of local row i in stream positions
+  int rel_v = long_i ? 0 : static_cast<int>(len_i);        // -> lane i: end of local row i in stream positions
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(rel_v, off, 64);
+    if (lane >= off) rel_v += t;
+  }
+  // entries of hub rows that lie in front of stream position p
+  auto hub_skip = [&](int p) -> int64_t {
+    int64_t sk = 0;
+    for (uint64_t mk = long_mask; mk != 0; mk &= mk - 1) {
+      const int j = __builtin_ctzll(mk);
+      if (__builtin_amdgcn_readlane(rel_v, j) <= p) sk += lane64(len_i, j);
+    }
+    return sk;
+  };
 
   // The first kStash stream positions of a half (16 rows): {byte offset of the source row, value}, followed by kStashPad
   // positions of {out-of-range offset, 0} — the unrolled steps of the gather loop read up to 3 batches past the end without
@@ -193,15 +210,25 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     int32_t col[kStashRegs];
     float val[kStashRegs];
   };
-  auto stash_load = [&](const int32_t* __restrict__ cih, const float* __restrict__ vah, int ne, StashRegs& sr) {
-    // range-checked loads (positions >= ne return 0 without touching memory): unconditional, so all of them are in
-    // flight before the first is used
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(cih), 0, ne * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vah), 0, ne * 4, 0x00020000);
+  auto stash_load = [&](int start, int ne, StashRegs& sr) {
+    if (long_mask == 0) {
+      // range-checked loads (positions >= ne return 0 without touching memory): unconditional, so all of them are in
+      // flight before the first is used
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(ci + start), 0, ne * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(va + start), 0, ne * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < kStashRegs; ++i) {
-      sr.col[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, (64 * i + lane) * 4, 0, 0);
-      sr.val[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, (64 * i + lane) * 4, 0, 0));
+      for (int i = 0; i < kStashRegs; ++i) {
+        sr.col[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, (64 * i + lane) * 4, 0, 0);
+        sr.val[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, (64 * i + lane) * 4, 0, 0));
+      }
+    } else {                                               // (rare) a hub among these rows: its entries are stepped over
+#pragma unroll
+      for (int i = 0; i < kStashRegs; ++i) {
+        const int idx = 64 * i + lane;
+        const int64_t g = static_cast<int64_t>(start) + idx + hub_skip(start + idx);
+        sr.col[i] = idx < ne ? ci[g] : 0;
+        sr.val[i] = idx < ne ? va[g] : 0.f;
+      }
     }
   };
   auto stash_park = [&](const StashRegs& sr, int ne) {
@@ -289,13 +316,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   const uint32_t b_lane = static_cast<uint32_t>(lane * 8);
 
   const bool tiles_on = NQ > 0 && !(dbg & 1);
-  const bool fast = mine && !slow_path;
+  const bool fast = mine;
   {
     // requested together: [stash of half 0] [A of chunk 0: entries or fragments] [entries of chunk 1] [X chunk 0]
     StashRegs sr;
     const int tot0 = (fast && !(dbg & 2)) ? half_stop(0) : 0;
     const int ne0 = tot0 < kStash ? tot0 : kStash;
-    if (fast) stash_load(ci, va, ne0, sr);
+    if (fast) stash_load(0, ne0, sr);
     if (tiles_on) {
       if (mine) {
         if (group_cells(0) < 0) build_a(0, nullptr);
@@ -381,38 +408,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   uint16_t* __restrict__ yl = y + r_base * ldy + (active ? fc : 0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
 
-  if (slow_path) {
-    // rare: a hub row among these 32 (its tile part is empty by construction: the plan leaves long rows alone)
-    refill_q(std::integral_constant<int, 0>{});
-    for (int r = 0; r < nr; ++r) {
-      if (r == 16) refill_q(std::integral_constant<int, 1>{});
-      const int64_t re = lane64(end_abs, r);
-      const int64_t rb = r == 0 ? e_first : lane64(end_abs, r - 1);
-      if (re - rb > lq.long_len) {
-        push_long_row(lq, r_base + r, re - rb, lane, 64);
-        continue;
-      }
-      for (int64_t e = rb; e < re; ++e) {
-        const uint32_t voff = lanebase + static_cast<uint32_t>(P.rem_col[e]) * pitch;
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(voff), 0, 0);
-        if (!hi) fma8(P.rem_val[e], raw);
-      }
-      // row finished: gathered part + the tile's partial sum, one rounding; lanes 0-31 write 8 bf16 each
-      if (active && !hi) {
-        const float* pr = patch + (r & (kPatchRows - 1)) * D + fc;
-        const float4 p0 = *reinterpret_cast<const float4*>(pr);
-        const float4 p1 = *reinterpret_cast<const float4*>(pr + 4);
-        uint4 o;                                           // v_cvt_pk_bf16_f32: round to nearest even, like f32_to_bf16
-        o.x = pack_bf16(racc[0] + p0.x, racc[1] + p0.y);
-        o.y = pack_bf16(racc[2] + p0.z, racc[3] + p0.w);
-        o.z = pack_bf16(racc[4] + p1.x, racc[5] + p1.y);
-        o.w = pack_bf16(racc[6] + p1.z, racc[7] + p1.w);
-        *reinterpret_cast<uint4*>(yl + r * ldy) = o;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) racc[k] = 0.f;
-    }
-    return;
+  for (uint64_t mk = long_mask; mk != 0; mk &= mk - 1) {   // hubs: queued for the workgroup-per-segment kernels
+    const int j = __builtin_ctzll(mk);
+    push_long_row(lq, r_base + j, lane64(len_i, j), lane, 64);
   }
 
   // ---- gathers consumed straight from registers -----------------------------------------------------------------------
@@ -429,8 +427,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     const int nrh = half_rows(h);
     const int start = half_start(h);                       // stream positions of this half
     const int tot = (dbg & 2) ? 0 : half_stop(h) - start;
-    const int32_t* __restrict__ cih = ci + start;
-    const float* __restrict__ vah = va + start;
     int row = 16 * h;                                      // first row of the half; rows without entries are skipped
     int row_end = __builtin_amdgcn_readlane(rel_v, row) - start;
     auto commit = [&](int pos) {                           // the row that ends at `pos` (relative to the half)
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
       const int np = ne >> 1;
       if (base > 0) {                                      // (rare: more than kStash positions in 16 rows)
         StashRegs sr;
-        stash_load(cih + base, vah + base, ne, sr);
+        stash_load(start + base, ne, sr);
         stash_park(sr, ne);
         issue(0, ra);
         issue(B, rb);
@@ -530,7 +526,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
       const int s1 = half_start(1);
       const int t1 = (dbg & 2) ? 0 : half_stop(1) - s1;
       ne1 = t1 < kStash ? t1 : kStash;
-      stash_load(ci + s1, va + s1, ne1, nx);
+      stash_load(s1, ne1, nx);
       __builtin_amdgcn_sched_barrier(0);
     }
     // rounding + store of the half's rows (a row without gathered entries holds the tile's partial sum as it is)

@@ -239,3 +239,36 @@ def test_module_on_tiled_graph_matches_oracle(cuda, d):
         r_t = float((gt[k] - gr).norm() / gr.norm())
         r_p = float((gp[k] - gr).norm() / gr.norm())
         assert r_t <= 0.12 and r_t <= 2.0 * r_p + 1e-2, (k, r_t, r_p)
+
+
+def test_spmm_tile_hubs_and_heavy_rows_in_one_tile(cuda):
+    """Hub rows (> LONG_ROW gathered entries: reduced by the long-row kernels) next to rows just BELOW the threshold, rows
+    without entries and ordinary rows, all inside the same 32-row tiles — the wave numbers its stream positions over the
+    non-hub rows and steps over the hubs' entries (csrc/spmm_tile.hip), several stash epochs per half.  Hubs first / last /
+    adjacent in a tile, two tiles of one block affected, one block without any staged source.  vs fp64 on the same inputs."""
+    from sgformer_amd import ops
+    rng = np.random.default_rng(11)
+    n, d = 2048, 256
+    lens = rng.integers(0, 12, size=n)
+    lens[0], lens[1], lens[2] = 1500, 900, 0             # hub first in its tile, a heavy neighbour, an empty row
+    lens[40], lens[41], lens[42], lens[63] = 2100, 1300, 1000, 1100      # adjacent hubs, heavy row, hub last in the tile
+    lens[300:316] = 700                                   # 16 heavy rows: 11 200 positions in one half
+    lens[1000] = 5000
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    colind = np.concatenate([np.sort(rng.choice(n, size=k, replace=bool(k > n))) for k in lens]).astype(np.int32)   # (duplicates in the longest rows)
+    val = rng.standard_normal(colind.size).astype(np.float32)
+    rp, ci, va = (torch.from_numpy(a).to(cuda) for a in (rowptr, colind, val))
+    blk = ops.K.tile_blocks(None, n, 128, cuda)
+    plan = ops.TilePlan(rp, ci, va, n, blk, cap=512, min_count=2)
+    assert plan.long_segments >= 5
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(torch.bfloat16)
+    y = ops.K.spmm_tile(plan, x.to(cuda), n)
+    ref = np.zeros((n, d))
+    np.add.at(ref, np.repeat(np.arange(n), lens), val.astype(np.float64)[:, None] * x.double().numpy()[colind])
+    ref = torch.from_numpy(ref)
+    err = (y.double().cpu() - ref).abs()
+    scale = ref.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)
+    assert float((err / scale).max()) <= 8e-3, float((err / scale).max())          # one bf16 rounding per element
+    assert torch.equal(ops.K.spmm_tile(plan, x.to(cuda), n), y)
+    assert float(y[2].abs().max()) == 0.0                                            # the empty row

@@ -1053,7 +1053,8 @@ class GraphView:
         if not g2.tiled:
             g2._tile_plans.clear()
         stats["kernel"] = ("row-block (LDS-staged)" if g2.blocked else
-                           "tiles (matrix cores) + gather remainder" if g2.tiled else "stream")
+                           "tiles (matrix cores) + gather remainder for bf16 rows of 128 / 256 features, else stream"
+                           if g2.tiled else "stream")
         return GraphView(g2, perm, inv, {**stats, "reordered": True})
 
 

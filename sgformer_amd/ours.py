@@ -492,7 +492,18 @@ class SGFormer(nn.Module):
             if repart is not None:
                 x, edge_index = repart.to_new(x), repart.edge_index
         if view is not None and view.perm is not None:
-            x = ops.permute_rows(x, view.perm, view.inv, cdt)
+            if x.requires_grad:
+                x = ops.permute_rows(x, view.perm, view.inv, cdt)
+            else:
+                # full-graph training hands in the SAME feature tensor every step: its permuted (and cast) copy is kept
+                # with the view, keyed on the tensor's identity and version (the key tensor is pinned so that a recycled
+                # data_ptr cannot alias it)
+                key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, cdt)
+                hit = getattr(view, "_x_cache", None)
+                if hit is None or hit[0] != key:
+                    hit = (key, ops.permute_rows(x, view.perm, view.inv, cdt), x)
+                    view._x_cache = hit
+                x = hit[1]
         elif x.dtype != cdt:
             x = x.to(cdt)
         # K10: the first Linear of both branches reads the same x — one pass, two outputs, the GCN stem's BatchNorm

@@ -272,3 +272,39 @@ def test_spmm_tile_hubs_and_heavy_rows_in_one_tile(cuda):
     assert float((err / scale).max()) <= 8e-3, float((err / scale).max())          # one bf16 rounding per element
     assert torch.equal(ops.K.spmm_tile(plan, x.to(cuda), n), y)
     assert float(y[2].abs().max()) == 0.0                                            # the empty row
+
+
+def test_permuted_features_are_cached_per_tensor_version(cuda):
+    """Full-graph training passes the same feature tensor every step: on a re-ordered graph its permuted copy is kept with
+    the graph view (sgformer_amd/ours.py) — reused while the tensor is unchanged, rebuilt after an in-place update or for
+    another tensor, never used for a tensor that requires grad."""
+    from sgformer_amd import ops
+    from sgformer_amd.ours import SGFormer
+    cfg = dict(trans_num_layers=1, trans_num_heads=1, trans_use_act=False, gnn_num_layers=2, gnn_use_init=True, graph_weight=0.5)
+    ei = _graphs()["community"].to(cuda)
+    n, f, c = int(ei.max()) + 1, 40, 6
+    torch.manual_seed(5)
+    m = SGFormer(f, 128, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16, **cfg).to(cuda).eval()
+    x = torch.randn(n, f, device=cuda)
+    prev = ops.set_reorder_mode("always")
+    try:
+        ops.graph_cache.clear()
+        with torch.no_grad():
+            a = m(x, ei)
+            view = ops.graph_cache.get(ei, n).view()
+            assert view.perm is not None
+            kept = view._x_cache[1]
+            b = m(x, ei)
+            assert view._x_cache[1] is kept and torch.equal(a, b)              # reused
+            x.mul_(2.0)                                                         # same storage, new version
+            c2 = m(x, ei)
+            assert view._x_cache[1] is not kept and not torch.equal(c2, a)
+            fresh = m(x.clone(), ei)                                            # another tensor with the same values
+            assert torch.equal(fresh, c2)
+        xg = x.clone().requires_grad_(True)
+        kept = view._x_cache[1]
+        m(xg, ei).sum().backward()
+        assert view._x_cache[1] is kept and xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+    finally:
+        ops.set_reorder_mode(prev)
+        ops.graph_cache.clear()

@@ -11,15 +11,18 @@
 //                    whole chunks of 32; their rows of X stream ONCE per block through a 2 x 16 KiB LDS ring, chunk by chunk,
 //                    by LDS-DMA (global_load_lds_dwordx4: no staging registers), written directly in the image the
 //                    transposing LDS read wants (512-byte units of four [4 keys][16 columns] subtiles);
-//   dense tile       A[rows of the block, staged sources] lives in HBM as ready-made matrix-core A fragments, value = hi +
-//                    lo bf16 (|error| <= 2^-17 relative), built once per graph; wave t owns the 32-row tile t and all 256
-//                    feature columns: per chunk 4 coalesced 1 KiB fragment loads, 32 ds_read_b64_tr_b16 (B fragments:
-//                    k = source, n = feature, straight out of the row-major staged rows) and 32 v_mfma_f32_32x32x16_bf16
-//                    into 8 x 16 accumulator registers — products of bf16 values are exact in fp32, accumulation is fp32;
+//   dense tile       A[rows of the block, staged sources] as matrix-core A fragments, value = hi + lo bf16 (|error| <= 2^-17
+//                    relative), built once per graph and PACKED in HBM (spmm_pack.hip: sparse groups as 8-byte entries the
+//                    wave scatters over its cleared 4 KiB fragment area in LDS, dense groups copied there by DMA); wave t
+//                    owns the 32-row tile t and all 256 feature columns: per chunk 4 ds_read_b128 of fragments, 32
+//                    ds_read_b64_tr_b16 (B fragments: k = source, n = feature, straight out of the row-major staged rows)
+//                    and 32 v_mfma_f32_32x32x16_bf16 into 8 x 16 accumulator registers — products of bf16 values are
+//                    exact in fp32, accumulation is fp32; nothing but DMA is loaded inside the chunk loop;
 //   remainder        the entries that are not in the tile (other communities, 20-40 %) keep their CSR form (rem_*) and
 //                    are gathered two per 16-byte-per-lane load as in k_spmm_seg_bf16x2 (spmm.hip), 16 rows per pass,
-//                    8 pair loads in flight; the tile's fp32 partial sums wait in a per-wave LDS patch (the ring's
-//                    memory, free by then) and are added when a row is finished: ONE rounding to bf16.
+//                    three sets of 8 pair loads in flight; the tile's fp32 partial sums wait in a per-wave LDS patch (the
+//                    ring's memory, free by then) and are added when a row is finished: ONE rounding to bf16.  Hub rows go
+//                    to the long-row queue; their wave steps over them.
 //
 // A staged row is read from L2 / HBM once per block instead of once per entry, the dense part costs 0.2 ms of matrix-core
 // time at products size instead of 2 ms of gathers, and what is left on the gather path is the part no blocking can
@@ -54,7 +57,7 @@ __device__ __forceinline__ float sum_halves(float v) {
 }
 
 constexpr int kChunk = 32;                    // staged sources per ring slot
-constexpr int kRingPairs = 8;                 // epilogue: 1 KiB gather slots per wave (two rows of X each)
+constexpr int kRingPairs = 8;                 // epilogue: pair loads (two rows of X each) per register set
 constexpr int kStashPad = 96;                 // positions of padding behind an epoch (>= 10 kRingPairs: see the gather loop)
 constexpr uint32_t kOobOffset = 0xfffffc00u;  // a gather offset beyond any x (x_bytes < 2^32 - 2048): the load returns zeros
 constexpr int kStash = 224;                   // epilogue: {source, value} pairs parked in LDS per epoch
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   }
 
   // ---- gathers consumed straight from registers -----------------------------------------------------------------------
-  // Two register sets of B pair loads each: while set A is consumed, set B is in flight, and A is re-issued as soon as
+  // Register sets of B pair loads each: while one set is consumed the others are in flight, and a set is re-issued as soon as
   // its last pair is consumed.  Steps are unrolled, registers and LDS offsets static: per pair one ds_read_b32 of the
   // source offset (for the re-issue), one of the value, the multiply-adds, and a wave-uniform compare for a row end.
   // A row end COMMITS the row — (even + odd positions) added into the row's slot of the patch, which already holds the

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """A/B of the wave-level SpMM kernels on ONE box (launch times vary +-5 % from box to box):
 k_spmm_wave (r01: 64-bit addressing, wave per row), k_spmm_row (buffer addressing), k_spmm_seg /
-k_spmm_seg_bf16x2 (flattened stream; two bf16 rows per load).  Interleaved, median of 9."""
+k_spmm_seg_bf16x2 (flattened stream; two bf16 rows per load), and — on the re-ordered graphs, bf16 — the matrix-core
+row-block kernel k_spmm_tile_bf16.  Interleaved, median of 9.
+
+    python scripts/spmm_ab.py [uniform|community|powerlaw] [bf16|f32]
+(powerlaw: synth.synthetic_graph_community_powerlaw — skewed communities, local and global hubs, shuffled ids)"""
 import json
 import os
 import sys
@@ -20,26 +24,39 @@ def main():
     graph = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
     n, deg = 2449029, 50.5
-    gen = synth.synthetic_graph_community if graph == "community" else synth.synthetic_graph
+    gen = {"community": synth.synthetic_graph_community, "powerlaw": synth.synthetic_graph_community_powerlaw,
+           "uniform": synth.synthetic_graph}[graph]
     ei = gen(n, deg, seed=123, device=dev)
-    if graph == "community":
-        _, inv, _ = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
+    structured = graph != "uniform"
+    plan = None
+    if structured:
+        perm, inv, comm = ops.K.reorder(ei, n, *ops.REORDER_ITERS)
         ei = inv.long()[ei]
     g = ops.CSRGraph(ei, n, validate=False)
     del ei
     x = torch.randn(n, 256, device=dev).to(dtype)
-    times = {k: [] for k in VARIANTS}
+    variants = dict(VARIANTS)
+    if structured and dtype == torch.bfloat16:
+        g.blk_row = ops.K.tile_blocks(comm[perm.long()].contiguous(), n, ops.TILE_MAX_ROWS, dev)
+        plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row)
+        if plan.tile_density < ops.TILE_SPARSE_DENSITY:          # the policy of ops.GraphView
+            plan = ops.TilePlan(g.rowptr, g.colind, g.val, n, g.blk_row, min_count=ops.TILE_MIN_COUNT + 1)
+        variants["k_spmm_tile_bf16"] = None
+    times = {k: [] for k in variants}
     for rep in range(10):
-        for name, force in VARIANTS.items():
-            os.environ["SGF_SPMM_KERNEL"] = force        # (seg2 falls back to row for fp32 storage)
+        for name, force in variants.items():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            ops.K.spmm(g.rowptr, g.colind, g.val, x, n, long_segments=g.long_segments)
+            if force is None:
+                ops.K.spmm_tile(plan, x, n)
+            else:
+                os.environ["SGF_SPMM_KERNEL"] = force    # (seg2 falls back to row for fp32 storage)
+                ops.K.spmm(g.rowptr, g.colind, g.val, x, n, long_segments=g.long_segments)
             b.record()
             torch.cuda.synchronize()
             if rep:
                 times[name].append(a.elapsed_time(b))
-    print(json.dumps({"graph": graph + (" (sgf_reorder order)" if graph == "community" else ""), "dtype": str(dtype),
+    print(json.dumps({"graph": graph + (" (sgf_reorder order)" if structured else ""), "dtype": str(dtype),
                       "median_ms": {k: round(sorted(v)[len(v) // 2], 3) for k, v in times.items()}}))
 
 

@@ -18,15 +18,17 @@ sys.path.insert(0, ROOT)
 from sgformer_amd import ops, synth  # noqa: E402
 
 
-def timed(fn, reps=9):
+def timed(fn, reps=15, warm=12):
+    """median of `reps` launches after `warm` untimed ones (the first ~20 ms after an idle phase run at ramping clocks:
+    with a single warm-up launch the same kernel measured 7 % slower)"""
     ts = []
-    for i in range(reps + 1):
+    for i in range(reps + warm):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
         torch.cuda.synchronize()
-        if i:
+        if i >= warm:
             ts.append(a.elapsed_time(b))
     ts.sort()
     return ts[len(ts) // 2]
@@ -97,16 +99,16 @@ def main():
                tile_bytes=plan.tile_bytes, dense_tile_bytes=plan.fragments * 2048, rem_entries=plan.rem_entries, long_segments=plan.long_segments,
                plan_s=round(t_plan, 3), rel_diff_vs_stream=rel)
         if a.sweep:
-            for dbg in (4, 8, 12):
-                os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg)
-                report(f"  nt loads/stores [debug={dbg}: 4 = A fragments nt, 8 = y stores nt]", timed(lambda: ops.K.spmm_tile(plan, x, n)))
-            for ch in (16, 32, 128, 256, 1024):
-                os.environ["SGF_SPMM_TILE_CHUNK"] = str(ch)
-                for dbg in (0, 12):
-                    os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg)
-                    report(f"  XCD chunk {ch} blocks, debug={dbg}", timed(lambda: ops.K.spmm_tile(plan, x, n)))
-            os.environ.pop("SGF_SPMM_TILE_DEBUG")
-            os.environ.pop("SGF_SPMM_TILE_CHUNK")
+            # XCD chunk: how many consecutive row blocks one XCD takes before the next stripe (SGF_SPMM_TILE_CHUNK);
+            # two interleaved rounds so that clock drift shows
+            for rnd in range(2):
+                for ch in (0, 8, 16, 32, 64, 128, 256, 512, 1024, 4096):
+                    if ch:
+                        os.environ["SGF_SPMM_TILE_CHUNK"] = str(ch)
+                    else:
+                        os.environ.pop("SGF_SPMM_TILE_CHUNK", None)
+                    report(f"  XCD chunk {ch or 'default'} blocks (round {rnd})", timed(lambda: ops.K.spmm_tile(plan, x, n)))
+            os.environ.pop("SGF_SPMM_TILE_CHUNK", None)
         if a.ablate:
             for dbg, what in ((1, "no tile phase (gathers + stores only)"), (2, "no gathers (tiles + stores only)"),
                               (3, "neither (skeleton)"), (16, "gathers clamped to 4096 rows (all L2 hits)"),

@@ -93,6 +93,25 @@ class HaloPlan:
         pos = torch.searchsorted(remote, c.clamp(max=max(ctx.n_global - 1, 0)))
         self.colind = torch.where(is_local, c - ctx.r0, ctx.n_local + pos).to(torch.int32)
         self.n_ext = ctx.n_local + self.n_halo
+        self._split = None
+
+    def split(self, rowptr: torch.Tensor, val: torch.Tensor, n_local: int):
+        """((rowptr, colind, val, long_segments) of the entries whose source this rank owns, the same for the entries
+        whose source arrives with the halo — columns then index the RECEIVED rows): the own part can be multiplied
+        while the exchange is on the links (ops._sharded_spmm).  Stored order inside every row is kept.  Built once."""
+        if self._split is None:
+            n_rows = int(rowptr.numel()) - 1
+            c = self.colind.long()
+            own = c < n_local
+            rows = torch.repeat_interleave(torch.arange(n_rows, device=c.device), rowptr[1:] - rowptr[:-1])
+
+            def part(mask, shift):
+                rp = torch.zeros(n_rows + 1, dtype=torch.int64, device=c.device)
+                torch.cumsum(torch.bincount(rows[mask], minlength=n_rows), 0, out=rp[1:])
+                return rp, (c[mask] - shift).to(torch.int32).contiguous(), val[mask].contiguous(), ops.long_row_segments(rp, None)
+
+            self._split = (part(own, 0), part(~own, n_local))
+        return self._split
 
 
 class ShardedGraph:
@@ -343,6 +362,9 @@ class ShardContext:
         self.n_local = self.r1 - self.r0
         self.local_edges = bool(local_edges)
         self.halo_max = float(os.environ.get("SGF_HALO_MAX", "0.5"))   # largest halo / remote-rows ratio served by the halo path
+        # own-column entries are multiplied while the halo rows are on the links (SGF_DIST_OVERLAP=0: one product on
+        # [own rows ; halo rows] after the exchange, the r02 form)
+        self.overlap = os.environ.get("SGF_DIST_OVERLAP", "1") != "0"
         self.bytes_all_reduced = 0
         self.bytes_all_gathered = 0
         self.bytes_halo_sent = 0
@@ -438,6 +460,16 @@ class ShardContext:
         dist.all_to_all_single(ext[self.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
         self.bytes_halo_sent += send.numel() * send.element_size()
         return ext
+
+    def halo_exchange_start(self, x: torch.Tensor, plan: "HaloPlan"):
+        """(rows of the peers in `plan.need` order [n_halo, d], work): the exchange is issued asynchronously (on the
+        collective's own stream); the buffer is valid after work.wait()."""
+        d = x.shape[1]
+        send = ops.gather_rows(x, plan.send_idx) if plan.send_idx.numel() else x.new_empty((0, d))
+        recv = torch.empty((plan.n_halo, d), dtype=x.dtype, device=x.device)
+        work = dist.all_to_all_single(recv, send, plan.recv_counts, plan.send_counts, group=self.group, async_op=True)
+        self.bytes_halo_sent += send.numel() * send.element_size()
+        return recv, work, send
 
     def gather_chunks(self, d: int) -> int:
         """Column chunks the SpMM operand is gathered in (ops._sharded_spmm): up to 4, each at least

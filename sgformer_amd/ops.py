@@ -1112,6 +1112,17 @@ def _sharded_spmm(graph, x, shard, transposed: bool):
     n_local = graph.n_local
     plan = graph.halo(shard, transposed) if hasattr(graph, "halo") else None
     if plan is not None and plan.enabled:
+        if getattr(shard, "overlap", False) and plan.n_halo > 0:
+            # the entries whose source this rank owns are multiplied while the halo rows are on the links; the halo
+            # entries follow when they have arrived (their sum is rounded to the storage dtype before it is added: bf16
+            # rows with cut edges carry two roundings more than the single-GPU product)
+            (rp_o, ci_o, va_o, seg_o), (rp_h, ci_h, va_h, seg_h) = plan.split(rowptr, val, n_local)
+            recv, work, keep = shard.halo_exchange_start(x, plan)
+            y = K.spmm(rp_o, ci_o, va_o, x, n_local, long_segments=seg_o)
+            work.wait()
+            y.add_(K.spmm(rp_h, ci_h, va_h, recv, n_local, long_segments=seg_h))
+            del keep
+            return y
         return K.spmm(rowptr, plan.colind, val, shard.halo_exchange(x, plan), n_local, long_segments=long_segments)
     d = x.shape[1]
     chunks = shard.gather_chunks(d)

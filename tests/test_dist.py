@@ -106,11 +106,12 @@ def test_sharded_step_matches_full_graph(world, cfg_name, directed, chunk_cols):
         assert e["gathered"] > 0 and e["reduced"] > 0
 
 
-def _worker_halo(rank, world, port, directed, ret):
+def _worker_halo(rank, world, port, directed, ret, overlap="1"):
     """A graph whose contiguous node ranges cut few edges (planted communities, ids NOT shuffled): the
     SpMM exchange must take the halo path (no all-gather at all) and match the full-graph oracle."""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_REORDER="0")   # the caller's order HAS the locality
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGF_DIST_REORDER="0",   # the caller's order HAS the locality
+                      SGF_DIST_OVERLAP=overlap)   # "1": own-column entries multiplied while the halo rows travel
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
@@ -156,20 +157,24 @@ def _worker_halo(rank, world, port, directed, ret):
         ret[rank] = {"logits": float((logits.detach().double() - ref.detach()[ctx.r0:ctx.r1]).abs().max()),
                      "grad": gerr, "halo_sent": ctx.bytes_halo_sent, "gathered": ctx.bytes_all_gathered,
                      "n_halo": g.halo(ctx, False).n_halo, "fraction": g.halo(ctx, False).max_fraction,
-                     "symmetric": bool(g.symmetric), "plans": len(g._halo)}
+                     "symmetric": bool(g.symmetric), "plans": len(g._halo),
+                     "split": g.halo(ctx, False)._split is not None, "overlap": ctx.overlap}
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,directed", [(2, False), (3, False), (2, True)])
-def test_halo_exchange_matches_full_graph(world, directed):
-    """halo all-gather for cut-edge neighbour features (large/ours.py:34 sharded by rows)."""
+@pytest.mark.parametrize("world,directed,overlap", [(2, False, "1"), (3, False, "1"), (2, True, "1"), (2, False, "0"),
+                                                    (3, True, "0")])
+def test_halo_exchange_matches_full_graph(world, directed, overlap):
+    """halo all-gather for cut-edge neighbour features (large/ours.py:34 sharded by rows); with the
+    own-column entries multiplied while the halo rows are on the links (default) and as one product after the exchange."""
     port = _free_port()
     ret = mp.Manager().dict()
-    mp.spawn(_worker_halo, args=(world, port, directed, ret), nprocs=world, join=True)
+    mp.spawn(_worker_halo, args=(world, port, directed, ret, overlap), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         e = ret[rank]
+        assert e["overlap"] == (overlap == "1") and e["split"] == (overlap == "1"), e
         assert e["logits"] < 5e-5 and e["grad"] < 2e-3, e
         assert e["gathered"] == 0 and e["halo_sent"] > 0, e          # halo path only: no all-gather of X
         assert e["fraction"] <= 0.5 and 0 < e["n_halo"] < 601 // world, e

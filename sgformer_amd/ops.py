@@ -1913,4 +1913,14 @@ def linear_cat(xs, w, b):
 
 
 def out_linear(x, w, b):
+    """The output head (large/ours.py:275).  fp32 storage and a class count that is not a multiple of 4 (C = 47): W and b
+    are padded with zero rows to the next multiple and the result sliced, so that the layer still runs on the streaming
+    fp32 kernel (csrc/linear_f32.hip) instead of a library GEMM; autograd slices the gradients back."""
+    m = w.shape[0]
+    if (x.dtype == _F32 and x.is_cuda and x.dim() == 2 and m % 4 != 0
+            and K.gcn_epilogue_supported(w.shape[1], (m + 3) // 4 * 4, _F32)):
+        pad = (m + 3) // 4 * 4 - m
+        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
+        return _Linear.apply(wp, bp, None, x)[:, :m]
     return _Linear.apply(w, b, None, x)

@@ -785,7 +785,8 @@ def test_linear_f32_stats_dx_and_cat(cuda, n, d_in, d_out):
     assert _rel(stc[:d_out], vc.sum(0)) <= 1e-5 and _rel(stc[d_out:], (vc * vc).sum(0)) <= 2e-6
 
 
-def test_fp32_module_runs_without_a_library_gemm(cuda):
+@pytest.mark.parametrize("c", [40, 47])
+def test_fp32_module_runs_without_a_library_gemm(cuda, c):
     """The arxiv recipe (config 2: fp32, f = 128, d = 256, C = 40) through the module: every Linear (stems, GCN layers,
     attention projections are algebra on d x d, head) takes the streaming fp32 kernels — torch's matmul / addmm /
     F.linear are not called on [N, .] operands — and the result is the fp64 oracle's to the fp32 bar."""
@@ -793,7 +794,7 @@ def test_fp32_module_runs_without_a_library_gemm(cuda):
     from sgformer_amd import ops, synth
     from sgformer_amd.ours import SGFormer
     cfg = dict(synth.RECIPES["ogbn-arxiv"])
-    n, f, d, c = 3000, 128, 256, 40
+    n, f, d = 3000, 128, 256             # c = 47: the head's W / b are padded to 48 rows (ops.out_linear)
     torch.manual_seed(1)
     x, ei = torch.randn(n, f), O.synthetic_graph(n, 8.0, seed=2)
     y, idx = torch.randint(0, c, (n,)), torch.randperm(n)[: n // 2]

@@ -390,7 +390,8 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
         exchanged = {"halo_bytes_sent_per_step": ctx.bytes_halo_sent // max(warmup + steps, 1),
                      "all_gather_bytes_per_step": ctx.bytes_all_gathered // max(warmup + steps, 1),
                      "all_reduce_bytes_per_step": ctx.bytes_all_reduced // max(warmup + steps, 1),
-                     "repartition_bytes_per_step": ctx.bytes_repartition // max(warmup + steps, 1)}
+                     "repartition_bytes_per_step": ctx.bytes_repartition // max(warmup + steps, 1),
+                     "halo_overlapped_with_own_columns": bool(getattr(ctx, "overlap", False))}
     out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_fused=ms_fused, loss_mode=state["mode"],
                roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
                peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))

@@ -136,6 +136,45 @@ def test_products_recipe_auto_policy_bf16(cuda, products_case):
         assert r_t <= 0.15 and r_t <= 2.0 * r_p + 2e-2, (name, report)
 
 
+def test_products_recipe_powerlaw_graph_with_hubs_bf16(cuda):
+    """The same comparison on a power-law community graph with global hubs (SURVEY §8d input class (b): skewed community
+    sizes, rows of thousands of entries next to ordinary ones; ids shuffled), 150 k nodes, bf16, AUTO policy: the tile
+    SpMM with its hub rows on the long-row queue and their waves stepping over them — bounded by twice the distance of
+    the plain kernels on the graph as given."""
+    from sgformer_amd import ops, synth
+    n, f, c, d = 150_000, 100, 47, 256
+    cfg = dict(synth.RECIPES["ogbn-products"])
+    ei = synth.synthetic_graph_community_powerlaw(n, 24.0, seed=13, p_hub=0.1, hub_gamma=6.0)   # 5 rows beyond LONG_ROW (up to 22 813 entries), 6 just below
+    x, y, idx = synth.synthetic_task(n, f, c, seed=13)
+    p = O.init_params(cfg, f, d, c, seed=2)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref, loss_ref, g64 = _oracle(cfg, p, x, ei, y, idx)
+    case = dict(f=f, d=d, c=c, cfg=cfg, p=p)
+    m = _module(case, cuda, torch.bfloat16)
+    lt, loss_t, gt, view = _run(m, x, ei, y, idx, cuda)
+    assert view.perm is not None and view.graph.tiled
+    plan = view.graph.tile_plan(False)
+    assert plan.long_segments > 0                                     # hubs are really there, on the queue
+    prev = ops.set_reorder_mode("never")
+    try:
+        lp, loss_p, gp, view0 = _run(m, x, ei, y, idx, cuda)
+    finally:
+        ops.set_reorder_mode(prev)
+    assert view0.perm is None
+    e_t = float((lt - ref).norm() / ref.norm())
+    e_p = float((lp - ref).norm() / ref.norm())
+    report = {"logits_rel_tiled": e_t, "logits_rel_plain": e_p, "loss": [loss_t, loss_p, loss_ref],
+              "long_segments": plan.long_segments, "tile_fraction": plan.tile_fraction}
+    for name in ["fc.weight", "graph_conv.convs.2.W.weight", "graph_conv.fcs.0.weight", "trans_conv.fcs.0.weight"]:
+        g = g64[name]
+        report["grad/" + name] = [float((gt[name] - g).norm() / g.norm()), float((gp[name] - g).norm() / g.norm())]
+    print("products-recipe power-law 150k bf16 (tiled vs plain):", json.dumps(report))
+    assert e_t <= 3e-2 and e_t <= 2.0 * e_p + 1e-3, report
+    assert abs(loss_t - loss_ref) <= 3e-2 * abs(loss_ref), report
+    for name, (r_t, r_p) in ((n_, v) for n_, v in report.items() if n_.startswith("grad/")):
+        assert r_t <= 0.15 and r_t <= 2.0 * r_p + 2e-2, (name, report)
+
+
 def test_pokec_recipe_fp32_with_unlabeled_nodes(cuda):
     """BASELINE.json config 4's model: large/run.sh:22-26 (two GCN layers + use_init, one attention layer, gw 0.5),
     hidden 256, C = 2, fp32; 30 % of the labels are -1 = unlabeled and the training rows are drawn from the labelled

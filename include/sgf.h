@@ -43,6 +43,9 @@ extern "C" {
 
 int sgf_version(void);
 const char* sgf_last_error(void);
+/* Experiment switches (SGF_* environment variables read by the library) are cached per process; call this after changing
+ * one so that it is read again at its next use. */
+int sgf_reload_env(void);
 
 /* ------------------------------------------------------------------------------------------
  * T1 — adjacency normalisation + CSR build.   Replaces large/ours.py:26-33
@@ -549,6 +552,12 @@ int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ld
                            int64_t n, int32_t d_in, int32_t d_out, int32_t dtype, void* y, int64_t ldy,
                            const float* shift, float* stats, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Both input gradients of the two-operand Linear W [a1 | a2] (large/ours.py:36-38) from one read of dy out of HBM:
+ * dx1 = dy w1, dx2 = dy w2 with w1 = W[:, :d], w2 = W[:, d:] (same leading dimension ldw).  pair != 0: ONE launch whose
+ * workgroups come in pairs on one XCD walking the same row tiles (the second read of a tile is an L2 hit); pair = 0 or
+ * fp32 storage: two sgf_gcn_epilogue_dx launches.  Results are identical either way. */
+int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1, const void* w2, int64_t ldw, int64_t n, int32_t d,
+                         int32_t dtype, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2, int32_t pair, void* stream);
 int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw, int64_t n, int32_t d_in,
                         int32_t d_out, int32_t dtype, void* dx, int64_t lddx, void* stream);
 /* GraphConvLayer with use_init (large/ours.py:36-38):  y = [a1 | a2] W^T + bias,  W = [W1 | W2] of width 2 d.

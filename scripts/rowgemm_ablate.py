@@ -4,7 +4,7 @@ import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from sgformer_amd import ops  # noqa: E402
+from sgformer_amd import _lib, ops  # noqa: E402
 
 def timed(fn, reps=10):
     fn(); torch.cuda.synchronize()
@@ -22,9 +22,9 @@ w = (torch.randn(d, d, device=dev) / 16).bfloat16()
 bias = torch.randn(d, device=dev)
 out = {}
 for flags in (0, 2, 4, 6):
-    os.environ["SGF_ROWGEMM_DEBUG"] = str(flags)
+    os.environ["SGF_ROWGEMM_DEBUG"] = str(flags); _lib.load().sgf_reload_env()
     out[f"dbg={flags}"] = round(timed(lambda: ops.K.gcn_epilogue_stats(a, w, bias)), 4)
-os.environ["SGF_ROWGEMM_DEBUG"] = "0"
+os.environ["SGF_ROWGEMM_DEBUG"] = "0"; _lib.load().sgf_reload_env()
 y = torch.empty_like(a)
 out["copy_ (torch)"] = round(timed(lambda: y.copy_(a)), 4)
 print(json.dumps(out))

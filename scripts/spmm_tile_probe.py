@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from sgformer_amd import ops, synth  # noqa: E402
+from sgformer_amd import _lib, ops, synth  # noqa: E402
 
 
 def timed(fn, reps=15, warm=12):
@@ -104,11 +104,11 @@ def main():
             for rnd in range(2):
                 for ch in (0, 8, 16, 32, 64, 128, 256, 512, 1024, 4096):
                     if ch:
-                        os.environ["SGF_SPMM_TILE_CHUNK"] = str(ch)
+                        os.environ["SGF_SPMM_TILE_CHUNK"] = str(ch); _lib.load().sgf_reload_env()
                     else:
-                        os.environ.pop("SGF_SPMM_TILE_CHUNK", None)
+                        os.environ.pop("SGF_SPMM_TILE_CHUNK", None); _lib.load().sgf_reload_env()
                     report(f"  XCD chunk {ch or 'default'} blocks (round {rnd})", timed(lambda: ops.K.spmm_tile(plan, x, n)))
-            os.environ.pop("SGF_SPMM_TILE_CHUNK", None)
+            os.environ.pop("SGF_SPMM_TILE_CHUNK", None); _lib.load().sgf_reload_env()
         if a.ablate:
             for dbg, what in ((1, "no tile phase (gathers + stores only)"), (2, "no gathers (tiles + stores only)"),
                               (3, "neither (skeleton)"), (16, "gathers clamped to 4096 rows (all L2 hits)"),
@@ -116,9 +116,9 @@ def main():
                               (33, "no tile phase, no multiply-adds"), (49, "no tile phase, L2-hit gathers, no multiply-adds"),
                               (128, "tile phase without matrix-core work"), (130, "no gathers, tile phase without MFMA"),
                               ):
-                os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg)
+                os.environ["SGF_SPMM_TILE_DEBUG"] = str(dbg); _lib.load().sgf_reload_env()
                 report(f"  ablation [{what}]", timed(lambda: ops.K.spmm_tile(plan, x, n)))
-            os.environ.pop("SGF_SPMM_TILE_DEBUG")
+            os.environ.pop("SGF_SPMM_TILE_DEBUG"); _lib.load().sgf_reload_env()
         del plan
 
 

@@ -22,6 +22,7 @@ _P = c_void_p
 SIGNATURES = {
     "sgf_version": (c_int32, []),
     "sgf_last_error": (c_char_p, []),
+    "sgf_reload_env": (c_int32, []),
     "sgf_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_csr_build": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_csr_transpose": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -125,6 +126,8 @@ SIGNATURES = {
     "sgf_gcn_epilogue_stats": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, _P, c_int64,
                                          _P, _P, _P, c_size_t, _P]),
     "sgf_gcn_epilogue_dx": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_int64, _P]),
+    "sgf_gcn_epilogue_dx2": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64,
+                                       c_int32, _P]),
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
     "sgf_gcn_epilogue_partial_bytes": (c_size_t, [c_int64, c_int32]),

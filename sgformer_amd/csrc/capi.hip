@@ -8,6 +8,8 @@ namespace {
 thread_local char g_err[1024] = "";
 }  // namespace
 
+int g_env_epoch = 0;
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -19,3 +21,5 @@ void set_error(const char* fmt, ...) {
 extern "C" int sgf_version(void) { return SGF_VERSION; }
 
 extern "C" const char* sgf_last_error(void) { return sgf::g_err; }
+
+extern "C" int sgf_reload_env(void) { return ++sgf::g_env_epoch; }

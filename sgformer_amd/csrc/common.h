@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <cstdlib>
 
 #include "../../include/sgf.h"
 
@@ -39,6 +40,25 @@ void set_error(const char* fmt, ...);
       return SGF_E_HIP;                                                             \
     }                                                                               \
   } while (0)
+
+// ---- experiment switches: environment variables read ONCE per process, not per launch --------------------------------
+// sgf_reload_env() (include/sgf.h) makes every switch re-read its variable at its next use (probe scripts that flip a
+// switch between launches call it after changing os.environ).
+extern int g_env_epoch;
+struct EnvInt {
+  const char* name;
+  int dflt;
+  int value = 0;
+  int epoch = -1;
+  int get() {
+    if (epoch != g_env_epoch) {
+      const char* e = getenv(name);
+      value = (e && *e) ? atoi(e) : dflt;
+      epoch = g_env_epoch;
+    }
+    return value;
+  }
+};
 
 // ---- chip constants (MI355X / gfx950) ------------------------------------------------------
 constexpr int kWave = 64;      // wavefront width

@@ -50,6 +50,9 @@ struct RowGemmArgs {
   uint16_t* y; int64_t ldy;
   int64_t n;
   uint4* part;                                         // IO 1 (written) / IO 2 (read): [tiles][NS][2][64 lanes] x 16 B
+  // PAIRED launch (pair != 0): blocks b and b + 8 (same XCD under the observed b % 8 placement) walk the SAME tiles, one
+  // with (w, y), the other with (w2, y2) — two products of one operand whose second read is served by the XCD's L2.
+  const uint16_t* w2; uint16_t* y2; int64_t ldy2; int pair;
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
@@ -86,6 +89,15 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
   const int hi = lane >> 5;
   unsigned char* const stg = lds + D * BT + wave * kStageBytes;
   float* const cvec = reinterpret_cast<float*>(lds + D * BT + kRgWaves * kStageBytes);   // [bias | shift]
+  // paired launch: role 1 multiplies with w2 into y2; both roles of a pair walk the same tiles
+  const int role = p.pair ? (blockIdx.x >> 3) & 1 : 0;
+  const int64_t vblock = p.pair ? (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3) : blockIdx.x;
+  const int64_t vgrid = p.pair ? gridDim.x / 2 : gridDim.x;
+  if (role) {
+    p.w = p.w2;
+    p.y = p.y2;
+    p.ldy = p.ldy2;
+  }
 
   // ---- W -> LDS, once ----
   if (!p.trans) {
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
   }
 
   const int64_t ntiles = (p.n + 31) / 32;
-  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kRgWaves;
+  const int64_t nwaves = vgrid * kRgWaves;
   auto load_tile = [&](int64_t t, bf16x8 (&dst)[KS]) {
     int64_t row = t * 32 + i31;
     if (row >= p.n) row = p.n - 1;                     // ragged end: any valid row; its results are masked
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
   const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
 
   bf16x8 cur[KS], nxt[KS];
-  int64_t t = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+  int64_t t = vblock * kRgWaves + wave;
   if (t < ntiles) load_tile(t, cur);
   for (; t < ntiles; t += nwaves) {
     const int64_t tn = t + nwaves;
@@ -763,8 +775,8 @@ int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
     case 64: hipLaunchKernelGGL((k_rowgemm_bf16<64, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
     case 128: hipLaunchKernelGGL((k_rowgemm_bf16<128, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
     case 256: {
-      const char* e = getenv("SGF_ROWGEMM_DEBUG");
-      const int dbg = e ? atoi(e) : 0;
+      static EnvInt dbg_env{"SGF_ROWGEMM_DEBUG", 0};
+      const int dbg = dbg_env.get();
       switch (IO == 0 && !STATS ? dbg : 0) {
 #define SGF_RG_DBG(X) case X: hipLaunchKernelGGL((k_rowgemm_bf16<256, false, 0, X>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
         SGF_RG_DBG(2) SGF_RG_DBG(4) SGF_RG_DBG(6)
@@ -932,6 +944,31 @@ extern "C" int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, 
   RowGemmArgs args{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(w), ldw, 1, nullptr, nullptr,
                    nullptr, static_cast<uint16_t*>(dx), lddx, n, nullptr};
   return launch_rowgemm<false, 0>(args, d_in, grid_blocks(n), static_cast<hipStream_t>(stream));
+}
+
+// Both input gradients of the two-operand Linear from ONE read of dy out of HBM:  dx1 = dy W[:, :d], dx2 = dy W[:, d:]
+// (large/ours.py:36-38 differentiated).  [W1 | W2] is 256 KiB in bf16 — more than a CU's LDS — so the launch is PAIRED:
+// blocks b and b + 8 (one XCD) walk the same row tiles, one holding W1, the other W2; whichever runs behind finds the
+// tile in the XCD's L2, which also pulls the two back together.  pair = 0 runs the two products as two launches.
+extern "C" int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1, const void* w2, int64_t ldw, int64_t n,
+                                    int32_t d, int32_t dtype, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2,
+                                    int32_t pair, void* stream) {
+  int rc = check_common("sgf_gcn_epilogue_dx2", dy, lddy, w1, ldw, n, d, d, dtype, dx1, lddx1);
+  if (rc != SGF_OK) return rc;
+  rc = check_common("sgf_gcn_epilogue_dx2", dy, lddy, w2, ldw, n, d, d, dtype, dx2, lddx2);
+  if (rc != SGF_OK) return rc;
+  if (n == 0) return SGF_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32 || !pair || grid_blocks(n) < 16) {
+    rc = sgf_gcn_epilogue_dx(dy, lddy, w1, ldw, n, d, d, dtype, dx1, lddx1, stream);
+    if (rc != SGF_OK) return rc;
+    return sgf_gcn_epilogue_dx(dy, lddy, w2, ldw, n, d, d, dtype, dx2, lddx2, stream);
+  }
+  RowGemmArgs args{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(w1), ldw, 1, nullptr, nullptr,
+                   nullptr, static_cast<uint16_t*>(dx1), lddx1, n, nullptr,
+                   static_cast<const uint16_t*>(w2), static_cast<uint16_t*>(dx2), lddx2, 1};
+  const int pairs = grid_blocks(n) / 16 * 8;          // whole groups of 8 pairs = 16 consecutive blocks
+  return launch_rowgemm<false, 0>(args, d, 2 * pairs, st);
 }
 
 // ---- two-operand Linear  y = [a1 | a2] W^T + bias  (GraphConvLayer with use_init, large/ours.py:36-38) -------------

@@ -601,10 +601,10 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers,
   // 4 / 8 = nt fragment loads / y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
   // loop, 128 = no matrix-core work in the tile phase
-  const char* dbg_env = getenv("SGF_SPMM_TILE_DEBUG");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  int chunk = 64;                                        // an XCD walks 64 consecutive blocks (<= 8192 rows) at a time
-  if (const char* e = getenv("SGF_SPMM_TILE_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
+  // (both switches are cached: a launch costs no environment look-up; sgf_reload_env() re-reads them)
+  static EnvInt dbg_env{"SGF_SPMM_TILE_DEBUG", 0}, chunk_env{"SGF_SPMM_TILE_CHUNK", 64};
+  const int dbg = dbg_env.get();
+  const int chunk = chunk_env.get() > 0 ? chunk_env.get() : 64;   // an XCD walks 64 consecutive blocks (<= 8192 rows) at a time
   const uint16_t* xs = static_cast<const uint16_t*>(x);
   uint16_t* ys = static_cast<uint16_t*>(y);
 #define SGF_TILE_LAUNCH(NCT_, NW_, DBG_)                                                                               \

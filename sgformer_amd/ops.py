@@ -495,10 +495,13 @@ class HipKernels:
 
     @staticmethod
     def ln_bwd(gy, y, x, res, a: float, b: float, gamma, relu: bool, mean, rstd):
+        """(dx, dres, dgamma, dbeta).  a == b (the large variant's (x + res) / 2): dx and dres are the same values —
+        ONE tensor is written and returned for both."""
         n, d = x.shape
         dev = x.device
         dx = torch.empty_like(x)
-        dres = torch.empty_like(res) if res is not None else None
+        shared = res is not None and float(a) == float(b)
+        dres = torch.empty_like(res) if (res is not None and not shared) else None
         dgamma = torch.empty(d, dtype=_F32, device=dev) if gamma is not None else None
         dbeta = torch.empty(d, dtype=_F32, device=dev) if gamma is not None else None
         ws = _workspace(dev, "ln", _lib.load().sgf_ln_bwd_workspace_bytes(n, d))
@@ -507,7 +510,7 @@ class HipKernels:
                       _ld(res), float(a), float(b), _ptr(gamma), int(relu), _ptr(mean), _ptr(rstd), n,
                       d, _code(x), _ptr(dx), _ld(dx), _ptr(dres), _ld(dres), _ptr(dgamma), _ptr(dbeta),
                       _ptr(ws), ws.numel(), _stream(dev))
-        return dx, dres, dgamma, dbeta
+        return dx, (dx if shared else dres), dgamma, dbeta
 
     # ---- T6 ----
     @staticmethod
@@ -719,6 +722,18 @@ class HipKernels:
             _lib.call("sgf_gcn_epilogue_dx", _ptr(dy), _ld(dy), _ptr(w), w.stride(0), n, d_in, d_out, _code(dy),
                       _ptr(dx), _ld(dx), _stream(dy.device))
         return dx
+
+    @staticmethod
+    def gcn_epilogue_dx2(dy, w1, w2, pair: bool = True):
+        """(dy w1, dy w2) for two [d, d] column blocks of one weight matrix, dy read from HBM once (paired launch)."""
+        n, d = dy.shape
+        dx1 = torch.empty((n, d), dtype=dy.dtype, device=dy.device)
+        dx2 = torch.empty((n, d), dtype=dy.dtype, device=dy.device)
+        assert w1.stride(0) == w2.stride(0)
+        with torch.cuda.device(dy.device):
+            _lib.call("sgf_gcn_epilogue_dx2", _ptr(dy), _ld(dy), _ptr(w1), _ptr(w2), w1.stride(0), n, d, _code(dy),
+                      _ptr(dx1), _ld(dx1), _ptr(dx2), _ld(dx2), int(pair), _stream(dy.device))
+        return dx1, dx2
 
     # ---- T7 ----
     @staticmethod

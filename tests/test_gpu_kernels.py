@@ -748,6 +748,25 @@ def test_gcn_epilogue_stats_and_dx(cuda, n, d):
     assert bool((errdx <= 2.0 ** -8 * refdx.abs() + 1e-6).all())
 
 
+@pytest.mark.parametrize("n,d", [(100, 256), (4096, 256), (4097, 128), (70001, 256), (33000, 64)])
+def test_gcn_epilogue_dx2_paired_launch(cuda, n, d):
+    """Both input gradients of W [a1 | a2] (large/ours.py:36-38) from one launch whose workgroups come in pairs on one XCD
+    (sgf_gcn_epilogue_dx2): bit-identical to the two separate sgf_gcn_epilogue_dx launches, and dy W[:, d:] against fp64
+    of the same bf16 operands within one bf16 rounding.  n covers: too few tiles to pair (falls back), whole groups of
+    pairs, a ragged last tile."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    dy = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(d, 2 * d, generator=g) / d ** 0.5).bfloat16().to(cuda)
+    a1, a2 = ops.K.gcn_epilogue_dx2(dy, w[:, :d], w[:, d:], pair=True)
+    b1, b2 = ops.K.gcn_epilogue_dx2(dy, w[:, :d], w[:, d:], pair=False)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert torch.equal(b1, ops.K.gcn_epilogue_dx(dy, w[:, :d]))
+    ref = dy.double().cpu() @ w[:, d:].double().cpu()
+    err = (a2.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all())
+
+
 @pytest.mark.parametrize("n,d_in,d_out", [(3001, 256, 256), (517, 128, 256), (1000, 100, 64), (333, 256, 40), (5, 64, 64),
                                           (2111, 128, 128)])
 def test_linear_f32_stats_dx_and_cat(cuda, n, d_in, d_out):

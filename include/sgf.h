@@ -574,6 +574,17 @@ int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw
 int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, const void* res, int64_t ldr, int32_t relu, int64_t n, int32_t d,
                            int32_t dtype, void* out, int64_t ldo, void* stream);
+/* The same two-operand Linear in ONE pass over a1 and a2 (bf16 storage, d = d_in = d_out in {64, 128, 256}; W [d, 2 d]):
+ *   y = [a1 | a2] W^T + bias  [+ stats, as sgf_gcn_epilogue_stats].   d <= 128: W (64 KiB) is resident in LDS whole.
+ *   d = 256: W is 256 KiB, more than a CU's LDS, so the launch is PAIRED — workgroups b and b + 8 (one XCD) walk the same
+ *   row tiles, each producing one half of the output columns from its 128 rows of W; the second read of a tile is served
+ *   by the XCD's L2.  Placement and timing affect only the traffic, never the result.  Rounding: the sum of both products
+ *   is rounded ONCE (sgf_gcn_epilogue_partial / _stats_add round the first product to the storage dtype first).
+ * workspace: sgf_gcn_epilogue_workspace_bytes(n, d), only when stats != null. */
+int32_t sgf_gcn_epilogue_cat_supported(int32_t d, int32_t dtype);
+int sgf_gcn_epilogue_cat(const void* a1, int64_t lda1, const void* a2, int64_t lda2, const void* w, int64_t ldw,
+                         const float* bias, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy, const float* shift,
+                         float* stats, void* workspace, size_t workspace_bytes, void* stream);
 size_t sgf_gcn_epilogue_partial_bytes(int64_t n, int32_t d_out);
 size_t sgf_gcn_epilogue_dtype_partial_bytes(int64_t n, int32_t d_out, int32_t dtype);   /* fp32 storage: n * d_out * 4 */
 int sgf_gcn_epilogue_partial(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t n,

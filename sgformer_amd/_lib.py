@@ -130,6 +130,9 @@ SIGNATURES = {
                                        c_int32, _P]),
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
+    "sgf_gcn_epilogue_cat_supported": (c_int32, [c_int32, c_int32]),
+    "sgf_gcn_epilogue_cat": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64,
+                                       _P, _P, _P, c_size_t, _P]),
     "sgf_gcn_epilogue_partial_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_gcn_epilogue_dtype_partial_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sgf_gcn_epilogue_partial": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, _P,

@@ -296,6 +296,188 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The two-operand Linear  y = [a1 | a2] W^T + bias  (GraphConvLayer with use_init, large/ours.py:36-38) in ONE pass
+// (+ BatchNorm's column sums).  The contraction runs over 2 D indices, so W is [D, 2 D]:
+//   D <= 128: 64 KiB — one block holds all of it, a wave multiplies a1's tile, then a2's tile into the same accumulators;
+//   D = 256 : 256 KiB, more than a CU's LDS — the launch is PAIRED: blocks b and b + 8 (one XCD under the observed
+//             b % 8 placement) walk the same row tiles, each holding the 128 rows of W that produce ITS half of the output
+//             columns (ROLES = 2).  Both read the a1 / a2 tiles; whichever runs behind finds them in the XCD's L2 (and
+//             catches up: its loads return sooner), so the operands leave HBM once.  Correctness does not depend on the
+//             placement or on the timing — only the traffic does.
+// Per tile a wave keeps all NS accumulators of its role live (K-outer order): a1's 16 k-steps, then the load of the NEXT
+// tile's a1 rows into the registers just freed, a2's k-steps, the load of the next a2 tile, epilogue as in k_rowgemm_bf16.
+struct RowGemm2Args {
+  const uint16_t* a1; int64_t lda1;
+  const uint16_t* a2; int64_t lda2;
+  const uint16_t* w; int64_t ldw;                      // [D, 2 D] row-major (row j = output column j)
+  const float* bias;                                   // [D] or null
+  const float* shift;                                  // [D] or null (statistics only)
+  float* spart;                                        // [virtual blocks][2][D] statistics partials, or null
+  uint16_t* y; int64_t ldy;
+  int64_t n;
+};
+
+template <int D, int ROLES, bool STATS>
+__global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm2_bf16(RowGemm2Args p) {
+  constexpr int KS = D / 16;                           // k-steps per operand
+  constexpr int DC = D / ROLES;                        // output columns of one role
+  constexpr int NS = DC / 32;                          // 32-column strips of one role
+  constexpr int BT = 2 * D * 2 + 16;                   // bytes per row of B^T = W[j][0 .. 2 D) (+ one 16-byte slot of skew)
+  static_assert(NS % 2 == 0, "strips are drained in pairs");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[DC * BT + kRgWaves * kStageBytes + 2 * DC * 4];
+  unsigned char* const ldsB = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const stg = lds + DC * BT + wave * kStageBytes;
+  float* const cvec = reinterpret_cast<float*>(lds + DC * BT + kRgWaves * kStageBytes);   // [bias | shift] of this role
+  const int role = ROLES == 2 ? (blockIdx.x >> 3) & 1 : 0;
+  const int64_t vblock = ROLES == 2 ? (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3) : blockIdx.x;
+  const int64_t vgrid = ROLES == 2 ? gridDim.x / 2 : gridDim.x;
+  const int c0 = role * DC;                            // first output column of this role
+
+  // ---- this role's rows of W -> LDS, once ----
+  {
+    constexpr int CH = 2 * D / 8;                      // 16-byte chunks per row
+    for (int c = tid; c < DC * CH; c += kRgThreads) {
+      const int j = c / CH, q = c % CH;
+      *reinterpret_cast<uint4*>(ldsB + j * BT + 16 * q) =
+          *reinterpret_cast<const uint4*>(p.w + static_cast<int64_t>(c0 + j) * p.ldw + 8 * q);
+    }
+  }
+  for (int c = tid; c < DC; c += kRgThreads) {
+    cvec[c] = p.bias ? p.bias[c0 + c] : 0.f;
+    cvec[DC + c] = (STATS && p.shift) ? p.shift[c0 + c] : 0.f;
+  }
+  __syncthreads();
+
+  float s1[NS], s2[NS];
+#pragma unroll
+  for (int w = 0; w < NS; ++w) {
+    s1[w] = 0.f;
+    s2[w] = 0.f;
+  }
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = vgrid * kRgWaves;
+  auto load_tile = [&](const uint16_t* base, int64_t ld, int64_t t, bf16x8 (&dst)[KS]) {
+    int64_t row = t * 32 + i31;
+    if (row >= p.n) row = p.n - 1;                     // ragged end: any valid row; its results are masked
+    const uint16_t* src = base + row * ld + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+  };
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+
+  bf16x8 bufa[KS], bufb[KS];
+  int64_t t = vblock * kRgWaves + wave;
+  if (t < ntiles) {
+    load_tile(p.a1, p.lda1, t, bufa);
+    load_tile(p.a2, p.lda2, t, bufb);
+  }
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    f32x16 acc[NS];
+#pragma unroll
+    for (int w = 0; w < NS; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int w = 0; w < NS; ++w) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bufa[s], b, acc[w], 0, 0, 0);
+      }
+    if (tn < ntiles) load_tile(p.a1, p.lda1, tn, bufa);            // into the registers the loop above has just read
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int w = 0; w < NS; ++w) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 2 * D + 32 * s);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bufb[s], b, acc[w], 0, 0, 0);
+      }
+    if (tn < ntiles) load_tile(p.a2, p.lda2, tn, bufb);
+
+    uint16_t* const yrow = p.y + (row0 + (lane >> 3)) * p.ldy + c0 + 8 * (lane & 7);
+#pragma unroll
+    for (int u = 0; u < NS / 2; ++u) {
+      float bias_c[2], shift_c[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bias_c[c] = cvec[32 * (2 * u + c) + i31];
+        shift_c[c] = STATS ? cvec[DC + 32 * (2 * u + c) + i31] : 0.f;
+      }
+      // accumulator register r of lane (i31, hi): row (r & 3) + 8 (r >> 2) + 4 hi, column 32 w + i31.
+      // Rows 0-15 are registers 0-7, rows 16-31 registers 8-15: two passes through the 16-row patch.
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        uint32_t pk[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+            const uint32_t v = cvt_pk_bf16(acc[2 * u + c][r] + bias_c[c], acc[2 * u + c][r + 1] + bias_c[c]);
+            const int rl = (r & 3) + 8 * ((r >> 2) & 1);                 // row inside the patch (+ 4 hi in st_w)
+            *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+            pk[c][(r >> 1) & 3] = v;
+          }
+        }
+        if (STATS) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int64_t ra = row0 + 16 * hh + ((2 * q) & 3) + 8 * (q >> 1) + 4 * hi;
+              const float v0 = (!tail || ra < p.n) ? __uint_as_float(pk[c][q] << 16) - shift_c[c] : 0.f;
+              const float v1 = (!tail || ra + 1 < p.n) ? __uint_as_float(pk[c][q] & 0xffff0000u) - shift_c[c] : 0.f;
+              s1[2 * u + c] += v0 + v1;
+              s2[2 * u + c] = fmaf(v0, v0, fmaf(v1, v1, s2[2 * u + c]));
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
+            *reinterpret_cast<uint4*>(yrow + (16 * hh + 8 * q) * p.ldy + 64 * u) = v;
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+
+  if (STATS) {
+    __syncthreads();                                   // every wave is done with its staging patch
+    static_assert(kRgWaves * 2 * DC * 4 <= kRgWaves * kStageBytes, "reduction scratch must fit the staging patches");
+    float* const redb = reinterpret_cast<float*>(lds + DC * BT);   // [wave][2][DC]
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      const float a1s = s1[w] + __shfl_xor(s1[w], 32, 64);
+      const float a2s = s2[w] + __shfl_xor(s2[w], 32, 64);
+      if (hi == 0) {
+        redb[(wave * 2 + 0) * DC + 32 * w + i31] = a1s;
+        redb[(wave * 2 + 1) * DC + 32 * w + i31] = a2s;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * DC; c += kRgThreads) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < kRgWaves; ++v) s += redb[v * 2 * DC + c];
+      p.spart[vblock * 2 * D + (c / DC) * D + c0 + (c % DC)] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same skeleton for the attention-from-input apply passes (include/sgf.h, sgf_attn_h_fwd / sgf_attn_h_bwd_apply;
 // large/ours.py:130-151 with the projections folded into d x d matrices): a streamed [n, d] operand times a resident
 // d x d matrix, with PER-ROW scalars in the epilogue.  In the accumulator layout a lane's 16 registers are 16 rows, so
@@ -887,7 +1069,8 @@ extern "C" int32_t sgf_gcn_epilogue_supported(int32_t d_in, int32_t d_out, int32
 
 extern "C" size_t sgf_gcn_epilogue_workspace_bytes(int64_t n, int32_t d_out) {
   if (n < 0 || d_out <= 0) return 0;
-  const int b = grid_blocks(n) > linear_f32_blocks(n) ? grid_blocks(n) : linear_f32_blocks(n);
+  int b = grid_blocks(n) > linear_f32_blocks(n) ? grid_blocks(n) : linear_f32_blocks(n);
+  if (b < 8) b = 8;                                    // a paired launch runs whole groups of 8 pairs
   return static_cast<size_t>(b) * 2 * static_cast<size_t>(d_out) * sizeof(float);
 }
 
@@ -969,6 +1152,57 @@ extern "C" int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1
                    static_cast<const uint16_t*>(w2), static_cast<uint16_t*>(dx2), lddx2, 1};
   const int pairs = grid_blocks(n) / 16 * 8;          // whole groups of 8 pairs = 16 consecutive blocks
   return launch_rowgemm<false, 0>(args, d, 2 * pairs, st);
+}
+
+// ---- the two-operand Linear in ONE pass (paired launch at d = 256) ---------------------------------------------------
+extern "C" int32_t sgf_gcn_epilogue_cat_supported(int32_t d, int32_t dtype) {
+  return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) ? 1 : 0;
+}
+
+extern "C" int sgf_gcn_epilogue_cat(const void* a1, int64_t lda1, const void* a2, int64_t lda2, const void* w, int64_t ldw,
+                                    const float* bias, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,
+                                    const float* shift, float* stats, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  const char* fn = "sgf_gcn_epilogue_cat";
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
+  SGF_REQUIRE(sgf_gcn_epilogue_cat_supported(d, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, d in {64, 128, 256} (got d = %d, dtype %d)", fn, d, dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (stats) SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * static_cast<size_t>(d) * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(a1 && a2 && w && y, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(lda1 >= d && lda2 >= d && ldy >= d && ldw >= 2 * d, SGF_E_INVALID, "%s: leading dimension smaller than the width", fn);
+  SGF_REQUIRE(rows16(a1, lda1) && rows16(a2, lda2) && rows16(w, ldw) && rows16(y, ldy), SGF_E_INVALID,
+              "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
+  const int roles = d == 256 ? 2 : 1;
+  int vblocks = grid_blocks(n);
+  if (roles == 2) {                                    // whole groups of 8 pairs = 16 consecutive blocks
+    vblocks = (vblocks + 1) / 2;
+    vblocks = (vblocks + 7) / 8 * 8;
+    if (vblocks > kNumCU / 2) vblocks = kNumCU / 2;
+  }
+  RowGemm2Args args{static_cast<const uint16_t*>(a1), lda1, static_cast<const uint16_t*>(a2), lda2,
+                    static_cast<const uint16_t*>(w), ldw, bias, shift, nullptr, static_cast<uint16_t*>(y), ldy, n};
+  if (stats) {
+    SGF_REQUIRE(workspace && workspace_bytes >= sgf_gcn_epilogue_workspace_bytes(n, d), SGF_E_WORKSPACE,
+                "%s: workspace %zu < %zu", fn, workspace_bytes, sgf_gcn_epilogue_workspace_bytes(n, d));
+    args.spart = static_cast<float*>(workspace);
+  }
+#define SGF_RG2(D_, R_)                                                                                                 \
+  if (stats) hipLaunchKernelGGL((k_rowgemm2_bf16<D_, R_, true>), dim3(vblocks * R_), dim3(kRgThreads), 0, st, args);     \
+  else hipLaunchKernelGGL((k_rowgemm2_bf16<D_, R_, false>), dim3(vblocks * R_), dim3(kRgThreads), 0, st, args)
+  if (d == 64) { SGF_RG2(64, 1); }
+  else if (d == 128) { SGF_RG2(128, 1); }
+  else { SGF_RG2(256, 2); }
+#undef SGF_RG2
+  SGF_LAUNCH_CHECK();
+  if (stats) {
+    hipLaunchKernelGGL(k_rowgemm_stats, dim3((2 * d + 63) / 64), dim3(256), 0, st, args.spart, vblocks, 2 * d, stats);
+    SGF_LAUNCH_CHECK();
+  }
+  return SGF_OK;
 }
 
 // ---- two-operand Linear  y = [a1 | a2] W^T + bias  (GraphConvLayer with use_init, large/ours.py:36-38) -------------

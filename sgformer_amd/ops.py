@@ -671,12 +671,24 @@ class HipKernels:
 
     @staticmethod
     def gcn_epilogue_cat(a1, a2, w, bias, shift=None, want_stats=False):
-        """y = [a1 | a2] w^T + bias (w [d, 2 d]) in two streaming passes: a1's product stays in the matrix cores'
-        accumulator layout (an opaque scratch buffer) and is added, unrounded-sum-wise, in a2's pass."""
+        """y = [a1 | a2] w^T + bias (w [d, 2 d]).  bf16, square blocks: ONE pass over a1 and a2 (sgf_gcn_epilogue_cat: W
+        resident in LDS for d <= 128, a paired launch for d = 256; SGF_GCN_CAT=0 keeps the two-pass form).  Otherwise two
+        streaming passes: a1's product stays in the matrix cores' accumulator layout (an opaque scratch buffer) and is
+        added in a2's pass."""
         n, d1 = a1.shape
         d2, d = a2.shape[1], w.shape[0]
         dev = a1.device
         lib = _lib.load()
+        if (a1.dtype == _BF16 and d1 == d2 == d and _one_pass_cat() and lib.sgf_gcn_epilogue_cat_supported(d, _lib.SGF_BF16)
+                and w.stride(1) == 1 and w.shape[1] == 2 * d):
+            y = torch.empty((n, d), dtype=a1.dtype, device=dev)
+            stats = torch.empty(2 * d, dtype=_F32, device=dev) if want_stats else None
+            ws = _workspace(dev, "gcn_epi", lib.sgf_gcn_epilogue_workspace_bytes(n, d)) if want_stats else None
+            with torch.cuda.device(dev):
+                _lib.call("sgf_gcn_epilogue_cat", _ptr(a1), _ld(a1), _ptr(a2), _ld(a2), _ptr(w), w.stride(0), _ptr(bias), n,
+                          d, _code(a1), _ptr(y), _ld(y), _ptr(shift), _ptr(stats), _ptr(ws),
+                          0 if ws is None else ws.numel(), _stream(dev))
+            return y, stats
         part = _workspace(dev, "gcn_part", lib.sgf_gcn_epilogue_dtype_partial_bytes(n, d, _code(a1)))
         y = torch.empty((n, d), dtype=a1.dtype, device=dev)
         stats = torch.empty(2 * d, dtype=_F32, device=dev) if want_stats else None
@@ -744,6 +756,11 @@ class HipKernels:
             _lib.call("sgf_axpby", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), n, d,
                       _code(x1), _ptr(y), y.stride(0), _stream(x1.device))
         return y
+
+
+def _one_pass_cat() -> bool:
+    import os
+    return os.environ.get("SGF_GCN_CAT", "1") != "0"
 
 
 K = HipKernels()

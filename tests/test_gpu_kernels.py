@@ -912,12 +912,47 @@ def test_linear_bn_stats_matches_unfused(cuda, n, d):
     assert float((m2 - mean).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max())) and _rel(var, v2) <= 1e-5
 
 
-@pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (1000, 128), (20001, 256)])
-def test_gcn_epilogue_two_operands(cuda, n, d):
-    """GraphConvLayer with use_init, large/ours.py:36-38: y = [a1 | a2] W^T + b in two streaming passes with the first
-    product kept in the accumulator layout.  Reference on the host in fp64: first product rounded to bf16 (what the
-    partial buffer stores), the sum rounded once; statistics of the returned y; both input gradients."""
+@pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (255, 256), (1000, 128), (4096, 256), (20001, 256), (70003, 256), (9000, 64)])
+def test_gcn_epilogue_cat_one_pass(cuda, n, d):
+    """GraphConvLayer with use_init, large/ours.py:36-38: y = [a1 | a2] W^T + b in ONE pass (sgf_gcn_epilogue_cat: W resident
+    for d <= 128, a PAIRED launch — two workgroups per row tile, one per half of the output columns — for d = 256).  Against
+    fp64 on the host of the same bf16 operands: the sum of both products rounded ONCE; statistics = fp64 column sums of the
+    returned y; run-to-run identical.  n covers fewer tiles than paired blocks, ragged last tiles, many tiles per wave."""
     from sgformer_amd import ops
+    g = torch.Generator().manual_seed(11 * n + d)
+    a1 = torch.randn(n, d, generator=g).bfloat16()
+    a2 = torch.randn(n, d, generator=g).bfloat16()
+    w = (torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5).bfloat16()
+    bias = torch.randn(d, generator=g)
+    shift = torch.randn(d, generator=g) * 0.1
+    y, st = ops.K.gcn_epilogue_cat(a1.to(cuda), a2.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
+    ref = torch.cat([a1, a2], 1).double() @ w.double().t() + bias.double()
+    err = (y.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), float((err - 2.0 ** -8 * ref.abs()).max())
+    v = y.double().cpu() - shift.double()
+    st_ref = torch.cat([v.sum(0), (v * v).sum(0)])
+    tolst = 2e-6 * torch.cat([v.abs().sum(0), (v * v).sum(0)]).clamp_min(1e-3)
+    assert bool(((st.double().cpu() - st_ref).abs() <= tolst).all())
+    y2, none = ops.K.gcn_epilogue_cat(a1.to(cuda), a2.to(cuda), w.to(cuda), bias.to(cuda))
+    assert none is None and torch.equal(y, y2)
+    y3, st3 = ops.K.gcn_epilogue_cat(a1.to(cuda), a2.to(cuda), w.to(cuda), bias.to(cuda), shift.to(cuda), want_stats=True)
+    assert torch.equal(y, y3) and torch.equal(st, st3)
+    # strided operands (column slices of wider buffers), no bias / shift
+    wide = torch.randn(n, 2 * d + 8, generator=g).bfloat16().to(cuda)
+    b1, b2 = wide[:, :d], wide[:, d + 8:]
+    y4, st4 = ops.K.gcn_epilogue_cat(b1, b2, w.to(cuda), None, None, want_stats=True)
+    ref4 = torch.cat([b1, b2], 1).double().cpu() @ w.double().t()
+    assert bool(((y4.double().cpu() - ref4).abs() <= 2.0 ** -8 * ref4.abs() + 1e-6).all())
+    assert _rel(st4[:d], y4.double().sum(0)) <= 2e-6 or float(y4.double().sum(0).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (1000, 128), (20001, 256)])
+def test_gcn_epilogue_two_operands(cuda, n, d, monkeypatch):
+    """The two-pass form (SGF_GCN_CAT=0; also what fp32 storage runs): y = [a1 | a2] W^T + b in two streaming passes with
+    the first product kept in the accumulator layout.  Reference on the host in fp64: first product rounded to bf16 (what
+    the partial buffer stores), the sum rounded once; statistics of the returned y; both input gradients."""
+    from sgformer_amd import ops
+    monkeypatch.setenv("SGF_GCN_CAT", "0")
     g = torch.Generator().manual_seed(7 * n + d)
     a1 = torch.randn(n, d, generator=g).bfloat16()
     a2 = torch.randn(n, d, generator=g).bfloat16()

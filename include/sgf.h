@@ -454,6 +454,12 @@ size_t sgf_gram_workspace_bytes(int64_t n, int32_t m, int32_t k);
 int sgf_gram(const void* a, int64_t lda, int32_t m, const void* b, int64_t ldb, int32_t k,
              int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum_a, void* workspace,
              size_t workspace_bytes, void* stream);
+/* Two such products that share a — c1 = a^T b1, c2 = a^T b2 (dW of the two-operand Linear: a = dz, b1 = Ax, b2 = x0) — in ONE
+ * paired launch (bf16 storage, m, k <= 256): workgroups b and b + 8 (one XCD) walk the same row tiles, a's second read is an
+ * L2 hit.  Other shapes / fp32: two sgf_gram launches.  Same workspace as sgf_gram; colsum_a as there. */
+int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, int64_t ldb1, const void* b2, int64_t ldb2, int32_t k,
+              int64_t n, int32_t dtype, float* c1, int64_t ldc1, float* c2, int64_t ldc2, float* colsum_a, void* workspace,
+              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T5 — TransConv glue.   Replaces large/ours.py:198-202 and :210-216 (medium/ours.py:150-156,
@@ -574,6 +580,24 @@ int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw
 int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, const void* res, int64_t ldr, int32_t relu, int64_t n, int32_t d,
                            int32_t dtype, void* out, int64_t ldo, void* stream);
+/* Backward of the GCN layer's dense half in ONE launch (large/ours.py:36-40 + :87-93 differentiated; bf16 storage,
+ * d in {64, 128, 256}).  Forward:  z = [Ax | x0] W^T + b,  out = [relu](BatchNorm(z)) [+ x0].  Given gy = d out, z, the
+ * BatchNorm coefficients and the reduced statistics stats = [sum g' | sum g' xhat] of sgf_bn_bwd_stats:
+ *     dz    = sgf_bn_bwd_apply(gy, z, ...)                 written row-major (the weight gradients read it: sgf_gram)
+ *     dy    = dz W[:, :d]                                  gradient of Ax, row-major
+ *     dx0'  = dx0 + dz W[:, d:] (+ gy when add_gy)         gradient of x0, ACCUMULATED over the layers of the branch:
+ * acc_in (null for the first call) / acc_out are opaque buffers of sgf_gcn_epilogue_partial_bytes(n, d) holding the running
+ * sum in the matrix cores' accumulator layout (bf16); the LAST call passes dx0 != null (and acc_out = null) and gets the
+ * total row-major.  Exactly one of acc_out / dx0 is non-null.  gy and z leave HBM once: the workgroups that produce the
+ * 2 d virtual output columns of one row tile (128 columns each) are launched 8 apart, i.e. on one XCD, and share the tiles
+ * through its L2 (placement affects traffic only).  inv_n = 1 / (global row count); training = 0: running statistics (no
+ * mean terms). */
+int32_t sgf_gcn_bn_bwd_dx_supported(int32_t d, int32_t dtype);
+int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,
+                      int32_t training, const void* w, int64_t ldw, int64_t n, int32_t d, int32_t dtype, void* dz,
+                      int64_t lddz, void* dy, int64_t lddy, const void* acc_in, void* acc_out, size_t acc_bytes,
+                      void* dx0, int64_t lddx0, int32_t add_gy, void* stream);
 /* The same two-operand Linear in ONE pass over a1 and a2 (bf16 storage, d = d_in = d_out in {64, 128, 256}; W [d, 2 d]):
  *   y = [a1 | a2] W^T + bias  [+ stats, as sgf_gcn_epilogue_stats].   d <= 128: W (64 KiB) is resident in LDS whole.
  *   d = 256: W is 256 KiB, more than a CU's LDS, so the launch is PAIRED — workgroups b and b + 8 (one XCD) walk the same

@@ -93,6 +93,8 @@ SIGNATURES = {
     "sgf_gram_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sgf_gram": (c_int32, [_P, c_int64, c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P,
                            _P, c_size_t, _P]),
+    "sgf_gram2": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P,
+                            c_int64, _P, _P, c_size_t, _P]),
     "sgf_ln_fwd": (c_int32, [_P, c_int64, _P, c_int64, c_float, c_float, _P, _P, c_int32, c_float,
                              c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     "sgf_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
@@ -130,6 +132,10 @@ SIGNATURES = {
                                        c_int32, _P]),
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
+    "sgf_gcn_bn_bwd_dx_supported": (c_int32, [c_int32, c_int32]),
+    "sgf_gcn_bn_bwd_dx": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float, c_int32, _P, c_int64,
+                                    c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, _P, c_size_t, _P, c_int64,
+                                    c_int32, _P]),
     "sgf_gcn_epilogue_cat_supported": (c_int32, [c_int32, c_int32]),
     "sgf_gcn_epilogue_cat": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64,
                                        _P, _P, _P, c_size_t, _P]),

@@ -68,6 +68,9 @@ struct ReduceArgs {
   int32_t db;                 // valid columns of operand b (= d except for sgf_gram)
   float gscale;               // bwd: 1/H
   float* partial;             // [gridDim.x * heads][kPartialStride]
+  // kModeGram, PAIRED launch (pair != 0, bf16): blocks b and b + 8 (one XCD) walk the same row tiles, one multiplying with
+  // b, the other with b2 — A leaves HBM once, its second read is served by the XCD's L2.  Partials: [role][virtual block].
+  const void* b2; int64_t ldb2; int32_t pair;
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -665,6 +668,15 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   const bool a_ok = c0 < p.d;
   const bool b_ok = c0 < p.db;
 
+  // paired Gram launch: role 1 multiplies with b2; both roles of a pair walk the same tiles
+  const bool paired = MODE == kModeGram && p.pair != 0;
+  const int role = paired ? (blockIdx.x >> 3) & 1 : 0;
+  const int64_t vblock = paired ? (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3) : blockIdx.x;
+  const int64_t vgrid = paired ? gridDim.x / 2 : gridDim.x;
+  if (role) {
+    p.b = p.b2;
+    p.ldb = p.ldb2;
+  }
   const uint16_t* pa = static_cast<const uint16_t*>(p.a) + static_cast<int64_t>(head) * p.d + c0;
   const uint16_t* pb = static_cast<const uint16_t*>(p.b) +
                        (p.b_heads == 1 ? 0 : static_cast<int64_t>(head) * p.d) + c0;
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   };
 
   static_assert(SPG % NPASS == 0, "k-steps must split evenly over the staging passes");
-  int64_t tile = blockIdx.x;
+  int64_t tile = vblock;
   int buf = 0;
   if (tile < ntiles) {
 #pragma unroll
@@ -786,8 +798,8 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   __syncthreads();
   const int ca0 = 64 * wm + i31, ca1 = ca0 + 32;
   const int cb0 = BN * wd + i31;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int64_t next = tile + gridDim.x;
+  for (; tile < ntiles; tile += vgrid) {
+    const int64_t next = tile + vgrid;
     const bool has_next = next < ntiles;
     const unsigned char* ta = lds + buf * 2 * OPB;
     const unsigned char* tb = ta + OPB;
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   }
 
   // ---- this block's partial, same layout as k_attn_reduce: [grp][m][dd] | colsum[DP] | ssq ----
-  float* part = p.partial + (static_cast<int64_t>(head) * gridDim.x + blockIdx.x) * kPartialStride;
+  float* part = p.partial + ((static_cast<int64_t>(head) + role) * vgrid + vblock) * kPartialStride;
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1209,6 +1221,49 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
   return SGF_OK;
 }
 }  // namespace
+
+// Two Gram products that share A in ONE paired launch (bf16 storage, m, k <= 256): c1 = a^T b1, c2 = a^T b2.
+extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, int64_t ldb1, const void* b2, int64_t ldb2,
+                         int32_t k, int64_t n, int32_t dtype, float* c1, int64_t ldc1, float* c2, int64_t ldc2,
+                         float* colsum_a, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_gram2";
+  SGF_REQUIRE(n >= 0 && m >= 1 && k >= 1, SGF_E_INVALID, "%s: bad sizes n=%lld m=%d k=%d", fn, static_cast<long long>(n), m, k);
+  SGF_REQUIRE(m % 4 == 0 && k % 4 == 0, SGF_E_UNSUPPORTED, "%s: m and k must be multiples of 4 (m=%d k=%d)", fn, m, k);
+  SGF_REQUIRE(dtype == SGF_F32 || dtype == SGF_BF16, SGF_E_INVALID, "%s: unknown dtype %d", fn, dtype);
+  SGF_REQUIRE(c1 && c2 && ldc1 >= k && ldc2 >= k, SGF_E_INVALID, "%s: null c or ldc < k", fn);
+  const int R = dtype == SGF_BF16 && m <= 256 && k <= 256
+                    ? reduce_rows_per_tile<uint16_t, kModeGram>(padded_dim(m > k ? m : k)) : 1;
+  const int64_t ntiles = (n + R - 1) / R;
+  if (dtype != SGF_BF16 || m > 256 || k > 256 || ntiles < 16) {     // nothing to pair: two plain products
+    int rc = sgf_gram(a, lda, m, b1, ldb1, k, n, dtype, c1, ldc1, colsum_a, workspace, workspace_bytes, stream);
+    if (rc != SGF_OK) return rc;
+    return sgf_gram(a, lda, m, b2, ldb2, k, n, dtype, c2, ldc2, nullptr, workspace, workspace_bytes, stream);
+  }
+  SGF_REQUIRE(a && b1 && b2, SGF_E_INVALID, "%s: null operand", fn);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE, "%s: workspace too small", fn);
+  SGF_REQUIRE(aligned4<uint16_t>(a, lda) && aligned4<uint16_t>(b1, ldb1) && aligned4<uint16_t>(b2, ldb2), SGF_E_INVALID,
+              "%s: a / b must be 4-element aligned with ld %% 4 == 0", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int DP = padded_dim(m > k ? m : k);
+  int64_t pairs = ntiles / 2 < kMaxBlocks / 2 ? ntiles / 2 : kMaxBlocks / 2;
+  pairs = pairs / 8 * 8;                               // whole groups of 8 pairs = 16 consecutive blocks (>= 8: ntiles >= 16)
+  ReduceArgs r{};
+  r.a = a; r.lda = lda; r.b = b1; r.ldb = ldb1; r.b2 = b2; r.ldb2 = ldb2; r.pair = 1;
+  r.q = nullptr; r.ldq = 0; r.den = nullptr;
+  r.n = n; r.d = m; r.db = k; r.heads = 1; r.b_heads = 1; r.gscale = 1.f;
+  r.partial = static_cast<float*>(workspace);
+  int rc = launch_reduce<uint16_t, kModeGram>(r, DP, static_cast<int>(2 * pairs), st);
+  if (rc != SGF_OK) return rc;
+  const int RG = reduce_row_groups<uint16_t, kModeGram>(DP);
+  const int64_t len = static_cast<int64_t>(m) * k + m;
+  const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+  hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, r.partial, static_cast<int>(pairs), m, k, DP, RG, c1, ldc1,
+                     colsum_a);
+  hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, r.partial + pairs * kPartialStride, static_cast<int>(pairs),
+                     m, k, DP, RG, c2, ldc2, static_cast<float*>(nullptr));
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
 
 extern "C" size_t sgf_gram_workspace_bytes(int64_t n, int32_t m, int32_t k) {
   (void)n; (void)m; (void)k;

@@ -478,6 +478,276 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm2_bf16(RowGemm2Args p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Backward of the GCN layer's dense half in ONE launch (large/ours.py:36-40 + :87-93 differentiated):
+//     out = relu(BatchNorm(z)) + x0,   z = [Ax | x0] W^T + b          (forward)
+//     dz  = BatchNorm'(relu'(gy))                                       (sgf_bn_bwd_apply's arithmetic, from gy, z and the
+//                                                                        reduced statistics [sum g' | sum g' xhat])
+//     d[Ax] = dz W[:, :D],     dx0 += gy + dz W[:, D:]                  (both input gradients + the residual's)
+// gy and z are read in matrix-core A-fragment layout, dz is formed in registers per k-step and multiplied right away
+// (K-outer order: all accumulators of a block live, the fragment registers of step s re-loaded with the NEXT tile's step s
+// as soon as they have been consumed — a full tile of gy and z in flight per wave at all times).  The virtual output
+// [d[Ax] | dx0] is 2 D columns wide and W is up to 256 KiB, so a block produces 128 virtual columns from its 128 columns of
+// W and the launch runs ROLES = 2 D / 128 blocks per row tile: blocks b, b + 8, (b + 16, b + 24) sit on one XCD under the
+// observed b % 8 placement and walk the same tiles, the XCD's L2 serves all but the first read of a tile.  The residual's
+// gradient gy enters dx0 through the matrix cores as well: gy's fragments times an identity fragment (exact).  dx0 is
+// ACCUMULATED across the layers of the branch (acc_in -> acc_out, bf16, kept in the matrix cores' accumulator layout — an
+// opaque buffer of sgf_gcn_epilogue_partial_bytes) and leaves row-major after the last one: the 8-stream gradient sum of
+// x0's consumers (k_sum_n<7>: 10 GB per step at ogbn-products scale) does not exist any more.
+struct BnBwdDxArgs {
+  const uint16_t* gy; int64_t ldg;
+  const uint16_t* z; int64_t ldz;
+  const float* mean; const float* rstd; const float* gamma; const float* beta;   // gamma / beta may be null
+  const float* stats; float inv_n; int training; int relu;                       // stats [2 D] (training only)
+  const uint16_t* w; int64_t ldw;                      // [D, 2 D] row-major
+  uint16_t* dz; int64_t lddz;                          // out, row-major
+  uint16_t* dy; int64_t lddy;                          // out, row-major: dz W[:, :D]
+  const uint4* acc_in;                                 // opaque running dx0, or null
+  uint4* acc_out;                                      // opaque running dx0 (when dx0 == null)
+  uint16_t* dx0; int64_t lddx0;                        // out, row-major (the last layer of the chain), or null
+  int add_gy;                                          // the layer has the residual  + x0
+  int64_t n;
+};
+
+template <int D, int ROLES>
+__global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
+  constexpr int KS = D / 16;                           // k-steps
+  constexpr int RING = KS > 8 ? 8 : KS;                // fragment slots per stream: step s lives in slot s % RING and is
+                                                       // re-loaded with step s + RING (of this tile or the next) once consumed
+  constexpr int NS = 4;                                // strips (of 32 virtual columns) per block
+  constexpr int NSD = D / 32;                          // strips of d[Ax] = strips of dx0
+  constexpr int BT = D * 2 + 16;                       // bytes per row of B^T
+  static_assert(ROLES * 128 == 2 * D, "a block produces 128 virtual columns");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * BT + kRgWaves * kStageBytes + 6 * D * 4];
+  unsigned char* const ldsB = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const stg = lds + 128 * BT + wave * kStageBytes;
+  float* const coef = reinterpret_cast<float*>(lds + 128 * BT + kRgWaves * kStageBytes);   // [mu | rs | ga | be | c0 | c1][D]
+  int role = 0;
+  int64_t vblock = blockIdx.x, vgrid = gridDim.x;
+  if (ROLES == 2) {
+    role = (blockIdx.x >> 3) & 1;
+    vblock = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);
+    vgrid = gridDim.x / 2;
+  } else if (ROLES == 4) {
+    role = (blockIdx.x >> 3) & 3;
+    vblock = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
+    vgrid = gridDim.x / 4;
+  }
+  const int v0 = role * 128;                           // first virtual column of this block
+  const int strip0 = v0 / 32;                          // its first virtual strip; strips >= NSD belong to dx0
+
+  // ---- B^T -> LDS: B^T[j][k] = W[k][v0 + j] (a row of W scattered down a column) ----
+  {
+    constexpr int CH = 128 / 8;
+    for (int c = tid; c < D * CH; c += kRgThreads) {
+      const int k = c / CH, q = c % CH;
+      const uint4 v = *reinterpret_cast<const uint4*>(p.w + static_cast<int64_t>(k) * p.ldw + v0 + 8 * q);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<uint16_t*>(ldsB + (8 * q + e) * BT + 2 * k) =
+            static_cast<uint16_t>(e & 1 ? u[e >> 1] >> 16 : u[e >> 1] & 0xffffu);
+    }
+  }
+  for (int c = tid; c < D; c += kRgThreads) {
+    coef[c] = p.mean[c];
+    coef[D + c] = p.rstd[c];
+    coef[2 * D + c] = p.gamma ? p.gamma[c] : 1.f;
+    coef[3 * D + c] = p.beta ? p.beta[c] : 0.f;
+    coef[4 * D + c] = p.training ? p.stats[c] * p.inv_n : 0.f;
+    coef[5 * D + c] = p.training ? p.stats[D + c] * p.inv_n : 0.f;
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = vgrid * kRgWaves;
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+  // identity fragments: B[k = 8 hi + e][j = i31] of the two k-steps that cover a strip's own 32 columns
+  bf16x8 ident[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ident[0][e] = static_cast<short>(i31 == 8 * hi + e ? 0x3f80 : 0);
+    ident[1][e] = static_cast<short>(i31 == 16 + 8 * hi + e ? 0x3f80 : 0);
+  }
+  // which k-steps of dz this block stores: the d[Ax] blocks share the columns of dz between them
+  constexpr int DYR = ROLES >= 2 ? ROLES / 2 : 1;      // blocks that produce d[Ax] strips only
+  const int ws0 = role < DYR ? role * (KS / DYR) : KS, ws1 = role < DYR ? (role + 1) * (KS / DYR) : KS;
+
+  bf16x8 G[RING], Z[RING];
+  int64_t t = vblock * kRgWaves + wave;
+  auto rowptr_of = [&](int64_t tt) {
+    int64_t row = tt * 32 + i31;
+    if (row >= p.n) row = p.n - 1;                     // ragged end: any valid row; its results are masked
+    return row;
+  };
+  if (t < ntiles) {
+    const int64_t row = rowptr_of(t);
+    const uint16_t* sg = p.gy + row * p.ldg + 8 * hi;
+    const uint16_t* sz = p.z + row * p.ldz + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+      G[s] = *reinterpret_cast<const bf16x8*>(sg + 16 * s);
+      Z[s] = *reinterpret_cast<const bf16x8*>(sz + 16 * s);
+    }
+  }
+  const bool has_dx0 = strip0 + NS > NSD;              // this block owns dx0 strips
+  uint4 accn[NS][2];                                   // the running dx0 of the tile about to be processed
+  auto load_acc = [&](int64_t tt) {
+#pragma unroll
+    for (int w = 0; w < NS; ++w)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        accn[w][q] = (strip0 + w >= NSD)
+                         ? p.acc_in[tt * (NSD * 2 * 64) + ((strip0 + w - NSD) * 2 + q) * 64 + lane]
+                         : make_uint4(0u, 0u, 0u, 0u);
+  };
+  if (has_dx0 && p.acc_in && t < ntiles) load_acc(t);
+
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    const bool has_next = tn < ntiles;
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    const int64_t rowc = rowptr_of(t), rown = has_next ? rowptr_of(tn) : 0;
+    const uint16_t* const cg = p.gy + rowc * p.ldg + 8 * hi;
+    const uint16_t* const cz = p.z + rowc * p.ldz + 8 * hi;
+    const uint16_t* const ng = p.gy + rown * p.ldg + 8 * hi;
+    const uint16_t* const nz = p.z + rown * p.ldz + 8 * hi;
+    uint16_t* const dzrow = p.dz + (row0 + i31) * p.lddz + 8 * hi;
+    const bool row_ok = row0 + i31 < p.n;
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      if (has_dx0 && p.acc_in && strip0 + w >= NSD) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t d4[4] = {accn[w][q].x, accn[w][q].y, accn[w][q].z, accn[w][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[w][8 * q + 2 * e] = __uint_as_float(d4[e] << 16);
+            acc[w][8 * q + 2 * e + 1] = __uint_as_float(d4[e] & 0xffff0000u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
+      }
+    }
+
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // ---- dz for columns 16 s + 8 hi .. + 7 of row i31 ----
+      const float* cf = coef + 16 * s + 8 * hi;
+      const int sl = s % RING;
+      const uint4 gq = *reinterpret_cast<const uint4*>(&G[sl]);
+      const uint4 zq = *reinterpret_cast<const uint4*>(&Z[sl]);
+      const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
+      uint32_t du[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 mu = *reinterpret_cast<const float4*>(cf + 4 * h);
+        const float4 rs = *reinterpret_cast<const float4*>(cf + D + 4 * h);
+        const float4 ga = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
+        const float4 be = *reinterpret_cast<const float4*>(cf + 3 * D + 4 * h);
+        const float4 k0 = *reinterpret_cast<const float4*>(cf + 4 * D + 4 * h);
+        const float4 k1 = *reinterpret_cast<const float4*>(cf + 5 * D + 4 * h);
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+        const float k0v[4] = {k0.x, k0.y, k0.z, k0.w}, k1v[4] = {k1.x, k1.y, k1.z, k1.w};
+        float dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t gw_ = gu[2 * h + (e >> 1)], zw_ = zu[2 * h + (e >> 1)];
+          float g = (e & 1) ? __uint_as_float(gw_ & 0xffff0000u) : __uint_as_float(gw_ << 16);
+          const float zv = (e & 1) ? __uint_as_float(zw_ & 0xffff0000u) : __uint_as_float(zw_ << 16);
+          const float xh = (zv - muv[e]) * rsv[e];
+          if (p.relu) g = (xh * gav[e] + bev[e]) > 0.f ? g : 0.f;
+          g -= k0v[e] + xh * k1v[e];                   // both zero when not training
+          dv[e] = gav[e] * rsv[e] * g;
+        }
+        du[2 * h] = cvt_pk_bf16(dv[0], dv[1]);
+        du[2 * h + 1] = cvt_pk_bf16(dv[2], dv[3]);
+      }
+      const uint4 dq = make_uint4(du[0], du[1], du[2], du[3]);
+      const bf16x8 dzs = *reinterpret_cast<const bf16x8*>(&dq);
+      if (s >= ws0 && s < ws1 && row_ok) *reinterpret_cast<uint4*>(dzrow + 16 * s) = dq;
+#pragma unroll
+      for (int w = 0; w < NS; ++w) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzs, b, acc[w], 0, 0, 0);
+      }
+      // the residual's gradient: gy's own columns of dx0 strip (s >> 1), added through an identity fragment
+      if (has_dx0 && p.add_gy) {
+#pragma unroll
+        for (int w = 0; w < NS; ++w)
+          if (strip0 + w - NSD == (s >> 1))
+            acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[sl], ident[s & 1], acc[w], 0, 0, 0);
+      }
+      if (s + RING < KS) {                             // step s + RING of this tile into the slot just consumed
+        G[sl] = *reinterpret_cast<const bf16x8*>(cg + 16 * (s + RING));
+        Z[sl] = *reinterpret_cast<const bf16x8*>(cz + 16 * (s + RING));
+      } else if (has_next) {                           // ... or step s + RING - KS of the NEXT tile
+        G[sl] = *reinterpret_cast<const bf16x8*>(ng + 16 * (s + RING - KS));
+        Z[sl] = *reinterpret_cast<const bf16x8*>(nz + 16 * (s + RING - KS));
+      }
+    }
+    if (has_dx0 && p.acc_in && has_next) load_acc(tn);
+
+    // ---- epilogue: strips leave in pairs ----
+#pragma unroll
+    for (int u = 0; u < NS / 2; ++u) {
+      const bool is_dx0 = strip0 + 2 * u >= NSD;       // pairs never straddle the boundary (NSD is even)
+      if (is_dx0 && p.dx0 == nullptr) {                // running sum stays in accumulator layout
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            uint4 v;
+            v.x = cvt_pk_bf16(acc[2 * u + c][8 * q + 0], acc[2 * u + c][8 * q + 1]);
+            v.y = cvt_pk_bf16(acc[2 * u + c][8 * q + 2], acc[2 * u + c][8 * q + 3]);
+            v.z = cvt_pk_bf16(acc[2 * u + c][8 * q + 4], acc[2 * u + c][8 * q + 5]);
+            v.w = cvt_pk_bf16(acc[2 * u + c][8 * q + 6], acc[2 * u + c][8 * q + 7]);
+            p.acc_out[t * (NSD * 2 * 64) + ((strip0 + 2 * u + c - NSD) * 2 + q) * 64 + lane] = v;
+          }
+        continue;
+      }
+      uint16_t* const orow = is_dx0
+                                 ? p.dx0 + (row0 + (lane >> 3)) * p.lddx0 + 32 * (strip0 + 2 * u - NSD) + 8 * (lane & 7)
+                                 : p.dy + (row0 + (lane >> 3)) * p.lddy + 32 * (strip0 + 2 * u) + 8 * (lane & 7);
+      const int64_t ldo = is_dx0 ? p.lddx0 : p.lddy;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+            const uint32_t v = cvt_pk_bf16(acc[2 * u + c][r], acc[2 * u + c][r + 1]);
+            const int rl = (r & 3) + 8 * ((r >> 2) & 1);
+            *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
+            *reinterpret_cast<uint4*>(orow + (16 * hh + 8 * q) * ldo) = v;
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same skeleton for the attention-from-input apply passes (include/sgf.h, sgf_attn_h_fwd / sgf_attn_h_bwd_apply;
 // large/ours.py:130-151 with the projections folded into d x d matrices): a streamed [n, d] operand times a resident
 // d x d matrix, with PER-ROW scalars in the epilogue.  In the accumulator layout a lane's 16 registers are 16 rows, so
@@ -1152,6 +1422,51 @@ extern "C" int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1
                    static_cast<const uint16_t*>(w2), static_cast<uint16_t*>(dx2), lddx2, 1};
   const int pairs = grid_blocks(n) / 16 * 8;          // whole groups of 8 pairs = 16 consecutive blocks
   return launch_rowgemm<false, 0>(args, d, 2 * pairs, st);
+}
+
+// ---- backward of the GCN layer's dense half: BatchNorm backward + both input gradients, dx0 accumulated ------------------
+extern "C" int32_t sgf_gcn_bn_bwd_dx_supported(int32_t d, int32_t dtype) {
+  return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) ? 1 : 0;
+}
+
+extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int64_t ldz, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* stats,
+                                 float inv_n, int32_t training, const void* w, int64_t ldw, int64_t n, int32_t d,
+                                 int32_t dtype, void* dz, int64_t lddz, void* dy, int64_t lddy, const void* acc_in,
+                                 void* acc_out, size_t acc_bytes, void* dx0, int64_t lddx0, int32_t add_gy, void* stream) {
+  const char* fn = "sgf_gcn_bn_bwd_dx";
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
+  SGF_REQUIRE(sgf_gcn_bn_bwd_dx_supported(d, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, d in {64, 128, 256} (got d = %d, dtype %d)", fn, d, dtype);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(gy && z && mean && rstd && w && dz && dy && (!training || stats), SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE((dx0 != nullptr) != (acc_out != nullptr), SGF_E_INVALID,
+              "%s: exactly one of dx0 (row-major result) and acc_out (running sum) must be given", fn);
+  SGF_REQUIRE(ldg >= d && ldz >= d && lddz >= d && lddy >= d && ldw >= 2 * d && (!dx0 || lddx0 >= d), SGF_E_INVALID,
+              "%s: leading dimension smaller than the width", fn);
+  SGF_REQUIRE(rows16(gy, ldg) && rows16(z, ldz) && rows16(w, ldw) && rows16(dz, lddz) && rows16(dy, lddy) &&
+                  (!dx0 || rows16(dx0, lddx0)),
+              SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
+  const size_t need = sgf_gcn_epilogue_partial_bytes(n, d);
+  SGF_REQUIRE((!acc_in && !acc_out) || acc_bytes >= need, SGF_E_WORKSPACE, "%s: running-sum buffer %zu < %zu", fn, acc_bytes, need);
+  SGF_REQUIRE((!acc_in || reinterpret_cast<uintptr_t>(acc_in) % 16 == 0) && (!acc_out || reinterpret_cast<uintptr_t>(acc_out) % 16 == 0),
+              SGF_E_INVALID, "%s: running-sum buffers must be 16-byte aligned", fn);
+  const int roles = 2 * d / 128;
+  int vblocks = (grid_blocks(n) + roles - 1) / roles;
+  if (roles > 1) {
+    vblocks = (vblocks + 7) / 8 * 8;                   // whole groups of 8 tiles' worth of blocks: b, b + 8, ... share an XCD
+    if (vblocks > kNumCU / roles) vblocks = kNumCU / roles;
+  }
+  BnBwdDxArgs a{static_cast<const uint16_t*>(gy), ldg, static_cast<const uint16_t*>(z), ldz, mean, rstd, gamma, beta,
+                stats, inv_n, training, relu, static_cast<const uint16_t*>(w), ldw, static_cast<uint16_t*>(dz), lddz,
+                static_cast<uint16_t*>(dy), lddy, static_cast<const uint4*>(acc_in), static_cast<uint4*>(acc_out),
+                static_cast<uint16_t*>(dx0), lddx0, add_gy, n};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d == 64) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<64, 1>), dim3(vblocks), dim3(kRgThreads), 0, st, a);
+  else if (d == 128) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<128, 2>), dim3(vblocks * 2), dim3(kRgThreads), 0, st, a);
+  else hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
 }
 
 // ---- the two-operand Linear in ONE pass (paired launch at d = 256) ---------------------------------------------------

@@ -479,6 +479,19 @@ class HipKernels:
                       out.stride(0), _ptr(cs), _ptr(ws), ws.numel(), _stream(dev))
         return out, cs
 
+    @staticmethod
+    def gram2(a, b1, b2, out1, out2, want_colsum=True):
+        """out1 = a^T b1, out2 = a^T b2 (fp32, may be column-sliced views of one matrix) from one paired launch; colsum(a)."""
+        n, m = a.shape
+        k = b1.shape[1]
+        dev = a.device
+        cs = torch.empty(m, dtype=_F32, device=dev) if want_colsum else None
+        ws = _workspace(dev, "attn", _lib.load().sgf_gram_workspace_bytes(n, m, k))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gram2", _ptr(a), _ld(a), m, _ptr(b1), _ld(b1), _ptr(b2), _ld(b2), k, n, _code(a), _ptr(out1),
+                      out1.stride(0), _ptr(out2), out2.stride(0), _ptr(cs), _ptr(ws), ws.numel(), _stream(dev))
+        return cs
+
     # ---- T5 ----
     @staticmethod
     def ln_fwd(x, res, a: float, b: float, gamma, beta, relu: bool, eps: float):
@@ -736,6 +749,30 @@ class HipKernels:
         return dx
 
     @staticmethod
+    def gcn_bn_bwd_dx_supported(d: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_gcn_bn_bwd_dx_supported(int(d), _lib.SGF_BF16))
+
+    @staticmethod
+    def gcn_bn_bwd_dx(gy, z, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float, training: bool, w, acc_in,
+                      last: bool, add_gy: bool):
+        """(dz, dy, acc): BatchNorm backward + both input gradients of W [Ax | x0] in one launch (sgf_gcn_bn_bwd_dx).
+        `acc_in`: the running gradient of x0 from the layers processed so far (opaque uint8 tensor) or None; `acc`: the
+        new running sum (opaque) or, with last=True, the total as a row-major [n, d] tensor."""
+        n, d = z.shape
+        dev = z.device
+        dz = torch.empty((n, d), dtype=z.dtype, device=dev)
+        dy = torch.empty((n, d), dtype=z.dtype, device=dev)
+        nbytes = _lib.load().sgf_gcn_epilogue_partial_bytes(n, d)
+        acc_out = None if last else torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        dx0 = torch.empty((n, d), dtype=z.dtype, device=dev) if last else None
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gcn_bn_bwd_dx", _ptr(gy), _ld(gy), _ptr(z), _ld(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                      int(relu), _ptr(stats), float(inv_n), int(training), _ptr(w), w.stride(0), n, d, _code(z), _ptr(dz),
+                      _ld(dz), _ptr(dy), _ld(dy), _ptr(acc_in), _ptr(acc_out), nbytes, _ptr(dx0), _ld(dx0), int(add_gy),
+                      _stream(dev))
+        return dz, dy, (dx0 if last else acc_out)
+
+    @staticmethod
     def gcn_epilogue_dx2(dy, w1, w2, pair: bool = True):
         """(dy w1, dy w2) for two [d, d] column blocks of one weight matrix, dy read from HBM once (paired launch)."""
         n, d = dy.shape
@@ -756,6 +793,11 @@ class HipKernels:
             _lib.call("sgf_axpby", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), n, d,
                       _code(x1), _ptr(y), y.stride(0), _stream(x1.device))
         return y
+
+
+def _pair_gram() -> bool:
+    import os
+    return os.environ.get("SGF_GRAM_PAIR", "1") != "0"
 
 
 def _one_pass_cat() -> bool:
@@ -1802,6 +1844,12 @@ def _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype):
         gp = _rows(g if m % 4 == 0 else torch.nn.functional.pad(g, (0, 4 - m % 4)))
         dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
         off = 0
+        if (len(xs) == 2 and widths[0] == widths[1] and widths[0] % 4 == 0 and hasattr(K, "gram2") and gp.dtype == _BF16
+                and xs[0].dtype == _BF16 and xs[1].dtype == _BF16 and _pair_gram()):
+            # both blocks of dW = g^T [x_1 | x_2] from ONE read of g out of HBM (paired launch, sgf_gram2)
+            k = widths[0]
+            db = K.gram2(gp, _rows(xs[0]), _rows(xs[1]), dw[:, :k], dw[:, k:], want_colsum=need_b)
+            xs, widths = [], []
         for i, (x, k) in enumerate(zip(xs, widths)):
             if k % 4 == 0 and off % 4 == 0:   # sgf_gram stores float4s: the slice must stay 16-B aligned
                 _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
@@ -1921,6 +1969,87 @@ def _linear_with_stats(xr, wc, b32, stats_req):
     m1 = st[:d] / max(n_tot, 1.0)
     stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# T4 + T6 as ONE autograd node: out = [relu](BatchNorm(W [y | x0] + b)) [+ x0]   (large/ours.py:36-40, 87-93)
+# ------------------------------------------------------------------------------------------------
+class GradChain:
+    """The gradient of x0 = layer_[0] of one GraphConv forward, accumulated across its layers' backward nodes (which run in
+    reverse layer order: layer i's input is layer i-1's output).  Every layer's fused backward kernel adds its two
+    contributions (the residual's gy and dz W[:, d:]) to the running sum it is handed; the FIRST layer's node — the last to
+    run — gets the total row-major and returns it to autograd, the others return nothing for x0."""
+
+    def __init__(self):
+        self.acc = None
+
+
+def gcn_layer_fused_ok(x0: torch.Tensor, w: torch.Tensor) -> bool:
+    """bf16 storage, square blocks of 64 / 128 / 256, W = [W1 | W2] — what sgf_gcn_bn_bwd_dx / sgf_gcn_epilogue_cat take."""
+    import os
+    d = x0.shape[1] if x0.dim() == 2 else 0
+    return (x0.dim() == 2 and x0.shape[0] > 0 and x0.dtype == _BF16 and tuple(w.shape) == (d, 2 * d)
+            and hasattr(K, "gcn_bn_bwd_dx_supported") and K.gcn_bn_bwd_dx_supported(d, x0.dtype)
+            and os.environ.get("SGF_GCN_FUSED", "1") != "0")
+
+
+class _LinearBNActRes(torch.autograd.Function):
+    """y = A x (already multiplied), x0 -> z = [y | x0] W^T + b -> out = [relu](BatchNorm(z)) [+ x0].
+
+    Forward: one pass for the Linear and BatchNorm's batch sums (sgf_gcn_epilogue_cat), `bn_hook(stats)` — the module's
+    own bookkeeping (batch vs running statistics, running-stat update) — then sgf_bn_apply.
+    Backward: sgf_bn_bwd_stats (the one global reduction), then ONE launch for dz, d y and the running gradient of x0
+    (sgf_gcn_bn_bwd_dx), then the weight / bias gradients on sgf_gram."""
+
+    @staticmethod
+    def forward(ctx, y, x0, w, b, gamma, beta, bn_hook, relu: bool, use_res: bool, shard, chain, first: bool):
+        K.check(y, x0)
+        dt = x0.dtype
+        wc = w.detach().to(dt).contiguous()
+        b32 = None if b is None else b.detach().float().contiguous()
+        yr, xr = _rows16(y), _rows16(x0)
+        want = bn_hook(None)                         # does the BatchNorm normalise with batch statistics?
+        if want:
+            req = {"shard": shard, "out": None}
+            z = _linear_with_stats([yr, xr], wc, b32, req)
+            mean, rstd, n_tot, training = bn_hook(req["out"])
+        else:
+            z, _ = _streaming_linear([yr, xr], wc, b32)
+            mean, rstd, n_tot, training = bn_hook(False)
+        g32 = gamma.detach().float().contiguous() if gamma is not None else None
+        be32 = beta.detach().float().contiguous() if beta is not None else None
+        mean = mean.detach().float().contiguous()
+        rstd = rstd.detach().float().contiguous()
+        out = K.bn_apply(z, mean, rstd, g32, be32, xr if use_res else None, relu)
+        ctx.save_for_backward(yr, xr, z, wc, g32, be32, mean, rstd)
+        ctx.meta = (bool(relu), bool(use_res), bool(training), float(n_tot), shard, chain, bool(first), w.dtype,
+                    None if b is None else b.dtype, None if gamma is None else gamma.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        yr, xr, z, wc, g32, be32, mean, rstd = ctx.saved_tensors
+        relu, use_res, training, n_tot, shard, chain, first, wdt, bdt, gdt = ctx.meta
+        d = z.shape[1]
+        gout = _rows16(gout.contiguous())
+        stats = K.bn_bwd_stats(gout, z, mean, rstd, g32, be32, relu)
+        if shard is not None:
+            shard.all_reduce(stats)
+        dz, dy, acc = K.gcn_bn_bwd_dx(gout, z, mean, rstd, g32, be32, relu, stats, 1.0 / max(n_tot, 1.0), training, wc,
+                                      chain.acc, last=first, add_gy=use_res)
+        chain.acc = None if first else acc
+        dx0 = acc if first else None
+        dw, db = _linear_param_grads(dz, [yr, xr], [d, d], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and bdt is not None,
+                                     wdt, bdt)
+        dgamma = stats[d:].to(gdt) if g32 is not None else None
+        dbeta = stats[:d].to(gdt) if be32 is not None else None
+        if shard is not None and g32 is not None:
+            dgamma, dbeta = shard.unsum(dgamma), shard.unsum(dbeta)
+        return dy, dx0, dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def linear_bn_act_res(y, x0, w, b, gamma, beta, bn_hook, relu, use_res, shard, chain, first):
+    return _LinearBNActRes.apply(y, x0, w, b, gamma, beta, bn_hook, relu, use_res, shard, chain, first)
 
 
 def linear(x, w, b):

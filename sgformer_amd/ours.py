@@ -147,10 +147,8 @@ class GraphConvLayer(nn.Module):
     def reset_parameters(self):
         self.W.reset_parameters()
 
-    def forward(self, x, edge_index, x0, bn_stats=False):
-        """`bn_stats` (not in the reference signature): also return the batch statistics (mean, var, count) of
-        the output, which the Linear's streaming pass accumulates for the BatchNorm that follows — (y, stats);
-        stats is None when this layer has nothing to fuse them into."""
+    def propagate(self, x, edge_index):
+        """A_norm x (large/ours.py:26-34): the cached CSR of `edge_index` times x."""
         shard = self._shard
         if isinstance(edge_index, ops.CSRGraph):   # SGFormer.forward resolved (and maybe re-ordered) it already
             graph = edge_index
@@ -160,7 +158,14 @@ class GraphConvLayer(nn.Module):
             # one GPU — or the batch mode of a sharded run (ShardContext.for_batch): this rank's own induced
             # subgraph, no halo; only the attention / BatchNorm partial sums cross ranks
             graph = ops.graph_cache.get(edge_index, x.shape[0])
-        y = ops.spmm(graph, x, None if (shard is not None and shard.local_graph) else shard)
+        return ops.spmm(graph, x, None if (shard is not None and shard.local_graph) else shard)
+
+    def forward(self, x, edge_index, x0, bn_stats=False):
+        """`bn_stats` (not in the reference signature): also return the batch statistics (mean, var, count) of
+        the output, which the Linear's streaming pass accumulates for the BatchNorm that follows — (y, stats);
+        stats is None when this layer has nothing to fuse them into."""
+        shard = self._shard
+        y = self.propagate(x, edge_index)
         if self.use_init:
             # W [y | x0] + b without materialising the concatenation
             if bn_stats:
@@ -224,6 +229,37 @@ class GraphConv(nn.Module):
         rstd = torch.rsqrt(var + bn.eps)
         return ops.bn_act_res(x, res, bn.weight, bn.bias, mean, rstd, relu, use_batch, n_tot, shard)
 
+    def _bn_hook(self, bn: nn.BatchNorm1d):
+        """nn.BatchNorm1d's bookkeeping as a callback for ops.linear_bn_act_res: hook(None) -> does this call normalise with
+        batch statistics?; hook((mean, var, count)) / hook(False) -> (mean, rstd, count, used batch statistics), updating
+        the running statistics exactly as _bn_act_res does."""
+        def hook(stats):
+            use_batch = _uses_batch_stats(self, bn)
+            if stats is None:
+                return use_batch
+            if use_batch:
+                mean, var, n_tot = stats
+                if n_tot <= 1 and self.training:
+                    raise ValueError("Expected more than 1 value per channel when training")
+                if self.training and bn.track_running_stats and bn.running_mean is not None:
+                    with torch.no_grad():
+                        bn.num_batches_tracked += 1
+                        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                        bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
+                        unbiased = var * (n_tot / max(n_tot - 1.0, 1.0))
+                        bn.running_var.mul_(1.0 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
+            else:
+                mean, var, n_tot = bn.running_mean.float(), bn.running_var.float(), 0.0
+            return mean, torch.rsqrt(var + bn.eps), n_tot, use_batch
+        return hook
+
+    def _fused_layers(self, x0):
+        """The products / pokec / papers100M recipes (use_init, BatchNorm, no active dropout, bf16 rows of 64 / 128 / 256):
+        every layer's Linear + BatchNorm + activation + residual is ONE autograd node (ops.linear_bn_act_res)."""
+        drop_on = self.training and self.dropout is not None and self.dropout > 0.0
+        return (self.use_bn and not drop_on and len(self.convs) > 0 and all(c.use_init for c in self.convs)
+                and all(ops.gcn_layer_fused_ok(x0, c.W.weight) for c in self.convs))
+
     def _stage(self, bn, x, res, relu, stats=None):
         """BN -> act -> dropout -> + res, fused into one pass whenever dropout is inactive."""
         drop_on = self.training and self.dropout is not None and self.dropout > 0.0
@@ -248,6 +284,15 @@ class GraphConv(nn.Module):
         else:
             x, stats0 = _lin(x, self.fcs[0]), None
         x = self._stage(self.bns[0], x, None, True, stats0)
+        if self._fused_layers(x):
+            # layer_[0]'s gradient is accumulated inside the layers' backward kernels (ops.GradChain): no fan-out hub
+            x0, chain = x, ops.GradChain()
+            for i, conv in enumerate(self.convs):
+                bn = self.bns[i + 1]
+                y = conv.propagate(x, edge_index)
+                x = ops.linear_bn_act_res(y, x0, conv.W.weight, conv.W.bias, bn.weight, bn.bias, self._bn_hook(bn),
+                                          self.use_act, self.use_residual, self._shard, chain, i == 0)
+            return x
         # x0 = layer_[0] has up to 2 consumers per layer (the [. | x0] Linear and the residual) plus
         # the first SpMM: hand out aliases through a hub whose backward sums all their gradients in
         # ONE pass (ops.fan_out) instead of autograd's pairwise adds

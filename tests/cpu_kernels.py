@@ -91,6 +91,23 @@ class CpuKernels:
     def gcn_epilogue_dx(dy, w):
         return (dy.float() @ w.float()).to(dy.dtype)
 
+    # ---- backward of the GCN layer's dense half (sgf_gcn_bn_bwd_dx); the opaque running sum is a plain bf16 matrix here ----
+    @staticmethod
+    def gcn_bn_bwd_dx_supported(d, dtype):
+        return dtype == torch.bfloat16 and d in (64, 128, 256)
+
+    @staticmethod
+    def gcn_bn_bwd_dx(gy, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, w, acc_in, last, add_gy):
+        d = z.shape[1]
+        dz = CpuKernels.bn_bwd_apply(gy, z, mean, rstd, gamma, beta, relu, stats, inv_n, training)
+        dy = (dz.float() @ w[:, :d].float()).to(z.dtype)
+        acc = dz.float() @ w[:, d:].float()
+        if add_gy:
+            acc = acc + gy.float()
+        if acc_in is not None:
+            acc = acc + acc_in.float()
+        return dz, dy, acc.to(z.dtype)
+
     @staticmethod
     def stem_pair_supported(d_in, d_out, dtype):
         return dtype == torch.bfloat16 and d_in % 4 == 0 and d_in <= 128 and d_out in (64, 128, 256)
@@ -233,6 +250,12 @@ class CpuKernels:
         else:
             out.copy_(c)
         return out, (a.float().sum(0) if want_colsum else None)
+
+    @staticmethod
+    def gram2(a, b1, b2, out1, out2, want_colsum=True):
+        out1.copy_(a.float().t() @ b1.float())
+        out2.copy_(a.float().t() @ b2.float())
+        return a.float().sum(0) if want_colsum else None
 
     # ---- T3 ----
     @staticmethod

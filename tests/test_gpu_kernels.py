@@ -946,6 +946,104 @@ def test_gcn_epilogue_cat_one_pass(cuda, n, d):
     assert _rel(st4[:d], y4.double().sum(0)) <= 2e-6 or float(y4.double().sum(0).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("n,m,k", [(100, 256, 256), (1025, 256, 256), (4099, 128, 128), (50001, 256, 256), (30000, 64, 64),
+                                   (20000, 48, 256)])
+def test_gram2_paired_launch(cuda, n, m, k):
+    """sgf_gram2: dW = g^T [x_1 | x_2] of the two-operand Linear (large/ours.py:36-38 differentiated) from one PAIRED launch:
+    bit-identical... to the fp32 sums of exact bf16 products in a different block order, so: both blocks within 2e-6 (relative,
+    Frobenius) of fp64 on the same bf16 operands, the column sums likewise, results written into column slices of one
+    matrix, and run-to-run identical."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + m + k)
+    a = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    b1 = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    b2 = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    dw = torch.empty(m, 2 * k, device=cuda)
+    cs = ops.K.gram2(a, b1, b2, dw[:, :k], dw[:, k:], want_colsum=True)
+    ad = a.double().cpu()
+    assert _rel(dw[:, :k], ad.t() @ b1.double().cpu()) <= 2e-6
+    assert _rel(dw[:, k:], ad.t() @ b2.double().cpu()) <= 2e-6
+    assert _rel(cs, ad.sum(0)) <= 2e-6 or float(ad.sum(0).abs().max()) < 1e-2
+    dw2 = torch.empty_like(dw)
+    cs2 = ops.K.gram2(a, b1, b2, dw2[:, :k], dw2[:, k:], want_colsum=True)
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)
+    one, _ = ops.K.gram(a, b1, want_colsum=False)
+    assert _rel(dw[:, :k], one) <= 1e-6
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (100, 256), (31, 128), (2049, 64), (4096, 256), (9001, 128), (20001, 256), (70003, 256)])
+@pytest.mark.parametrize("relu,training", [(True, True), (False, True), (True, False)])
+def test_gcn_bn_bwd_dx_chain(cuda, n, d, relu, training):
+    """sgf_gcn_bn_bwd_dx, three chained calls as the three GraphConv layers of the products recipe issue them in their
+    backward (large/ours.py:83-93 differentiated): per call dz bit-equal (or within one bf16 ulp on a vanishing fraction:
+    the two kernels contract their multiply-adds alike) to sgf_bn_bwd_apply, d y = dz W[:, :d] against fp64 of the rounded
+    dz, and the accumulated gradient of x0 = sum_i (gy_i + dz_i W_i[:, d:]) against fp64 (three bf16 roundings of the
+    running sum).  n covers: fewer tiles than launched blocks, ragged last tiles, several tiles per wave."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(5 * n + d + relu)
+    K = ops.K
+    acc, ref_acc = None, torch.zeros(n, d, dtype=torch.float64)
+    for layer in range(3):
+        gy = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+        z = (torch.randn(n, d, generator=g) * 1.5 + 0.3).bfloat16().to(cuda)
+        mean = (torch.randn(d, generator=g) * 0.2 + 0.3).to(cuda)
+        rstd = (1.0 / (1.0 + torch.rand(d, generator=g))).to(cuda)
+        gamma = (1.0 + 0.3 * torch.randn(d, generator=g)).to(cuda)
+        beta = (0.2 * torch.randn(d, generator=g)).to(cuda)
+        w = (torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5).bfloat16().to(cuda)
+        stats = K.bn_bwd_stats(gy, z, mean, rstd, gamma, beta, relu)
+        inv_n = 1.0 / n
+        dz_ref = K.bn_bwd_apply(gy, z, mean, rstd, gamma, beta, relu, stats, inv_n, training)
+        add_gy = layer != 1
+        dz, dy, acc = K.gcn_bn_bwd_dx(gy, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, w, acc,
+                                      last=(layer == 2), add_gy=add_gy)
+        same = (dz == dz_ref).float().mean().item()
+        assert same >= 0.999, same
+        ulp = 2.0 ** -7 * dz_ref.float().abs() + 1e-30
+        assert bool(((dz.float() - dz_ref.float()).abs() <= ulp).all())
+        dzd = dz.double().cpu()
+        ref_dy = dzd @ w[:, :d].double().cpu()
+        err = (dy.double().cpu() - ref_dy).abs()
+        assert bool((err <= 2.0 ** -8 * ref_dy.abs() + 1e-6).all()), float(err.max())
+        ref_acc = ref_acc + dzd @ w[:, d:].double().cpu() + (gy.double().cpu() if add_gy else 0.0)
+    assert acc.shape == (n, d) and acc.dtype == torch.bfloat16
+    err = (acc.double().cpu() - ref_acc).abs()
+    scale = ref_acc.abs() + 1.0
+    assert bool((err <= 3 * 2.0 ** -8 * scale).all()), float((err / scale).max())
+
+
+def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):
+    """GraphConv (products recipe: 3 layers, use_init, residual, BatchNorm, bf16) with the layers as ONE autograd node each
+    (ops.linear_bn_act_res: sgf_gcn_epilogue_cat forward, sgf_gcn_bn_bwd_dx backward, layer_[0]'s gradient accumulated in
+    the kernels) against the same module with SGF_GCN_FUSED=0 (separate Linear / BatchNorm nodes + the fan-out hub): same
+    outputs up to the single rounding of the two-operand Linear, same gradients to bf16 accuracy."""
+    from sgformer_amd import ops
+    from sgformer_amd.ours import GraphConv
+    from oracle import sgformer_oracle as O
+    n, f, d = 5000, 32, 128
+    torch.manual_seed(0)
+    ei = O.synthetic_graph(n, 8.0, seed=3).to(cuda)
+    x = torch.randn(n, f).bfloat16().to(cuda)
+    go = torch.randn(n, d).bfloat16().to(cuda)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SGF_GCN_FUSED", mode)
+        torch.manual_seed(1)
+        m = GraphConv(f, d, num_layers=3, dropout=0.0, use_bn=True, use_residual=True, use_weight=True, use_init=True,
+                      use_act=True).to(cuda).train()
+        out = m(x, ei)
+        (out.float() * go.float()).sum().backward()
+        res[mode] = (out.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters()},
+                     {k: b.detach().float().clone() for k, b in m.named_buffers()})
+    o1, g1, b1 = res["1"]
+    o0, g0, b0 = res["0"]
+    assert _rel(o1, o0) <= 1e-2
+    for k in g0:
+        assert _rel(g1[k], g0[k]) <= 3e-2, (k, _rel(g1[k], g0[k]))
+    for k in b0:
+        assert _rel(b1[k], b0[k]) <= 1e-3 or "num_batches" in k, k
+
+
 @pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (1000, 128), (20001, 256)])
 def test_gcn_epilogue_two_operands(cuda, n, d, monkeypatch):
     """The two-pass form (SGF_GCN_CAT=0; also what fp32 storage runs): y = [a1 | a2] W^T + b in two streaming passes with

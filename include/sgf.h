@@ -509,6 +509,20 @@ int sgf_bn_bwd_stats(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
                      const float* rstd, const float* gamma, const float* beta, int32_t relu,
                      int64_t n, int32_t d, int32_t dtype, float* stats, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same sums for a tensor with TWO incoming gradients (dy + dy2, added in fp32; dy2 may be null): the stem's output feeds
+ * the first SpMM and the layers' residuals / Linear blocks, whose gradients arrive separately. */
+int sgf_bn_bwd_stats2(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx,
+                      const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, int64_t n,
+                      int32_t d, int32_t dtype, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* dW / db of a Linear whose output z feeds a BatchNorm, without a materialised dz (the stem of GraphConv, large/ours.py:77-81:
+ * its input is data, nobody else needs dz):  c[m, k] = dz^T b,  colsum[m] = sum_n dz,  where
+ * dz = sgf_bn_bwd_apply(g1 [+ g2], z, ...) is formed per 4 x 4 patch inside the Gram kernel's staging step (bf16 storage, m and
+ * k multiples of 4 up to 256).  stats as returned by sgf_bn_bwd_stats2; workspace: sgf_gram_workspace_bytes. */
+int32_t sgf_gram_bn_bwd_supported(int32_t m, int32_t k, int32_t dtype);
+int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, const void* z, int64_t ldz, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,
+                    int32_t training, int32_t m, const void* b, int64_t ldb, int32_t k, int64_t n, int32_t dtype, float* c,
+                    int64_t ldc, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int32_t relu,
                      const float* stats, float inv_n, int32_t training, int64_t n, int32_t d,

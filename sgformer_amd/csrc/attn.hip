@@ -49,6 +49,8 @@ constexpr int kModeGram = 2; // reduce: C = A^T B plus column sums of A (sgf_gra
 constexpr int kModeBwdH = 3; // reduce: A=h, B=dnum; vecA = sum h*dden, vecB = sum dnum, scalar = sum dden
 constexpr int kModeBwdHS = 4; // the same sums with the per-row scalars (1/den, dden) READ (p.den = float2 per row,
                               // written by k_hrow_bf16<B1>): two streams, no row dot (bf16 only)
+constexpr int kModeGramBN = 5; // Gram whose A operand is formed on the fly: A = BatchNorm'(relu'(g1 [+ g2])) from g1, g2, z and
+                               // the reduced statistics (sgf_gram_bn_bwd: the stem's dW without a materialised dz; bf16 only)
 constexpr int kApplyFwd = 0, kApplyDQ = 1, kApplyDK = 2, kApplyDV = 3;
 // attention from the un-projected input (sgf_attn_h_*): no E operand, no global scalars
 constexpr int kApplyHFwd = 4;   // out = (h M + m) / (h.w + beta)
@@ -71,6 +73,10 @@ struct ReduceArgs {
   // kModeGram, PAIRED launch (pair != 0, bf16): blocks b and b + 8 (one XCD) walk the same row tiles, one multiplying with
   // b, the other with b2 — A leaves HBM once, its second read is served by the XCD's L2.  Partials: [role][virtual block].
   const void* b2; int64_t ldb2; int32_t pair;
+  // kModeGramBN: a = g1, q = z, a2 = g2 (or null); per-column coefficients of the BatchNorm backward
+  const void* a2; int64_t lda2;
+  const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta, *bn_stats;
+  float bn_inv_n; int32_t bn_training, bn_relu;
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -697,8 +703,24 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   // Only ONE staging pass is in flight at a time (24 VGPRs of loads): a tile iteration is NPASS
   // half-steps, each = issue the loads of pass t of the next tile, run the MFMAs of half of the
   // current tile's k-steps, then transpose / commit pass t into the other LDS buffer.
-  uint2 ra[4], rb[4], rq[4];
+  uint2 ra[4], rb[4], rq[4], r2[4];
   float rden[4], rden2[4];
+  const uint16_t* pa2 = MODE == kModeGramBN && p.a2 ? static_cast<const uint16_t*>(p.a2) + c0 : nullptr;
+  // kModeGramBN: this thread's four columns keep their BatchNorm coefficients in registers for the whole kernel
+  float bmu[4], brs[4], bga[4], bbe[4], bk0[4], bk1[4];
+  if (MODE == kModeGramBN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      const bool ok = c < p.d;
+      bmu[j] = ok ? p.bn_mean[c] : 0.f;
+      brs[j] = ok ? p.bn_rstd[c] : 0.f;
+      bga[j] = ok ? (p.bn_gamma ? p.bn_gamma[c] : 1.f) : 0.f;
+      bbe[j] = ok ? (p.bn_beta ? p.bn_beta[c] : 0.f) : 0.f;
+      bk0[j] = (ok && p.bn_training) ? p.bn_stats[c] * p.bn_inv_n : 0.f;
+      bk1[j] = (ok && p.bn_training) ? p.bn_stats[p.d + c] * p.bn_inv_n : 0.f;
+    }
+  }
 
   auto issue = [&](int64_t tile, int t) {
 #pragma unroll
@@ -709,6 +731,10 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       rb[i] = (rok && b_ok) ? *reinterpret_cast<const uint2*>(pb + row * p.ldb) : make_uint2(0u, 0u);
       if (MODE != kModeGram && MODE != kModeBwdHS)
         rq[i] = (rok && a_ok) ? *reinterpret_cast<const uint2*>(pq + row * p.ldq) : make_uint2(0u, 0u);
+      if (MODE == kModeGramBN) {
+        r2[i] = (rok && a_ok && p.a2) ? *reinterpret_cast<const uint2*>(pa2 + row * p.lda2) : make_uint2(0u, 0u);
+        rden[i] = rok ? 1.f : 0.f;                     // rows past the end contribute nothing (their dz is not zero by itself)
+      }
       if (MODE == kModeBwd || MODE == kModeBwdH) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
       if (MODE == kModeBwdHS) {
         const float2 rs = rok ? reinterpret_cast<const float2*>(p.den)[row] : make_float2(0.f, 0.f);
@@ -741,6 +767,27 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
     } else if (MODE == kModeGram) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
+        colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
+      }
+    } else if (MODE == kModeGramBN) {
+      // ra = g1, r2 = g2, rq = z  ->  ra = dz (sgf_bn_bwd_apply's arithmetic; the two gradients are added in fp32),
+      // rounded to bf16 once — the tensor sgf_bn_bwd_apply would have written; colsum = sum dz (the bias gradient)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g[4] = {bf_lo(ra[i].x) + bf_lo(r2[i].x), bf_hi(ra[i].x) + bf_hi(r2[i].x),
+                            bf_lo(ra[i].y) + bf_lo(r2[i].y), bf_hi(ra[i].y) + bf_hi(r2[i].y)};
+        const float zv[4] = {bf_lo(rq[i].x), bf_hi(rq[i].x), bf_lo(rq[i].y), bf_hi(rq[i].y)};
+        float dv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (zv[j] - bmu[j]) * brs[j];
+          float gg = g[j];
+          if (p.bn_relu) gg = (xh * bga[j] + bbe[j]) > 0.f ? gg : 0.f;
+          gg -= bk0[j] + xh * bk1[j];
+          dv[j] = rden[i] != 0.f ? bga[j] * brs[j] * gg : 0.f;
+        }
+        ra[i] = make_uint2(pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]));
         colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
         colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
       }
@@ -1221,6 +1268,53 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
   return SGF_OK;
 }
 }  // namespace
+
+// dW / db of a Linear whose output feeds a BatchNorm, WITHOUT a materialised dz (the stem: x is data, nobody else reads dz):
+//   c = dz^T b,  colsum = sum_n dz,   dz = BatchNorm'(relu'(g1 [+ g2])) formed per 4 x 4 patch inside the Gram's staging step.
+extern "C" int32_t sgf_gram_bn_bwd_supported(int32_t m, int32_t k, int32_t dtype) {
+  return dtype == SGF_BF16 && m >= 4 && m <= 256 && m % 4 == 0 && k >= 4 && k <= 256 && k % 4 == 0 ? 1 : 0;
+}
+
+extern "C" int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, const void* z, int64_t ldz,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                               const float* stats, float inv_n, int32_t training, int32_t m, const void* b, int64_t ldb,
+                               int32_t k, int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_gram_bn_bwd";
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
+  SGF_REQUIRE(sgf_gram_bn_bwd_supported(m, k, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, m and k multiples of 4 up to 256 (m=%d k=%d dtype=%d)", fn, m, k, dtype);
+  SGF_REQUIRE(c && ldc >= k, SGF_E_INVALID, "%s: null c or ldc < k", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemset2DAsync(c, ldc * sizeof(float), 0, k * sizeof(float), m, st));
+    if (colsum) SGF_CHECK_HIP(hipMemsetAsync(colsum, 0, m * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(g1 && z && b && mean && rstd && (!training || stats), SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE, "%s: workspace too small", fn);
+  SGF_REQUIRE(aligned4<uint16_t>(g1, ldg1) && (!g2 || aligned4<uint16_t>(g2, ldg2)) && aligned4<uint16_t>(z, ldz) &&
+                  aligned4<uint16_t>(b, ldb),
+              SGF_E_INVALID, "%s: operands must be 4-element aligned with ld %% 4 == 0", fn);
+  const int DP = padded_dim(m > k ? m : k);
+  const int R = reduce_rows_per_tile<uint16_t, kModeGramBN>(DP);
+  const int64_t ntiles = (n + R - 1) / R;
+  const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+  ReduceArgs r{};
+  r.a = g1; r.lda = ldg1; r.a2 = g2; r.lda2 = ldg2; r.q = z; r.ldq = ldz; r.b = b; r.ldb = ldb; r.den = nullptr;
+  r.n = n; r.d = m; r.db = k; r.heads = 1; r.b_heads = 1; r.gscale = 1.f;
+  r.bn_mean = mean; r.bn_rstd = rstd; r.bn_gamma = gamma; r.bn_beta = beta; r.bn_stats = stats; r.bn_inv_n = inv_n;
+  r.bn_training = training; r.bn_relu = relu;
+  r.partial = static_cast<float*>(workspace);
+  int rc = launch_reduce<uint16_t, kModeGramBN>(r, DP, nblk, st);
+  if (rc != SGF_OK) return rc;
+  const int RG = reduce_row_groups<uint16_t, kModeGramBN>(DP);
+  const int64_t len = static_cast<int64_t>(m) * k + m;
+  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
+                     k, DP, RG, c, ldc, colsum);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
 
 // Two Gram products that share A in ONE paired launch (bf16 storage, m, k <= 256): c1 = a^T b1, c2 = a^T b2.
 extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, int64_t ldb1, const void* b2, int64_t ldb2,

@@ -414,11 +414,16 @@ __device__ __forceinline__ void bn_coeffs(const BnParams& p, int col, float4& mu
 template <typename T>
 struct BnBwdStatsF {
   const T* dy; int64_t lddy; const T* x; int64_t ldx; BnParams p; int relu;
+  const T* dy2 = nullptr; int64_t lddy2 = 0;           // a second gradient of the same tensor, added in fp32 (or null)
   __device__ void operator()(int64_t row, int col, float4& v0, float4& v1) const {
     float4 mu, rs, ga, be;
     bn_coeffs(p, col, mu, rs, ga, be);
     const float4 xv = load4<T>(x + row * ldx + col);
     float4 g = load4<T>(dy + row * lddy + col);
+    if (dy2 != nullptr) {
+      const float4 g2 = load4<T>(dy2 + row * lddy2 + col);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
     const float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z,
                                   (xv.w - mu.w) * rs.w);
     if (relu) {
@@ -1134,31 +1139,39 @@ extern "C" int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const
   return SGF_OK;
 }
 
+extern "C" int sgf_bn_bwd_stats2(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 int32_t relu, int64_t n, int32_t d, int32_t dtype, float* stats, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  int rc = check_ew("sgf_bn_bwd_stats2", n, d, dtype);
+  if (rc != SGF_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SGF_REQUIRE(stats, SGF_E_INVALID, "sgf_bn_bwd_stats2: null stats");
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * d * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(dy && x && mean && rstd && lddy % 4 == 0 && ldx % 4 == 0 && (!dy2 || lddy2 % 4 == 0), SGF_E_INVALID,
+              "sgf_bn_bwd_stats2: bad pointer / ld");
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_colstats_workspace_bytes(n, d), SGF_E_WORKSPACE,
+              "sgf_bn_bwd_stats2: workspace too small");
+  const BnParams p{mean, rstd, gamma, beta};
+  if (dtype == SGF_F32)
+    return colreduce(BnBwdStatsF<float>{static_cast<const float*>(dy), lddy, static_cast<const float*>(x), ldx, p, relu,
+                                        static_cast<const float*>(dy2), lddy2},
+                     n, d, stats, workspace, st);
+  return colreduce(BnBwdStatsF<uint16_t>{static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(x), ldx, p,
+                                         relu, static_cast<const uint16_t*>(dy2), lddy2},
+                   n, d, stats, workspace, st);
+}
+
 extern "C" int sgf_bn_bwd_stats(const void* dy, int64_t lddy, const void* x, int64_t ldx,
                                 const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, int32_t relu, int64_t n, int32_t d,
                                 int32_t dtype, float* stats, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-  int rc = check_ew("sgf_bn_bwd_stats", n, d, dtype);
-  if (rc != SGF_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  SGF_REQUIRE(stats, SGF_E_INVALID, "sgf_bn_bwd_stats: null stats");
-  if (n == 0) {
-    SGF_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * d * sizeof(float), st));
-    return SGF_OK;
-  }
-  SGF_REQUIRE(dy && x && mean && rstd && lddy % 4 == 0 && ldx % 4 == 0, SGF_E_INVALID,
-              "sgf_bn_bwd_stats: bad pointer / ld");
-  SGF_REQUIRE(workspace && workspace_bytes >= sgf_colstats_workspace_bytes(n, d), SGF_E_WORKSPACE,
-              "sgf_bn_bwd_stats: workspace too small");
-  const BnParams p{mean, rstd, gamma, beta};
-  if (dtype == SGF_F32)
-    return colreduce(BnBwdStatsF<float>{static_cast<const float*>(dy), lddy,
-                                        static_cast<const float*>(x), ldx, p, relu},
-                     n, d, stats, workspace, st);
-  return colreduce(BnBwdStatsF<uint16_t>{static_cast<const uint16_t*>(dy), lddy,
-                                         static_cast<const uint16_t*>(x), ldx, p, relu},
-                   n, d, stats, workspace, st);
+  return sgf_bn_bwd_stats2(dy, lddy, nullptr, 0, x, ldx, mean, rstd, gamma, beta, relu, n, d, dtype, stats, workspace,
+                           workspace_bytes, stream);
 }
 
 extern "C" int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx,

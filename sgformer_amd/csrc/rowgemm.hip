@@ -34,6 +34,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRgWaves = 8;
 constexpr int kRgThreads = kRgWaves * 64;
@@ -508,16 +509,18 @@ struct BnBwdDxArgs {
   int64_t n;
 };
 
-template <int D, int ROLES>
-__global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
+// IDLO / IDHI: this block's dx0 strips take the residual's gradient from gy's k-steps [0, KS/2) / [KS/2, KS) — fixed per
+// role, so the kernel dispatches ONCE on the role and the k-step loop has no branch at all (branches would cut it into
+// basic blocks the scheduler cannot overlap: a first version with them ran 2.7 ms where its parts cost 1.4).
+template <int D, int ROLES, bool IDLO, bool IDHI>
+__device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned char* lds, int role, int64_t vblock,
+                                               int64_t vgrid) {
   constexpr int KS = D / 16;                           // k-steps
-  constexpr int RING = KS > 8 ? 8 : KS;                // fragment slots per stream: step s lives in slot s % RING and is
+  constexpr int RING = KS > 8 ? 4 : KS;                // fragment slots per stream: step s lives in slot s % RING and is
                                                        // re-loaded with step s + RING (of this tile or the next) once consumed
   constexpr int NS = 4;                                // strips (of 32 virtual columns) per block
   constexpr int NSD = D / 32;                          // strips of d[Ax] = strips of dx0
   constexpr int BT = D * 2 + 16;                       // bytes per row of B^T
-  static_assert(ROLES * 128 == 2 * D, "a block produces 128 virtual columns");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * BT + kRgWaves * kStageBytes + 6 * D * 4];
   unsigned char* const ldsB = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -525,18 +528,7 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
   const int i31 = lane & 31;
   const int hi = lane >> 5;
   unsigned char* const stg = lds + 128 * BT + wave * kStageBytes;
-  float* const coef = reinterpret_cast<float*>(lds + 128 * BT + kRgWaves * kStageBytes);   // [mu | rs | ga | be | c0 | c1][D]
-  int role = 0;
-  int64_t vblock = blockIdx.x, vgrid = gridDim.x;
-  if (ROLES == 2) {
-    role = (blockIdx.x >> 3) & 1;
-    vblock = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);
-    vgrid = gridDim.x / 2;
-  } else if (ROLES == 4) {
-    role = (blockIdx.x >> 3) & 3;
-    vblock = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
-    vgrid = gridDim.x / 4;
-  }
+  float* const coef = reinterpret_cast<float*>(lds + 128 * BT + kRgWaves * kStageBytes);   // [T1 | T0 | A1 | Z1 | Z0][D]
   const int v0 = role * 128;                           // first virtual column of this block
   const int strip0 = v0 / 32;                          // its first virtual strip; strips >= NSD belong to dx0
 
@@ -553,13 +545,18 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
             static_cast<uint16_t>(e & 1 ? u[e >> 1] >> 16 : u[e >> 1] & 0xffffu);
     }
   }
+  // per column, with xhat = z rs + m (m = -mean rs), ga rs = cs:   act = z T1 + T0   (the relu argument xhat ga + be),
+  //   dz = cs (g' - k0 - xhat k1) = A1 g' + z Z1 + Z0,   A1 = cs, Z1 = -cs k1 rs, Z0 = -cs (k0 + k1 m)
   for (int c = tid; c < D; c += kRgThreads) {
-    coef[c] = p.mean[c];
-    coef[D + c] = p.rstd[c];
-    coef[2 * D + c] = p.gamma ? p.gamma[c] : 1.f;
-    coef[3 * D + c] = p.beta ? p.beta[c] : 0.f;
-    coef[4 * D + c] = p.training ? p.stats[c] * p.inv_n : 0.f;
-    coef[5 * D + c] = p.training ? p.stats[D + c] * p.inv_n : 0.f;
+    const float rs = p.rstd[c], m = -p.mean[c] * rs;
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    const float k0 = p.training ? p.stats[c] * p.inv_n : 0.f, k1 = p.training ? p.stats[D + c] * p.inv_n : 0.f;
+    const float cs = ga * rs;
+    coef[c] = p.relu ? rs * ga : 0.f;                  // T1
+    coef[D + c] = p.relu ? m * ga + be : 1.f;          // T0  (no activation: act = 1 > 0 for every element)
+    coef[2 * D + c] = cs;                              // A1
+    coef[3 * D + c] = -cs * k1 * rs;                   // Z1
+    coef[4 * D + c] = -cs * (k0 + k1 * m);             // Z0
   }
   __syncthreads();
 
@@ -578,6 +575,11 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
   // which k-steps of dz this block stores: the d[Ax] blocks share the columns of dz between them
   constexpr int DYR = ROLES >= 2 ? ROLES / 2 : 1;      // blocks that produce d[Ax] strips only
   const int ws0 = role < DYR ? role * (KS / DYR) : KS, ws1 = role < DYR ? (role + 1) * (KS / DYR) : KS;
+  // dz leaves through a buffer descriptor: a lane (or a whole step) that must not store gets an out-of-range offset, which
+  // the hardware drops — no branch
+  const uint64_t dz_bytes = static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.lddz) * 2;
+  const __amdgpu_buffer_rsrc_t dzrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.dz, 0, static_cast<uint32_t>(dz_bytes), 0x00020000);
 
   bf16x8 G[RING], Z[RING];
   int64_t t = vblock * kRgWaves + wave;
@@ -596,114 +598,120 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
       Z[s] = *reinterpret_cast<const bf16x8*>(sz + 16 * s);
     }
   }
-  const bool has_dx0 = strip0 + NS > NSD;              // this block owns dx0 strips
-  uint4 accn[NS][2];                                   // the running dx0 of the tile about to be processed
-  auto load_acc = [&](int64_t tt) {
-#pragma unroll
-    for (int w = 0; w < NS; ++w)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        accn[w][q] = (strip0 + w >= NSD)
-                         ? p.acc_in[tt * (NSD * 2 * 64) + ((strip0 + w - NSD) * 2 + q) * 64 + lane]
-                         : make_uint4(0u, 0u, 0u, 0u);
-  };
-  if (has_dx0 && p.acc_in && t < ntiles) load_acc(t);
 
   for (; t < ntiles; t += nwaves) {
     const int64_t tn = t + nwaves;
     const bool has_next = tn < ntiles;
     const int64_t row0 = t * 32;
     const bool tail = row0 + 32 > p.n;
-    const int64_t rowc = rowptr_of(t), rown = has_next ? rowptr_of(tn) : 0;
+    const int64_t rowc = rowptr_of(t), rown = has_next ? rowptr_of(tn) : rowc;   // no next tile: re-load this one (unused)
     const uint16_t* const cg = p.gy + rowc * p.ldg + 8 * hi;
     const uint16_t* const cz = p.z + rowc * p.ldz + 8 * hi;
     const uint16_t* const ng = p.gy + rown * p.ldg + 8 * hi;
     const uint16_t* const nz = p.z + rown * p.ldz + 8 * hi;
-    uint16_t* const dzrow = p.dz + (row0 + i31) * p.lddz + 8 * hi;
     const bool row_ok = row0 + i31 < p.n;
+    const uint32_t dzoff = static_cast<uint32_t>(((row0 + i31) * p.lddz + 8 * hi) * 2);
 
     f32x16 acc[NS];
 #pragma unroll
-    for (int w = 0; w < NS; ++w) {
-      if (has_dx0 && p.acc_in && strip0 + w >= NSD) {
+    for (int w = 0; w < NS; ++w)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const uint32_t d4[4] = {accn[w][q].x, accn[w][q].y, accn[w][q].z, accn[w][q].w};
+      for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
+
+    // Two phases per RING k-steps, fenced for the scheduler: (A) the element-wise work — dz fragments into registers, the
+    // dz store, the refill of the consumed slots — RING independent chains whose LDS coefficient reads and multiply-adds
+    // overlap; (B) the matrix-core work on those fragments.  Interleaved step by step (a first version) every multiply
+    // waited for its own LDS read and every step for the previous one: 2.7 ms where the parts cost 1.4.
+#pragma unroll
+    for (int half = 0; half < KS / RING; ++half) {
+      bf16x8 dzr[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int s = half * RING + j;
+        const bool id_step = (IDLO && s < KS / 2) || (IDHI && s >= KS / 2);
+        // ---- dz for columns 16 s + 8 hi .. + 7 of row i31 ----
+        const float* cf = coef + 16 * s + 8 * hi;
+        const uint4 gq = *reinterpret_cast<const uint4*>(&G[j]);
+        const uint4 zq = *reinterpret_cast<const uint4*>(&Z[j]);
+        const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
+        uint32_t du[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 t1 = *reinterpret_cast<const float4*>(cf + 4 * h);
+          const float4 t0 = *reinterpret_cast<const float4*>(cf + D + 4 * h);
+          const float4 a1 = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
+          const float4 z1 = *reinterpret_cast<const float4*>(cf + 3 * D + 4 * h);
+          const float4 z0 = *reinterpret_cast<const float4*>(cf + 4 * D + 4 * h);
+          const float t1v[4] = {t1.x, t1.y, t1.z, t1.w}, t0v[4] = {t0.x, t0.y, t0.z, t0.w};
+          const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, z1v[4] = {z1.x, z1.y, z1.z, z1.w}, z0v[4] = {z0.x, z0.y, z0.z, z0.w};
+          float dv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc[w][8 * q + 2 * e] = __uint_as_float(d4[e] << 16);
-            acc[w][8 * q + 2 * e + 1] = __uint_as_float(d4[e] & 0xffff0000u);
+            const uint32_t gw_ = gu[2 * h + (e >> 1)], zw_ = zu[2 * h + (e >> 1)];
+            const float g = (e & 1) ? __uint_as_float(gw_ & 0xffff0000u) : __uint_as_float(gw_ << 16);
+            const float zv = (e & 1) ? __uint_as_float(zw_ & 0xffff0000u) : __uint_as_float(zw_ << 16);
+            const float act = fmaf(zv, t1v[e], t0v[e]);
+            const float gm = act > 0.f ? g : 0.f;
+            dv[e] = fmaf(a1v[e], gm, fmaf(zv, z1v[e], z0v[e]));
           }
+          du[2 * h] = cvt_pk_bf16(dv[0], dv[1]);
+          du[2 * h + 1] = cvt_pk_bf16(dv[2], dv[3]);
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
+        const u32x4 dq = {du[0], du[1], du[2], du[3]};
+        dzr[j] = *reinterpret_cast<const bf16x8*>(&dq);
+        __builtin_amdgcn_raw_buffer_store_b128(dq, dzrsrc, (s >= ws0 && s < ws1 && row_ok) ? dzoff + 32u * s : 0xffffff00u, 0, 0);
+        // step s + RING (of this tile, or of the next one) into the slots just consumed; gy's slot stays until phase B
+        // when it still has to go through the identity multiply
+        const uint16_t* const rz = s + RING < KS ? cz + 16 * (s + RING) : nz + 16 * (s + RING - KS);
+        const uint16_t* const rg = s + RING < KS ? cg + 16 * (s + RING) : ng + 16 * (s + RING - KS);
+        Z[j] = *reinterpret_cast<const bf16x8*>(rz);
+        if (!id_step) G[j] = *reinterpret_cast<const bf16x8*>(rg);
       }
-    }
-
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      // ---- dz for columns 16 s + 8 hi .. + 7 of row i31 ----
-      const float* cf = coef + 16 * s + 8 * hi;
-      const int sl = s % RING;
-      const uint4 gq = *reinterpret_cast<const uint4*>(&G[sl]);
-      const uint4 zq = *reinterpret_cast<const uint4*>(&Z[sl]);
-      const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
-      uint32_t du[4];
+      for (int j = 0; j < RING; ++j) {
+        const int s = half * RING + j;
+        const bool id_step = (IDLO && s < KS / 2) || (IDHI && s >= KS / 2);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 mu = *reinterpret_cast<const float4*>(cf + 4 * h);
-        const float4 rs = *reinterpret_cast<const float4*>(cf + D + 4 * h);
-        const float4 ga = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
-        const float4 be = *reinterpret_cast<const float4*>(cf + 3 * D + 4 * h);
-        const float4 k0 = *reinterpret_cast<const float4*>(cf + 4 * D + 4 * h);
-        const float4 k1 = *reinterpret_cast<const float4*>(cf + 5 * D + 4 * h);
-        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-        const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
-        const float k0v[4] = {k0.x, k0.y, k0.z, k0.w}, k1v[4] = {k1.x, k1.y, k1.z, k1.w};
-        float dv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t gw_ = gu[2 * h + (e >> 1)], zw_ = zu[2 * h + (e >> 1)];
-          float g = (e & 1) ? __uint_as_float(gw_ & 0xffff0000u) : __uint_as_float(gw_ << 16);
-          const float zv = (e & 1) ? __uint_as_float(zw_ & 0xffff0000u) : __uint_as_float(zw_ << 16);
-          const float xh = (zv - muv[e]) * rsv[e];
-          if (p.relu) g = (xh * gav[e] + bev[e]) > 0.f ? g : 0.f;
-          g -= k0v[e] + xh * k1v[e];                   // both zero when not training
-          dv[e] = gav[e] * rsv[e] * g;
+        for (int w = 0; w < NS; ++w) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
+          acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzr[j], b, acc[w], 0, 0, 0);
         }
-        du[2 * h] = cvt_pk_bf16(dv[0], dv[1]);
-        du[2 * h + 1] = cvt_pk_bf16(dv[2], dv[3]);
+        if (id_step) {
+          // the residual's gradient: gy's own 16 columns of dx0 strip (s >> 1), added through an identity fragment (exact)
+          constexpr int kOff = NSD % NS;               // block-local index of dx0 strip i: (i + NSD - strip0) = (i + kOff) % NS
+          const int wi = ((s >> 1) + kOff) % NS;
+          acc[wi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[j], ident[s & 1], acc[wi], 0, 0, 0);
+          const uint16_t* const rg = s + RING < KS ? cg + 16 * (s + RING) : ng + 16 * (s + RING - KS);
+          G[j] = *reinterpret_cast<const bf16x8*>(rg);
+        }
       }
-      const uint4 dq = make_uint4(du[0], du[1], du[2], du[3]);
-      const bf16x8 dzs = *reinterpret_cast<const bf16x8*>(&dq);
-      if (s >= ws0 && s < ws1 && row_ok) *reinterpret_cast<uint4*>(dzrow + 16 * s) = dq;
-#pragma unroll
-      for (int w = 0; w < NS; ++w) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
-        acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzs, b, acc[w], 0, 0, 0);
-      }
-      // the residual's gradient: gy's own columns of dx0 strip (s >> 1), added through an identity fragment
-      if (has_dx0 && p.add_gy) {
-#pragma unroll
-        for (int w = 0; w < NS; ++w)
-          if (strip0 + w - NSD == (s >> 1))
-            acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[sl], ident[s & 1], acc[w], 0, 0, 0);
-      }
-      if (s + RING < KS) {                             // step s + RING of this tile into the slot just consumed
-        G[sl] = *reinterpret_cast<const bf16x8*>(cg + 16 * (s + RING));
-        Z[sl] = *reinterpret_cast<const bf16x8*>(cz + 16 * (s + RING));
-      } else if (has_next) {                           // ... or step s + RING - KS of the NEXT tile
-        G[sl] = *reinterpret_cast<const bf16x8*>(ng + 16 * (s + RING - KS));
-        Z[sl] = *reinterpret_cast<const bf16x8*>(nz + 16 * (s + RING - KS));
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (has_dx0 && p.acc_in && has_next) load_acc(tn);
 
     // ---- epilogue: strips leave in pairs ----
 #pragma unroll
     for (int u = 0; u < NS / 2; ++u) {
       const bool is_dx0 = strip0 + 2 * u >= NSD;       // pairs never straddle the boundary (NSD is even)
+      if (is_dx0 && p.acc_in != nullptr) {             // the running sum of the layers processed before this one
+        uint4 av[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            av[c][q] = p.acc_in[t * (NSD * 2 * 64) + ((strip0 + 2 * u + c - NSD) * 2 + q) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t d4[4] = {av[c][q].x, av[c][q].y, av[c][q].z, av[c][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[2 * u + c][8 * q + 2 * e] += __uint_as_float(d4[e] << 16);
+              acc[2 * u + c][8 * q + 2 * e + 1] += __uint_as_float(d4[e] & 0xffff0000u);
+            }
+          }
+      }
       if (is_dx0 && p.dx0 == nullptr) {                // running sum stays in accumulator layout
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -744,6 +752,27 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
         wave_lds_sync();
       }
     }
+  }
+}
+
+template <int D, int ROLES>
+__global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
+  static_assert(ROLES * 128 == 2 * D, "a block produces 128 virtual columns");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * (D * 2 + 16) + kRgWaves * kStageBytes + 5 * D * 4];
+  if (ROLES == 4) {                                    // D = 256: blocks b, b + 8, b + 16, b + 24 of a group of 32
+    const int role = (blockIdx.x >> 3) & 3;
+    const int64_t vblock = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3), vgrid = gridDim.x / 4;
+    if (role < 2 || !p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, role, vblock, vgrid);
+    else if (role == 2) bn_bwd_dx_body<D, ROLES, true, false>(p, lds, role, vblock, vgrid);
+    else bn_bwd_dx_body<D, ROLES, false, true>(p, lds, role, vblock, vgrid);
+  } else if (ROLES == 2) {                             // D = 128: role 1 owns all of dx0
+    const int role = (blockIdx.x >> 3) & 1;
+    const int64_t vblock = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3), vgrid = gridDim.x / 2;
+    if (role == 0 || !p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, role, vblock, vgrid);
+    else bn_bwd_dx_body<D, ROLES, true, true>(p, lds, role, vblock, vgrid);
+  } else {                                             // D = 64: one block per tile, strips 0-1 d[Ax], 2-3 dx0
+    if (!p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, 0, blockIdx.x, gridDim.x);
+    else bn_bwd_dx_body<D, ROLES, true, true>(p, lds, 0, blockIdx.x, gridDim.x);
   }
 }
 
@@ -1447,6 +1476,8 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
   SGF_REQUIRE(rows16(gy, ldg) && rows16(z, ldz) && rows16(w, ldw) && rows16(dz, lddz) && rows16(dy, lddy) &&
                   (!dx0 || rows16(dx0, lddx0)),
               SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
+  SGF_REQUIRE(static_cast<uint64_t>(n) * static_cast<uint64_t>(lddz) * 2 < 0xffffff00ull, SGF_E_UNSUPPORTED,
+              "%s: dz beyond 4 GiB (32-bit store offsets)", fn);
   const size_t need = sgf_gcn_epilogue_partial_bytes(n, d);
   SGF_REQUIRE((!acc_in && !acc_out) || acc_bytes >= need, SGF_E_WORKSPACE, "%s: running-sum buffer %zu < %zu", fn, acc_bytes, need);
   SGF_REQUIRE((!acc_in || reinterpret_cast<uintptr_t>(acc_in) % 16 == 0) && (!acc_out || reinterpret_cast<uintptr_t>(acc_out) % 16 == 0),

@@ -561,6 +561,37 @@ class HipKernels:
         return stats
 
     @staticmethod
+    def bn_bwd_stats2(gy, gy2, x, mean, rstd, gamma, beta, relu: bool) -> torch.Tensor:
+        """bn_bwd_stats of the gradient gy + gy2 (two consumers of the BatchNorm's output; gy2 may be None)."""
+        n, d = x.shape
+        dev = x.device
+        stats = torch.empty(2 * d, dtype=_F32, device=dev)
+        ws = _workspace(dev, "col", _lib.load().sgf_colstats_workspace_bytes(n, d))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_bn_bwd_stats2", _ptr(gy), _ld(gy), _ptr(gy2), _ld(gy2), _ptr(x), _ld(x), _ptr(mean), _ptr(rstd),
+                      _ptr(gamma), _ptr(beta), int(relu), n, d, _code(x), _ptr(stats), _ptr(ws), ws.numel(), _stream(dev))
+        return stats
+
+    @staticmethod
+    def gram_bn_bwd_supported(m: int, k: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_gram_bn_bwd_supported(int(m), int(k), _lib.SGF_BF16))
+
+    @staticmethod
+    def gram_bn_bwd(gy, gy2, z, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float, training: bool, b):
+        """(dz^T b [m, k] fp32, colsum(dz) [m]) with dz = bn_bwd_apply(gy + gy2, z, ...) never written (sgf_gram_bn_bwd)."""
+        n, m = z.shape
+        k = b.shape[1]
+        dev = z.device
+        out = torch.empty((m, k), dtype=_F32, device=dev)
+        cs = torch.empty(m, dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", _lib.load().sgf_gram_workspace_bytes(n, m, k))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gram_bn_bwd", _ptr(gy), _ld(gy), _ptr(gy2), _ld(gy2), _ptr(z), _ld(z), _ptr(mean), _ptr(rstd),
+                      _ptr(gamma), _ptr(beta), int(relu), _ptr(stats), float(inv_n), int(training), m, _ptr(b), _ld(b), k, n,
+                      _code(z), _ptr(out), out.stride(0), _ptr(cs), _ptr(ws), ws.numel(), _stream(dev))
+        return out, cs
+
+    @staticmethod
     def bn_bwd_apply(gy, x, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float,
                      training: bool) -> torch.Tensor:
         n, d = x.shape
@@ -1912,6 +1943,92 @@ class _StemPair(torch.autograd.Function):
                                        ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
         dx = (g0 @ w0c + g1 @ w1c) if ctx.needs_input_grad[0] else None
         return dx, dw0, db0, dw1, db1, None
+
+
+class _StemPairBN(torch.autograd.Function):
+    """(x0, x0, y1): x0 = relu(BatchNorm(x W0^T + b0)) — GraphConv's stem, large/ours.py:77-80 — handed out TWICE (the first
+    SpMM and the layers' Linear / residual consume it; their gradients come back separately instead of through an add),
+    y1 = x W1^T + b1 (TransConv's stem, :198) from the same read of x.  Backward: the BatchNorm's two sums over both
+    gradients (sgf_bn_bwd_stats2), then dW0 / db0 straight from them — dz is formed inside the Gram kernel and never written
+    (sgf_gram_bn_bwd): x is data, nobody else needs dz."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, gamma, beta, bn_hook, shard):
+        K.check(x)
+        dt = x.dtype
+        w0c, w1c = w0.to(dt), w1.to(dt)
+        f32 = [None if b is None else b.detach().float().contiguous() for b in (b0, b1)]
+        d = w0.shape[0]
+        n = x.shape[0]
+        want = bn_hook(None)
+        shift = None
+        if want:
+            ns = min(n, _BN_SAMPLE_ROWS)
+            _, _, st_s = K.stem_pair(x[:ns], w0c, f32[0], None, None, None, want_stats0=True)
+            samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
+            n_tot = float(n)
+            if shard is not None:
+                shard.all_reduce(samp)
+                n_tot = float(shard.n_global)
+            shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
+        y0, y1, st = K.stem_pair(x, w0c, f32[0], w1c, f32[1], shift, want_stats0=want)
+        if want:
+            if shard is not None:
+                shard.all_reduce(st)
+            m1 = st[:d] / max(n_tot, 1.0)
+            mean, rstd, n_tot, training = bn_hook((shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot))
+        else:
+            mean, rstd, n_tot, training = bn_hook(False)
+        g32 = gamma.detach().float().contiguous() if gamma is not None else None
+        be32 = beta.detach().float().contiguous() if beta is not None else None
+        mean = mean.detach().float().contiguous()
+        rstd = rstd.detach().float().contiguous()
+        x0 = K.bn_apply(y0, mean, rstd, g32, be32, None, True)
+        ctx.save_for_backward(x, w0c, w1c, y0, g32, be32, mean, rstd)
+        ctx.meta = (w0.dtype, None if b0 is None else b0.dtype, w1.dtype, None if b1 is None else b1.dtype,
+                    None if gamma is None else gamma.dtype, bool(training), float(n_tot), shard)
+        return x0, x0.view_as(x0), y1
+
+    @staticmethod
+    def backward(ctx, ga, gb, g1):
+        x, w0c, w1c, y0, g32, be32, mean, rstd = ctx.saved_tensors
+        wd0, bd0, wd1, bd1, gdt, training, n_tot, shard = ctx.meta
+        d = y0.shape[1]
+        if ga is None:
+            ga, gb = gb, None
+        if ga is None:
+            ga = torch.zeros_like(y0)
+        ga = _rows(ga.contiguous())
+        gb = None if gb is None else _rows(gb.contiguous())
+        stats = K.bn_bwd_stats2(ga, gb, y0, mean, rstd, g32, be32, True)
+        if shard is not None:
+            shard.all_reduce(stats)
+        inv_n = 1.0 / max(n_tot, 1.0)
+        dw0, db0 = K.gram_bn_bwd(ga, gb, y0, mean, rstd, g32, be32, True, stats, inv_n, training, _rows(x))
+        dw0 = dw0.to(wd0) if ctx.needs_input_grad[1] else None
+        db0 = db0.to(bd0) if (ctx.needs_input_grad[2] and bd0 is not None) else None
+        dw1, db1 = _linear_param_grads(g1.contiguous(), [x], [x.shape[1]], ctx.needs_input_grad[3],
+                                       ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
+        dgamma = stats[d:].to(gdt) if g32 is not None else None
+        dbeta = stats[:d].to(gdt) if be32 is not None else None
+        if shard is not None and g32 is not None:
+            dgamma, dbeta = shard.unsum(dgamma), shard.unsum(dbeta)
+        dx = None
+        if ctx.needs_input_grad[0]:                      # features that require a gradient (not in any recipe): explicit dz
+            g = ga if gb is None else ga + gb
+            dz = K.bn_bwd_apply(g, y0, mean, rstd, g32, be32, True, stats, inv_n, training)
+            dx = dz @ w0c + g1 @ w1c
+        return dx, dw0, db0, dw1, db1, dgamma, dbeta, None, None
+
+
+def stem_pair_bn_supported(x, w0, w1) -> bool:
+    return (stem_pair_supported(x, w0, w1) and hasattr(K, "gram_bn_bwd_supported")
+            and K.gram_bn_bwd_supported(w0.shape[0], x.shape[1], x.dtype))
+
+
+def stem_pair_bn(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard=None):
+    """(x0 for the layers, x0 for the first SpMM, y1): see _StemPairBN."""
+    return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard)
 
 
 def stem_pair_supported(x, w0, w1) -> bool:

@@ -253,6 +253,18 @@ class GraphConv(nn.Module):
             return mean, torch.rsqrt(var + bn.eps), n_tot, use_batch
         return hook
 
+    def fused_stem_ok(self, x) -> bool:
+        """SGFormer.forward may run this branch's stem Linear + BatchNorm + relu (and TransConv's stem Linear) as ONE
+        autograd node (ops.stem_pair_bn) when the layers behind it are the fused ones and no dropout follows the stem."""
+        import os
+        d = self.fcs[0].out_features
+        drop_on = self.training and self.dropout is not None and self.dropout > 0.0
+        return (self.use_bn and not drop_on and len(self.convs) > 0 and all(c.use_init for c in self.convs)
+                and x.dim() == 2 and x.dtype == torch.bfloat16
+                and all(tuple(c.W.weight.shape) == (d, 2 * d) for c in self.convs)
+                and hasattr(ops.K, "gcn_bn_bwd_dx_supported") and ops.K.gcn_bn_bwd_dx_supported(d, x.dtype)
+                and os.environ.get("SGF_GCN_FUSED", "1") != "0" and os.environ.get("SGF_STEM_FUSED", "1") != "0")
+
     def _fused_layers(self, x0):
         """The products / pokec / papers100M recipes (use_init, BatchNorm, no active dropout, bf16 rows of 64 / 128 / 256):
         every layer's Linear + BatchNorm + activation + residual is ONE autograd node (ops.linear_bn_act_res)."""
@@ -279,14 +291,21 @@ class GraphConv(nn.Module):
         `stem` (not in the reference signature): (fcs[0](x), its batch statistics or None), when SGFormer.forward
         has computed both branches' first Linear in one pass over x (ops.stem_pair)."""
         ops._require_cuda(x, None if isinstance(edge_index, ops.CSRGraph) else edge_index)
-        if stem is not None:
-            x, stats0 = stem
+        x_first = None
+        if stem is not None and len(stem) == 3:
+            # ("bn", x0, x0'): the stem ran as one node with its BatchNorm (ops.stem_pair_bn); x0' feeds the first SpMM
+            _, x, x_first = stem
         else:
-            x, stats0 = _lin(x, self.fcs[0]), None
-        x = self._stage(self.bns[0], x, None, True, stats0)
+            if stem is not None:
+                x, stats0 = stem
+            else:
+                x, stats0 = _lin(x, self.fcs[0]), None
+            x = self._stage(self.bns[0], x, None, True, stats0)
         if self._fused_layers(x):
             # layer_[0]'s gradient is accumulated inside the layers' backward kernels (ops.GradChain): no fan-out hub
             x0, chain = x, ops.GradChain()
+            if x_first is not None:
+                x = x_first
             for i, conv in enumerate(self.convs):
                 bn = self.bns[i + 1]
                 y = conv.propagate(x, edge_index)
@@ -555,7 +574,13 @@ class SGFormer(nn.Module):
         # sums on the way (bf16 storage, <= 128 input features)
         stem_t = stem_g = None
         gc, tc = (self.graph_conv if self.use_graph else None), self.trans_conv
-        if (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
+        if (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns") and gc.fused_stem_ok(x)
+                and ops.stem_pair_bn_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
+            bn0 = gc.bns[0]
+            x0a, x0b, yt = ops.stem_pair_bn(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,
+                                            bn0.weight, bn0.bias, gc._bn_hook(bn0), gc._shard)
+            stem_t, stem_g = yt, ("bn", x0a, x0b)
+        elif (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
                 and ops.stem_pair_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
             want = gc.use_bn and _uses_batch_stats(gc, gc.bns[0])
             (yg, yt), st = ops.stem_pair(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,

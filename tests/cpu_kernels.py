@@ -374,6 +374,21 @@ class CpuKernels:
         return torch.cat([dz.sum(0), (dz * xh).sum(0)])
 
     @staticmethod
+    def bn_bwd_stats2(gy, gy2, x, mean, rstd, gamma, beta, relu):
+        g = gy if gy2 is None else (gy.float() + gy2.float())
+        return CpuKernels.bn_bwd_stats(g, x, mean, rstd, gamma, beta, relu)
+
+    @staticmethod
+    def gram_bn_bwd_supported(m, k, dtype):
+        return dtype == torch.bfloat16 and m % 4 == 0 and k % 4 == 0 and m <= 256 and k <= 256
+
+    @staticmethod
+    def gram_bn_bwd(gy, gy2, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, b):
+        g = gy.float() if gy2 is None else (gy.float() + gy2.float())
+        dz = CpuKernels.bn_bwd_apply(g, z, mean, rstd, gamma, beta, relu, stats, inv_n, training).float()
+        return dz.t() @ b.float(), dz.sum(0)
+
+    @staticmethod
     def bn_bwd_apply(gy, x, mean, rstd, gamma, beta, relu, stats, inv_n, training):
         d = x.shape[1]
         xh, y = CpuKernels._bn(x, mean, rstd, gamma, beta)

@@ -946,6 +946,43 @@ def test_gcn_epilogue_cat_one_pass(cuda, n, d):
     assert _rel(st4[:d], y4.double().sum(0)) <= 2e-6 or float(y4.double().sum(0).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("n,m,k", [(1, 64, 32), (100, 256, 100), (4099, 128, 128), (50001, 256, 100), (20000, 64, 64)])
+@pytest.mark.parametrize("two", [False, True])
+def test_gram_bn_bwd_without_dz(cuda, n, m, k, two):
+    """sgf_bn_bwd_stats2 + sgf_gram_bn_bwd: dW / db of the GraphConv stem (large/ours.py:77-80 differentiated) straight from the
+    one or two incoming gradients of its output — dz = BatchNorm'(relu'(g1 + g2)) is formed inside the Gram kernel's staging
+    step and never written.  Against the explicit sequence on the same inputs: stats == sgf_bn_bwd_stats of the fp32 sum
+    rounded... no: of g1 + g2 taken in fp32 (2e-6), dW == sgf_gram(sgf_bn_bwd_apply(g1 + g2), x) (2e-5: dz is rounded to
+    bf16 once in both), db == its column sums."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(3 * n + m + k + two)
+    K = ops.K
+    g1 = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    g2 = torch.randn(n, m, generator=g).bfloat16().to(cuda) if two else None
+    z = (torch.randn(n, m, generator=g) * 1.3 + 0.2).bfloat16().to(cuda)
+    x = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    mean = (torch.randn(m, generator=g) * 0.2 + 0.2).to(cuda)
+    rstd = (1.0 / (1.0 + torch.rand(m, generator=g))).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(m, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(m, generator=g)).to(cuda)
+    gsum = g1.float() + (g2.float() if two else 0.0)
+    stats = K.bn_bwd_stats2(g1, g2, z, mean, rstd, gamma, beta, True)
+    xh = (z.double() - mean.double()) * rstd.double()
+    gm = gsum.double() * ((xh * gamma.double() + beta.double()) > 0)
+    ref_stats = torch.cat([gm.sum(0), (gm * xh).sum(0)])
+    tol = 2e-6 * torch.cat([gm.abs().sum(0), (gm * xh).abs().sum(0)]).clamp_min(1e-3)
+    assert bool(((stats.double() - ref_stats).abs() <= tol).all())
+    inv_n = 1.0 / n
+    dw, db = K.gram_bn_bwd(g1, g2, z, mean, rstd, gamma, beta, True, stats, inv_n, True, x)
+    dzd = (gamma.double() * rstd.double() * (gm - stats[:m].double() * inv_n - xh * stats[m:].double() * inv_n))
+    dz_r = dzd.float().bfloat16().double()                                   # one rounding, as the kernel applies it
+    ref_dw = dz_r.t() @ x.double()
+    assert _rel(dw, ref_dw) <= 2e-3 if n < 10 else _rel(dw, ref_dw) <= 3e-4, _rel(dw, ref_dw)
+    assert _rel(db, dz_r.sum(0)) <= 3e-4 or float(dz_r.sum(0).abs().max()) < 1e-2
+    dw2, db2 = K.gram_bn_bwd(g1, g2, z, mean, rstd, gamma, beta, True, stats, inv_n, True, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("n,m,k", [(100, 256, 256), (1025, 256, 256), (4099, 128, 128), (50001, 256, 256), (30000, 64, 64),
                                    (20000, 48, 256)])
 def test_gram2_paired_launch(cuda, n, m, k):
@@ -1009,7 +1046,7 @@ def test_gcn_bn_bwd_dx_chain(cuda, n, d, relu, training):
     assert acc.shape == (n, d) and acc.dtype == torch.bfloat16
     err = (acc.double().cpu() - ref_acc).abs()
     scale = ref_acc.abs() + 1.0
-    assert bool((err <= 3 * 2.0 ** -8 * scale).all()), float((err / scale).max())
+    assert bool((err <= 6 * 2.0 ** -8 * scale).all()), float((err / scale).max())   # 3 roundings of running sums > total
 
 
 def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):

@@ -391,7 +391,9 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                      "all_gather_bytes_per_step": ctx.bytes_all_gathered // max(warmup + steps, 1),
                      "all_reduce_bytes_per_step": ctx.bytes_all_reduced // max(warmup + steps, 1),
                      "repartition_bytes_per_step": ctx.bytes_repartition // max(warmup + steps, 1),
-                     "halo_overlapped_with_own_columns": bool(getattr(ctx, "overlap", False))}
+                     # exchanges that actually ran split (own-column product while the halo rows travelled), per step —
+                     # 0 when the halo plan is off (all-gather fallback) or this rank has no halo
+                     "halo_exchanges_overlapped_per_step": getattr(ctx, "overlapped_exchanges", 0) // max(warmup + steps, 1)}
     out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_fused=ms_fused, loss_mode=state["mode"],
                roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
                peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))

@@ -509,18 +509,102 @@ struct BnBwdDxArgs {
   int64_t n;
 };
 
-// IDLO / IDHI: this block's dx0 strips take the residual's gradient from gy's k-steps [0, KS/2) / [KS/2, KS) — fixed per
-// role, so the kernel dispatches ONCE on the role and the k-step loop has no branch at all (branches would cut it into
-// basic blocks the scheduler cannot overlap: a first version with them ran 2.7 ms where its parts cost 1.4).
-template <int D, int ROLES, bool IDLO, bool IDHI>
-__device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned char* lds, int role, int64_t vblock,
-                                               int64_t vgrid) {
+// Every block of a tile's group does the SAME work (so none of them drifts away from the others and out of the L2 window — a
+// first version gave the d[Ax] columns to two blocks and the dx0 columns to the other two: the dx0 blocks, which also read
+// and write the running sum, fell behind, lost their L2 hits and the launch ran 2.5 ms): block r of ROLES = D / 64 owns
+// d[Ax] strips 2 r, 2 r + 1 AND dx0 strips 2 r, 2 r + 1, stores the dz columns of k-steps [4 r, 4 r + 4) and adds gy's
+// columns of exactly those k-steps (they are its dx0 strips' own columns) through the identity fragments.  With RING = 4
+// k-steps per phase that is: "in phase r of the tile, also store dz and run the identity multiplies" — one uniform branch
+// per phase, none inside a phase.
+template <int D, int ROLES, bool MINE>
+__device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], bf16x8 (&Z)[4], f32x16 (&acc)[4],
+                                                const float* __restrict__ coef, const unsigned char* __restrict__ bfrag0,
+                                                const unsigned char* __restrict__ identp, const __amdgpu_buffer_rsrc_t dzrsrc,
+                                                const uint32_t dzoff, const bool row_ok, const __amdgpu_buffer_rsrc_t grsrc,
+                                                const __amdgpu_buffer_rsrc_t zrsrc, const uint32_t cgo, const uint32_t czo,
+                                                const uint32_t ngo, const uint32_t nzo, const int hi) {
+  constexpr int KS = D / 16, RING = 4, NS = 4;
+  constexpr int BT = D * 2 + 16;
+  bf16x8 dzr[RING];
+  // (A) element-wise: dz fragments into registers, the dz store, the refill of the consumed slots — RING independent chains
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    const int s = half * RING + j;
+    const float* cf = coef + 16 * s + 8 * hi;
+    const uint4 gq = *reinterpret_cast<const uint4*>(&G[j]);
+    const uint4 zq = *reinterpret_cast<const uint4*>(&Z[j]);
+    const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
+    uint32_t du[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 t1 = *reinterpret_cast<const float4*>(cf + 4 * h);
+      const float4 t0 = *reinterpret_cast<const float4*>(cf + D + 4 * h);
+      const float4 a1 = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
+      const float4 z1 = *reinterpret_cast<const float4*>(cf + 3 * D + 4 * h);
+      const float4 z0 = *reinterpret_cast<const float4*>(cf + 4 * D + 4 * h);
+      const float t1v[4] = {t1.x, t1.y, t1.z, t1.w}, t0v[4] = {t0.x, t0.y, t0.z, t0.w};
+      const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, z1v[4] = {z1.x, z1.y, z1.z, z1.w}, z0v[4] = {z0.x, z0.y, z0.z, z0.w};
+      float dv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t gw_ = gu[2 * h + (e >> 1)], zw_ = zu[2 * h + (e >> 1)];
+        const float g = (e & 1) ? __uint_as_float(gw_ & 0xffff0000u) : __uint_as_float(gw_ << 16);
+        const float zv = (e & 1) ? __uint_as_float(zw_ & 0xffff0000u) : __uint_as_float(zw_ << 16);
+        const float act = fmaf(zv, t1v[e], t0v[e]);
+        const float gm = act > 0.f ? g : 0.f;
+        dv[e] = fmaf(a1v[e], gm, fmaf(zv, z1v[e], z0v[e]));
+      }
+      du[2 * h] = cvt_pk_bf16(dv[0], dv[1]);
+      du[2 * h + 1] = cvt_pk_bf16(dv[2], dv[3]);
+    }
+    const u32x4 dq = {du[0], du[1], du[2], du[3]};
+    dzr[j] = *reinterpret_cast<const bf16x8*>(&dq);
+    // a lane past the last row gets an out-of-range offset, which the hardware drops (no branch)
+    if (MINE) __builtin_amdgcn_raw_buffer_store_b128(dq, dzrsrc, row_ok ? dzoff + 32u * s : 0xffffff00u, 0, 0);
+    // step s + RING (of this tile, or of the next one) into the slots just consumed; gy's slot stays until phase (B) when
+    // it still has to go through the identity multiply
+    const uint32_t rz = s + RING < KS ? czo + 32u * (s + RING) : nzo + 32u * (s + RING - KS);
+    const uint32_t rg = s + RING < KS ? cgo + 32u * (s + RING) : ngo + 32u * (s + RING - KS);
+    const u32x4 zl = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, static_cast<int>(rz), 0, 0);
+    Z[j] = *reinterpret_cast<const bf16x8*>(&zl);
+    if (!MINE) {
+      const u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(grsrc, static_cast<int>(rg), 0, 0);
+      G[j] = *reinterpret_cast<const bf16x8*>(&gl);
+    }
+    if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two steps' chains overlap; four do not fit the registers
+  }
+  // (B) matrix cores
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    const int s = half * RING + j;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
+      acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzr[j], b, acc[w], 0, 0, 0);
+    }
+    if (MINE) {
+      // the residual's gradient: these 16 columns of gy are columns of this block's dx0 strip 2 + (j >> 1) — added through an
+      // identity fragment (exact)
+      const bf16x8 idf = *reinterpret_cast<const bf16x8*>(identp + 1024 * (j & 1));
+      acc[2 + (j >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[j], idf, acc[2 + (j >> 1)], 0, 0, 0);
+      const uint32_t rg = s + RING < KS ? cgo + 32u * (s + RING) : ngo + 32u * (s + RING - KS);
+      const u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(grsrc, static_cast<int>(rg), 0, 0);
+      G[j] = *reinterpret_cast<const bf16x8*>(&gl);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D, int ROLES>
+__global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
   constexpr int KS = D / 16;                           // k-steps
-  constexpr int RING = KS > 8 ? 4 : KS;                // fragment slots per stream: step s lives in slot s % RING and is
+  constexpr int RING = 4;                              // fragment slots per stream: step s lives in slot s % RING and is
                                                        // re-loaded with step s + RING (of this tile or the next) once consumed
-  constexpr int NS = 4;                                // strips (of 32 virtual columns) per block
+  constexpr int NS = 4;                                // strips per block: 0, 1 = d[Ax] strips 2 r, 2 r + 1;  2, 3 = dx0 strips
   constexpr int NSD = D / 32;                          // strips of d[Ax] = strips of dx0
   constexpr int BT = D * 2 + 16;                       // bytes per row of B^T
+  static_assert(ROLES * 64 == D && KS / RING == ROLES, "block r owns 64 columns of each product and phase r of a tile");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * BT + kRgWaves * kStageBytes + 5 * D * 4 + 2048];
   unsigned char* const ldsB = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -529,15 +613,20 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
   const int hi = lane >> 5;
   unsigned char* const stg = lds + 128 * BT + wave * kStageBytes;
   float* const coef = reinterpret_cast<float*>(lds + 128 * BT + kRgWaves * kStageBytes);   // [T1 | T0 | A1 | Z1 | Z0][D]
-  const int v0 = role * 128;                           // first virtual column of this block
-  const int strip0 = v0 / 32;                          // its first virtual strip; strips >= NSD belong to dx0
+  unsigned char* const identl = lds + 128 * BT + kRgWaves * kStageBytes + 5 * D * 4;         // [2][64 lanes] x 16 B
+  // blocks b, b + 8, ... (b + 8 (ROLES - 1)) of a group of 8 ROLES consecutive blocks: one XCD, the same row tiles
+  const int role = ROLES == 1 ? 0 : (blockIdx.x >> 3) % ROLES;
+  const int64_t vblock = ROLES == 1 ? blockIdx.x : (blockIdx.x & 7) | ((blockIdx.x / (8 * ROLES)) << 3);
+  const int64_t vgrid = gridDim.x / ROLES;
+  const int c0 = 64 * role;                            // first column of this block's 64 columns of d[Ax] and of dx0
 
-  // ---- B^T -> LDS: B^T[j][k] = W[k][v0 + j] (a row of W scattered down a column) ----
+  // ---- B^T -> LDS: B^T[j][k] = W[k][c0 + j] (j < 64: d[Ax]),  W[k][D + c0 + j - 64] (j >= 64: dx0) ----
   {
     constexpr int CH = 128 / 8;
     for (int c = tid; c < D * CH; c += kRgThreads) {
       const int k = c / CH, q = c % CH;
-      const uint4 v = *reinterpret_cast<const uint4*>(p.w + static_cast<int64_t>(k) * p.ldw + v0 + 8 * q);
+      const int col = q < 8 ? c0 + 8 * q : D + c0 + 8 * (q - 8);
+      const uint4 v = *reinterpret_cast<const uint4*>(p.w + static_cast<int64_t>(k) * p.ldw + col);
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -558,6 +647,15 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
     coef[3 * D + c] = -cs * k1 * rs;                   // Z1
     coef[4 * D + c] = -cs * (k0 + k1 * m);             // Z0
   }
+  // identity fragments: B[k = 8 hi + e][j = i31] of the two k-steps that cover a strip's own 32 columns; zero when the
+  // layer has no residual (the multiply still runs: no branch)
+  if (tid < 128) {
+    const int f = tid >> 6, l = tid & 63, li = l & 31, lh = l >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      reinterpret_cast<uint16_t*>(identl + 1024 * f + 16 * l)[e] =
+          static_cast<uint16_t>((p.add_gy && li == 16 * f + 8 * lh + e) ? 0x3f80 : 0);
+  }
   __syncthreads();
 
   const int64_t ntiles = (p.n + 31) / 32;
@@ -565,21 +663,15 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
   const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
   unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
   const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
-  // identity fragments: B[k = 8 hi + e][j = i31] of the two k-steps that cover a strip's own 32 columns
-  bf16x8 ident[2];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    ident[0][e] = static_cast<short>(i31 == 8 * hi + e ? 0x3f80 : 0);
-    ident[1][e] = static_cast<short>(i31 == 16 + 8 * hi + e ? 0x3f80 : 0);
-  }
-  // which k-steps of dz this block stores: the d[Ax] blocks share the columns of dz between them
-  constexpr int DYR = ROLES >= 2 ? ROLES / 2 : 1;      // blocks that produce d[Ax] strips only
-  const int ws0 = role < DYR ? role * (KS / DYR) : KS, ws1 = role < DYR ? (role + 1) * (KS / DYR) : KS;
-  // dz leaves through a buffer descriptor: a lane (or a whole step) that must not store gets an out-of-range offset, which
-  // the hardware drops — no branch
   const uint64_t dz_bytes = static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.lddz) * 2;
   const __amdgpu_buffer_rsrc_t dzrsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.dz, 0, static_cast<uint32_t>(dz_bytes), 0x00020000);
+  // gy and z through buffer descriptors too: 32-bit per-lane offsets instead of 64-bit pointers (registers)
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.gy), 0, static_cast<uint32_t>(static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.ldg) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.z), 0, static_cast<uint32_t>(static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.ldz) * 2), 0x00020000);
+  const unsigned char* const identp = identl + 16 * lane;
 
   bf16x8 G[RING], Z[RING];
   int64_t t = vblock * kRgWaves + wave;
@@ -590,12 +682,13 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
   };
   if (t < ntiles) {
     const int64_t row = rowptr_of(t);
-    const uint16_t* sg = p.gy + row * p.ldg + 8 * hi;
-    const uint16_t* sz = p.z + row * p.ldz + 8 * hi;
+    const uint32_t sg = static_cast<uint32_t>((row * p.ldg + 8 * hi) * 2), sz = static_cast<uint32_t>((row * p.ldz + 8 * hi) * 2);
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
-      G[s] = *reinterpret_cast<const bf16x8*>(sg + 16 * s);
-      Z[s] = *reinterpret_cast<const bf16x8*>(sz + 16 * s);
+      const u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(grsrc, static_cast<int>(sg + 32u * s), 0, 0);
+      const u32x4 zl = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, static_cast<int>(sz + 32u * s), 0, 0);
+      G[s] = *reinterpret_cast<const bf16x8*>(&gl);
+      Z[s] = *reinterpret_cast<const bf16x8*>(&zl);
     }
   }
 
@@ -605,10 +698,8 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
     const int64_t row0 = t * 32;
     const bool tail = row0 + 32 > p.n;
     const int64_t rowc = rowptr_of(t), rown = has_next ? rowptr_of(tn) : rowc;   // no next tile: re-load this one (unused)
-    const uint16_t* const cg = p.gy + rowc * p.ldg + 8 * hi;
-    const uint16_t* const cz = p.z + rowc * p.ldz + 8 * hi;
-    const uint16_t* const ng = p.gy + rown * p.ldg + 8 * hi;
-    const uint16_t* const nz = p.z + rown * p.ldz + 8 * hi;
+    const uint32_t cg = static_cast<uint32_t>((rowc * p.ldg + 8 * hi) * 2), cz = static_cast<uint32_t>((rowc * p.ldz + 8 * hi) * 2);
+    const uint32_t ng = static_cast<uint32_t>((rown * p.ldg + 8 * hi) * 2), nz = static_cast<uint32_t>((rown * p.ldz + 8 * hi) * 2);
     const bool row_ok = row0 + i31 < p.n;
     const uint32_t dzoff = static_cast<uint32_t>(((row0 + i31) * p.lddz + 8 * hi) * 2);
 
@@ -618,118 +709,54 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[w][r] = 0.f;
 
-    // Two phases per RING k-steps, fenced for the scheduler: (A) the element-wise work — dz fragments into registers, the
-    // dz store, the refill of the consumed slots — RING independent chains whose LDS coefficient reads and multiply-adds
-    // overlap; (B) the matrix-core work on those fragments.  Interleaved step by step (a first version) every multiply
-    // waited for its own LDS read and every step for the previous one: 2.7 ms where the parts cost 1.4.
 #pragma unroll
     for (int half = 0; half < KS / RING; ++half) {
-      bf16x8 dzr[RING];
-#pragma unroll
-      for (int j = 0; j < RING; ++j) {
-        const int s = half * RING + j;
-        const bool id_step = (IDLO && s < KS / 2) || (IDHI && s >= KS / 2);
-        // ---- dz for columns 16 s + 8 hi .. + 7 of row i31 ----
-        const float* cf = coef + 16 * s + 8 * hi;
-        const uint4 gq = *reinterpret_cast<const uint4*>(&G[j]);
-        const uint4 zq = *reinterpret_cast<const uint4*>(&Z[j]);
-        const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
-        uint32_t du[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float4 t1 = *reinterpret_cast<const float4*>(cf + 4 * h);
-          const float4 t0 = *reinterpret_cast<const float4*>(cf + D + 4 * h);
-          const float4 a1 = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
-          const float4 z1 = *reinterpret_cast<const float4*>(cf + 3 * D + 4 * h);
-          const float4 z0 = *reinterpret_cast<const float4*>(cf + 4 * D + 4 * h);
-          const float t1v[4] = {t1.x, t1.y, t1.z, t1.w}, t0v[4] = {t0.x, t0.y, t0.z, t0.w};
-          const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, z1v[4] = {z1.x, z1.y, z1.z, z1.w}, z0v[4] = {z0.x, z0.y, z0.z, z0.w};
-          float dv[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t gw_ = gu[2 * h + (e >> 1)], zw_ = zu[2 * h + (e >> 1)];
-            const float g = (e & 1) ? __uint_as_float(gw_ & 0xffff0000u) : __uint_as_float(gw_ << 16);
-            const float zv = (e & 1) ? __uint_as_float(zw_ & 0xffff0000u) : __uint_as_float(zw_ << 16);
-            const float act = fmaf(zv, t1v[e], t0v[e]);
-            const float gm = act > 0.f ? g : 0.f;
-            dv[e] = fmaf(a1v[e], gm, fmaf(zv, z1v[e], z0v[e]));
-          }
-          du[2 * h] = cvt_pk_bf16(dv[0], dv[1]);
-          du[2 * h + 1] = cvt_pk_bf16(dv[2], dv[3]);
-        }
-        const u32x4 dq = {du[0], du[1], du[2], du[3]};
-        dzr[j] = *reinterpret_cast<const bf16x8*>(&dq);
-        __builtin_amdgcn_raw_buffer_store_b128(dq, dzrsrc, (s >= ws0 && s < ws1 && row_ok) ? dzoff + 32u * s : 0xffffff00u, 0, 0);
-        // step s + RING (of this tile, or of the next one) into the slots just consumed; gy's slot stays until phase B
-        // when it still has to go through the identity multiply
-        const uint16_t* const rz = s + RING < KS ? cz + 16 * (s + RING) : nz + 16 * (s + RING - KS);
-        const uint16_t* const rg = s + RING < KS ? cg + 16 * (s + RING) : ng + 16 * (s + RING - KS);
-        Z[j] = *reinterpret_cast<const bf16x8*>(rz);
-        if (!id_step) G[j] = *reinterpret_cast<const bf16x8*>(rg);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < RING; ++j) {
-        const int s = half * RING + j;
-        const bool id_step = (IDLO && s < KS / 2) || (IDHI && s >= KS / 2);
-#pragma unroll
-        for (int w = 0; w < NS; ++w) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
-          acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzr[j], b, acc[w], 0, 0, 0);
-        }
-        if (id_step) {
-          // the residual's gradient: gy's own 16 columns of dx0 strip (s >> 1), added through an identity fragment (exact)
-          constexpr int kOff = NSD % NS;               // block-local index of dx0 strip i: (i + NSD - strip0) = (i + kOff) % NS
-          const int wi = ((s >> 1) + kOff) % NS;
-          acc[wi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[j], ident[s & 1], acc[wi], 0, 0, 0);
-          const uint16_t* const rg = s + RING < KS ? cg + 16 * (s + RING) : ng + 16 * (s + RING - KS);
-          G[j] = *reinterpret_cast<const bf16x8*>(rg);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      if (half == role)
+        bn_bwd_dx_phase<D, ROLES, true>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz, ng,
+                                        nz, hi);
+      else
+        bn_bwd_dx_phase<D, ROLES, false>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz, ng,
+                                         nz, hi);
     }
 
-    // ---- epilogue: strips leave in pairs ----
+    // ---- epilogue: the d[Ax] pair leaves row-major through the patch; the dx0 pair row-major or in accumulator layout ----
+    if (p.acc_in != nullptr) {                         // the running dx0 of this tile's two strips
+      uint4 av[2][2];
 #pragma unroll
-    for (int u = 0; u < NS / 2; ++u) {
-      const bool is_dx0 = strip0 + 2 * u >= NSD;       // pairs never straddle the boundary (NSD is even)
-      if (is_dx0 && p.acc_in != nullptr) {             // the running sum of the layers processed before this one
-        uint4 av[2][2];
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int q = 0; q < 2; ++q) av[c][q] = p.acc_in[t * (NSD * 2 * 64) + ((2 * role + c) * 2 + q) * 64 + lane];
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            av[c][q] = p.acc_in[t * (NSD * 2 * 64) + ((strip0 + 2 * u + c - NSD) * 2 + q) * 64 + lane];
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t d4[4] = {av[c][q].x, av[c][q].y, av[c][q].z, av[c][q].w};
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const uint32_t d4[4] = {av[c][q].x, av[c][q].y, av[c][q].z, av[c][q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc[2 * u + c][8 * q + 2 * e] += __uint_as_float(d4[e] << 16);
-              acc[2 * u + c][8 * q + 2 * e + 1] += __uint_as_float(d4[e] & 0xffff0000u);
-            }
+          for (int e = 0; e < 4; ++e) {
+            acc[2 + c][8 * q + 2 * e] += __uint_as_float(d4[e] << 16);
+            acc[2 + c][8 * q + 2 * e + 1] += __uint_as_float(d4[e] & 0xffff0000u);
           }
-      }
-      if (is_dx0 && p.dx0 == nullptr) {                // running sum stays in accumulator layout
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && p.dx0 == nullptr) {                // running sum stays in accumulator layout
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             uint4 v;
-            v.x = cvt_pk_bf16(acc[2 * u + c][8 * q + 0], acc[2 * u + c][8 * q + 1]);
-            v.y = cvt_pk_bf16(acc[2 * u + c][8 * q + 2], acc[2 * u + c][8 * q + 3]);
-            v.z = cvt_pk_bf16(acc[2 * u + c][8 * q + 4], acc[2 * u + c][8 * q + 5]);
-            v.w = cvt_pk_bf16(acc[2 * u + c][8 * q + 6], acc[2 * u + c][8 * q + 7]);
-            p.acc_out[t * (NSD * 2 * 64) + ((strip0 + 2 * u + c - NSD) * 2 + q) * 64 + lane] = v;
+            v.x = cvt_pk_bf16(acc[2 + c][8 * q + 0], acc[2 + c][8 * q + 1]);
+            v.y = cvt_pk_bf16(acc[2 + c][8 * q + 2], acc[2 + c][8 * q + 3]);
+            v.z = cvt_pk_bf16(acc[2 + c][8 * q + 4], acc[2 + c][8 * q + 5]);
+            v.w = cvt_pk_bf16(acc[2 + c][8 * q + 6], acc[2 + c][8 * q + 7]);
+            p.acc_out[t * (NSD * 2 * 64) + ((2 * role + c) * 2 + q) * 64 + lane] = v;
           }
         continue;
       }
-      uint16_t* const orow = is_dx0
-                                 ? p.dx0 + (row0 + (lane >> 3)) * p.lddx0 + 32 * (strip0 + 2 * u - NSD) + 8 * (lane & 7)
-                                 : p.dy + (row0 + (lane >> 3)) * p.lddy + 32 * (strip0 + 2 * u) + 8 * (lane & 7);
-      const int64_t ldo = is_dx0 ? p.lddx0 : p.lddy;
+      uint16_t* const orow = (u == 1 ? p.dx0 + (row0 + (lane >> 3)) * p.lddx0 : p.dy + (row0 + (lane >> 3)) * p.lddy) + c0 +
+                             8 * (lane & 7);
+      const int64_t ldo = u == 1 ? p.lddx0 : p.lddy;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -752,27 +779,6 @@ __device__ __forceinline__ void bn_bwd_dx_body(const BnBwdDxArgs& p, unsigned ch
         wave_lds_sync();
       }
     }
-  }
-}
-
-template <int D, int ROLES>
-__global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
-  static_assert(ROLES * 128 == 2 * D, "a block produces 128 virtual columns");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * (D * 2 + 16) + kRgWaves * kStageBytes + 5 * D * 4];
-  if (ROLES == 4) {                                    // D = 256: blocks b, b + 8, b + 16, b + 24 of a group of 32
-    const int role = (blockIdx.x >> 3) & 3;
-    const int64_t vblock = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3), vgrid = gridDim.x / 4;
-    if (role < 2 || !p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, role, vblock, vgrid);
-    else if (role == 2) bn_bwd_dx_body<D, ROLES, true, false>(p, lds, role, vblock, vgrid);
-    else bn_bwd_dx_body<D, ROLES, false, true>(p, lds, role, vblock, vgrid);
-  } else if (ROLES == 2) {                             // D = 128: role 1 owns all of dx0
-    const int role = (blockIdx.x >> 3) & 1;
-    const int64_t vblock = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3), vgrid = gridDim.x / 2;
-    if (role == 0 || !p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, role, vblock, vgrid);
-    else bn_bwd_dx_body<D, ROLES, true, true>(p, lds, role, vblock, vgrid);
-  } else {                                             // D = 64: one block per tile, strips 0-1 d[Ax], 2-3 dx0
-    if (!p.add_gy) bn_bwd_dx_body<D, ROLES, false, false>(p, lds, 0, blockIdx.x, gridDim.x);
-    else bn_bwd_dx_body<D, ROLES, true, true>(p, lds, 0, blockIdx.x, gridDim.x);
   }
 }
 
@@ -1476,13 +1482,15 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
   SGF_REQUIRE(rows16(gy, ldg) && rows16(z, ldz) && rows16(w, ldw) && rows16(dz, lddz) && rows16(dy, lddy) &&
                   (!dx0 || rows16(dx0, lddx0)),
               SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
-  SGF_REQUIRE(static_cast<uint64_t>(n) * static_cast<uint64_t>(lddz) * 2 < 0xffffff00ull, SGF_E_UNSUPPORTED,
-              "%s: dz beyond 4 GiB (32-bit store offsets)", fn);
+  SGF_REQUIRE(static_cast<uint64_t>(n) * static_cast<uint64_t>(lddz) * 2 < 0xffffff00ull &&
+                  static_cast<uint64_t>(n) * static_cast<uint64_t>(ldg) * 2 < 0xffffff00ull &&
+                  static_cast<uint64_t>(n) * static_cast<uint64_t>(ldz) * 2 < 0xffffff00ull,
+              SGF_E_UNSUPPORTED, "%s: gy / z / dz beyond 4 GiB (32-bit offsets)", fn);
   const size_t need = sgf_gcn_epilogue_partial_bytes(n, d);
   SGF_REQUIRE((!acc_in && !acc_out) || acc_bytes >= need, SGF_E_WORKSPACE, "%s: running-sum buffer %zu < %zu", fn, acc_bytes, need);
   SGF_REQUIRE((!acc_in || reinterpret_cast<uintptr_t>(acc_in) % 16 == 0) && (!acc_out || reinterpret_cast<uintptr_t>(acc_out) % 16 == 0),
               SGF_E_INVALID, "%s: running-sum buffers must be 16-byte aligned", fn);
-  const int roles = 2 * d / 128;
+  const int roles = d / 64;
   int vblocks = (grid_blocks(n) + roles - 1) / roles;
   if (roles > 1) {
     vblocks = (vblocks + 7) / 8 * 8;                   // whole groups of 8 tiles' worth of blocks: b, b + 8, ... share an XCD

@@ -1137,7 +1137,12 @@ class GraphView:
         # tiles of community-aligned row blocks — the adoption criterion, whichever kernel then runs
         _, _, max_rows = _tile_params()
         g2.blk_row = K.tile_blocks(comm[perm.long()].contiguous(), g.n, max_rows, g.device)
-        tp = g2.tile_plan(False)
+        try:
+            tp = g2.tile_plan(False)
+        except (ValueError, _lib.SgfError) as e:
+            # a plan the tile kernel cannot take (a row block out of range, nnz beyond its 32-bit offsets): keep the graph
+            # as given rather than fail the forward
+            return GraphView(g, None, None, {"reordered": False, "why": f"tile plan unsupported: {e}"})
         if tp.tile_density < TILE_SPARSE_DENSITY and tp.min_count == TILE_MIN_COUNT and not os.environ.get("SGF_SPMM_TILE"):
             # tiles this sparse (a skewed graph: many sources referenced just twice per block) move more fragment bytes
             # than the gathers they replace: stage only sources with one more reference (power-law community graph at
@@ -1218,6 +1223,7 @@ def _sharded_spmm(graph, x, shard, transposed: bool):
     plan = graph.halo(shard, transposed) if hasattr(graph, "halo") else None
     if plan is not None and plan.enabled:
         if getattr(shard, "overlap", False) and plan.n_halo > 0:
+            shard.overlapped_exchanges = getattr(shard, "overlapped_exchanges", 0) + 1
             # the entries whose source this rank owns are multiplied while the halo rows are on the links; the halo
             # entries follow when they have arrived (their sum is rounded to the storage dtype before it is added: bf16
             # rows with cut edges carry two roundings more than the single-GPU product)
@@ -1269,10 +1275,15 @@ def spmm_on(graph, x: torch.Tensor, transposed: bool, out=None) -> torch.Tensor:
     plan = graph.plan(x.dtype, transposed) if (getattr(graph, "blocked", False) and x.shape[1] <= 256) else None
     if plan is not None:
         return K.spmm_blocked(rp, plan, x, graph.n, out=out, long_segments=segs)
-    if (getattr(graph, "tiled", False) and K.tile_supported(x.shape[1], x.dtype)
-            and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32
-            and (out is None or (out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0))):
-        return K.spmm_tile(graph.tile_plan(transposed), x, graph.n, out=out)
+    if getattr(graph, "tiled", False):
+        if (K.tile_supported(x.shape[1], x.dtype)
+                and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32 - 2048      # = sgf_spmm_tile's own bound
+                and (out is None or (out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0))):
+            return K.spmm_tile(graph.tile_plan(transposed), x, graph.n, out=out)
+        if not K.tile_supported(x.shape[1], x.dtype) and getattr(graph, "_tile_plans", None):
+            # this graph is being multiplied in a storage dtype / width the tile kernel does not take (fp32 runs): the plan
+            # GraphView.decide built for its adoption statistics (about the size of the CSR) is dropped, not kept resident
+            graph._tile_plans.clear()
     if getattr(graph, "locality", False):
         return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs, stream_hint=True)
     return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs)

@@ -44,6 +44,37 @@ class SampledBatch:
         return out
 
 
+class _DeviceGraph:
+    """What every loader over one Data object shares on the device: the in-neighbour CSR (rowptr / colind only — the
+    sampler never reads the normalisation values), the node -> local-id table, the largest in-degree.  100M/nb-sample.py:
+    125-151 builds THREE loaders (train / valid / test) from the same Data: at papers100M scale one copy of the CSR is
+    13 GB and the H2D copy + sort of the edge list 52 GB of transients — once, not three times."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, dev):
+        g = ops.CSRGraph(edge_index.to(dev), int(num_nodes))
+        self.rowptr, self.colind = g.rowptr, g.colind            # in-neighbours of every node
+        self.n = int(num_nodes)
+        self.max_deg = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.n > 0 else 0
+        self.local_of = torch.full((self.n,), torch.iinfo(torch.int32).min, dtype=torch.int32, device=dev)   # not in a batch
+        del g                                                    # frees val / deg
+
+
+# (tensor identity, version, shape, device) -> shared device copies; each entry pins its key tensors so that a recycled
+# data_ptr can never alias it.  Small and bounded: a trainer has one Data object.
+_shared: "dict[tuple, tuple]" = {}
+_SHARED_MAX = 4
+
+
+def _shared_get(kind: str, key_tensors, extra, build):
+    key = (kind, tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in key_tensors), extra)
+    hit = _shared.get(key)
+    if hit is None:
+        while len(_shared) >= _SHARED_MAX:
+            _shared.pop(next(iter(_shared)))
+        hit = _shared[key] = (build(), key_tensors)
+    return hit[0]
+
+
 class NeighborSampler:
     """sample(seeds) -> (n_id int64 [nodes], edge_index int64 [2, edges] in local ids, batch_size)."""
 
@@ -51,16 +82,14 @@ class NeighborSampler:
                  device: Optional[torch.device] = None):
         dev = torch.device(device) if device is not None else (
             edge_index.device if edge_index.is_cuda else torch.device("cuda", torch.cuda.current_device()))
-        g = ops.CSRGraph(edge_index.to(dev), int(num_nodes))
-        self.rowptr, self.colind = g.rowptr, g.colind            # in-neighbours of every node
+        dg = _shared_get("graph", (edge_index,), (int(num_nodes), str(dev)), lambda: _DeviceGraph(edge_index, num_nodes, dev))
+        self.rowptr, self.colind, self.local_of, self.max_deg = dg.rowptr, dg.colind, dg.local_of, dg.max_deg
         self.n, self.device = int(num_nodes), dev
         self.fanouts = [int(k) for k in num_neighbors]
         if any(k > 32 for k in self.fanouts):
             raise ValueError("NeighborSampler: fan-outs above 32 are not supported (use -1 for all neighbours)")
         self.seed = int(seed) & (2 ** 64 - 1)
-        self.local_of = torch.full((self.n,), torch.iinfo(torch.int32).min, dtype=torch.int32, device=dev)   # not in the batch
         self.batches = 0
-        self.max_deg = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.n > 0 else 0
 
     def sample(self, seeds: torch.Tensor, batch_id: Optional[int] = None):
         dev = self.device
@@ -74,6 +103,23 @@ class NeighborSampler:
         with torch.cuda.device(dev):
             _lib.call("sgf_neighbor_sample_mark", _ptr(self.local_of), _ptr(seeds32), bs, 0, st)
             frontier, local0, n_known = seeds32, 0, bs
+            try:
+                self._hops(st, nodes, srcs, dsts, frontier, local0, n_known, batch_id)
+            except BaseException:
+                # a hop failed (workspace, allocation, fan-out overflow): its kernel may have marked nodes that never made
+                # it into `nodes` — stale marks would hand out-of-range local ids to the next batch.  Reset the whole table.
+                self.local_of.fill_(torch.iinfo(torch.int32).min)
+                raise
+            # back to "not in a batch" for every id of this batch
+            n_id32 = torch.cat(nodes)
+            _lib.call("sgf_neighbor_sample_mark", _ptr(self.local_of), _ptr(n_id32), int(n_id32.numel()), -1, st)
+        ei = torch.stack([torch.cat(srcs), torch.cat(dsts)]).long() if srcs else torch.zeros(2, 0, dtype=torch.int64, device=dev)
+        ei._sgf_trusted = True          # local ids are in range by construction: ops.CSRGraph skips its host check
+        return n_id32.long(), ei, bs
+
+    def _hops(self, st, nodes, srcs, dsts, frontier, local0, n_known, batch_id):
+        dev = self.device
+        if True:   # (kept at this depth: the body is the per-hop loop of sample())
             for hop, k in enumerate(self.fanouts):
                 m = int(frontier.numel())
                 if m == 0:
@@ -95,11 +141,6 @@ class NeighborSampler:
                 frontier, local0 = new[:nn].contiguous(), n_known
                 n_known += nn
                 nodes.append(frontier)
-            n_id32 = torch.cat(nodes)
-            _lib.call("sgf_neighbor_sample_mark", _ptr(self.local_of), _ptr(n_id32), int(n_id32.numel()), -1, st)
-        ei = torch.stack([torch.cat(srcs), torch.cat(dsts)]).long() if srcs else torch.zeros(2, 0, dtype=torch.int64, device=dev)
-        ei._sgf_trusted = True          # local ids are in range by construction: ops.CSRGraph skips its host check
-        return n_id32.long(), ei, bs
 
 
 class NeighborLoader:
@@ -116,8 +157,10 @@ class NeighborLoader:
         n = int(x.shape[0])
         self.sampler = NeighborSampler(ei, n, list(num_neighbors), seed=torch.initial_seed() if seed is None else seed,
                                        device=dev)
-        self.x = x.to(dev) if feature_dtype is None else x.to(dev).to(feature_dtype)
-        self.y = y.to(dev) if y is not None else None
+        # the device copies of the features and labels are shared by every loader over the same Data (train / valid / test)
+        self.x = _shared_get("x", (x,), (str(dev), feature_dtype),
+                             lambda: x.to(dev) if feature_dtype is None else x.to(dev).to(feature_dtype))
+        self.y = _shared_get("y", (y,), (str(dev),), lambda: y.to(dev)) if y is not None else None
         if input_nodes is None:
             input_nodes = torch.arange(n)
         elif input_nodes.dtype == torch.bool:

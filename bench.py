@@ -292,6 +292,10 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                      compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
     if ctx is not None:
         shard_model(model, ctx)
+    # the optimizer exactly as the trainer constructs it (large/main.py:114-119); under sgformer_amd.launch — and here —
+    # torch's single-kernel form of the same arithmetic is the default for CUDA parameters (launch.patch_adam)
+    from sgformer_amd import launch as _launch_adam
+    _launch_adam.patch_adam()
     opt = torch.optim.Adam([{"params": model.params1, "weight_decay": 1e-5},
                             {"params": model.params2, "weight_decay": 1e-5}], lr=0.01)
     model.train()

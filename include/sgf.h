@@ -501,6 +501,12 @@ size_t sgf_colstats_workspace_bytes(int64_t n, int32_t d);
 int sgf_colstats(const void* x, int64_t ldx, const float* shift, int64_t n, int32_t d,
                  int32_t dtype, float* stats, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* BatchNorm's bookkeeping between its statistics pass and its apply pass, one launch: from the shifted column sums
+ * sums = [sum (x - shift) | sum (x - shift)^2] over n_total rows (shift may be null):  mean, rstd = 1 / sqrt(var + eps) with
+ * the biased variance, and — when the pointers are given — nn.BatchNorm1d's running update
+ *   running_mean = (1 - momentum) running_mean + momentum mean,  running_var likewise with the UNBIASED variance. */
+int sgf_bn_finalize(const float* sums, const float* shift, double n_total, float eps, float momentum, float* running_mean,
+                    float* running_var, int32_t d, float* mean, float* rstd, void* stream);
 int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const float* rstd,
                  const float* gamma, const float* beta, const void* res, int64_t ldr,
                  int32_t relu, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,
@@ -604,14 +610,16 @@ int sgf_gcn_epilogue_apply(const void* y, int64_t ldy, const float* mean, const 
  * sum in the matrix cores' accumulator layout (bf16); the LAST call passes dx0 != null (and acc_out = null) and gets the
  * total row-major.  Exactly one of acc_out / dx0 is non-null.  gy and z leave HBM once: the workgroups that produce the
  * 2 d virtual output columns of one row tile (128 columns each) are launched 8 apart, i.e. on one XCD, and share the tiles
- * through its L2 (placement affects traffic only).  inv_n = 1 / (global row count); training = 0: running statistics (no
- * mean terms). */
+ * through its L2 (placement affects traffic only); with a workspace (sgf_gcn_bn_bwd_dx_workspace_bytes, may be null) those
+ * workgroups meet once per tile — a bounded wait on device-scope counters, timing only — so that they stay inside the L2's
+ * window.  inv_n = 1 / (global row count); training = 0: running statistics (no mean terms). */
 int32_t sgf_gcn_bn_bwd_dx_supported(int32_t d, int32_t dtype);
+size_t sgf_gcn_bn_bwd_dx_workspace_bytes(int64_t n, int32_t d);   /* arrival counters of the per-tile rendezvous (optional) */
 int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,
                       int32_t training, const void* w, int64_t ldw, int64_t n, int32_t d, int32_t dtype, void* dz,
                       int64_t lddz, void* dy, int64_t lddy, const void* acc_in, void* acc_out, size_t acc_bytes,
-                      void* dx0, int64_t lddx0, int32_t add_gy, void* stream);
+                      void* dx0, int64_t lddx0, int32_t add_gy, void* workspace, size_t workspace_bytes, void* stream);
 /* The same two-operand Linear in ONE pass over a1 and a2 (bf16 storage, d = d_in = d_out in {64, 128, 256}; W [d, 2 d]):
  *   y = [a1 | a2] W^T + bias  [+ stats, as sgf_gcn_epilogue_stats].   d <= 128: W (64 KiB) is resident in LDS whole.
  *   d = 256: W is 256 KiB, more than a CU's LDS, so the launch is PAIRED — workgroups b and b + 8 (one XCD) walk the same

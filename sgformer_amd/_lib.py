@@ -103,6 +103,7 @@ SIGNATURES = {
                              _P, _P, c_size_t, _P]),
     "sgf_colstats_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_colstats": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_bn_finalize": (c_int32, [_P, _P, c_double, c_float, c_float, _P, _P, c_int32, _P, _P, _P]),
     "sgf_bn_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
     "sgf_bn_bwd_stats": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, c_int64, c_int32,
@@ -138,9 +139,10 @@ SIGNATURES = {
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
     "sgf_gcn_bn_bwd_dx_supported": (c_int32, [c_int32, c_int32]),
+    "sgf_gcn_bn_bwd_dx_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_gcn_bn_bwd_dx": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float, c_int32, _P, c_int64,
                                     c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, _P, c_size_t, _P, c_int64,
-                                    c_int32, _P]),
+                                    c_int32, _P, c_size_t, _P]),
     "sgf_gcn_epilogue_cat_supported": (c_int32, [c_int32, c_int32]),
     "sgf_gcn_epilogue_cat": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64,
                                        _P, _P, _P, c_size_t, _P]),

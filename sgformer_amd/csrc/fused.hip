@@ -1114,6 +1114,36 @@ extern "C" int sgf_colstats(const void* x, int64_t ldx, const float* shift, int6
                    workspace, st);
 }
 
+// BatchNorm's per-column bookkeeping between its two passes, in ONE launch (it was ~14 tiny ATen launches per BatchNorm
+// and step): mean / biased variance from the shifted sums, rstd, and the running-statistics update of nn.BatchNorm1d.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ sums, const float* __restrict__ shift,
+                                                     float inv_n, float unbias, float eps, float momentum,
+                                                     float* __restrict__ rmean, float* __restrict__ rvar, int d,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float m1 = sums[c] * inv_n;
+  const float mu = (shift ? shift[c] : 0.f) + m1;
+  float var = sums[d + c] * inv_n - m1 * m1;
+  var = var > 0.f ? var : 0.f;
+  mean[c] = mu;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (rmean) rmean[c] = rmean[c] * (1.0f - momentum) + momentum * mu;
+  if (rvar) rvar[c] = rvar[c] * (1.0f - momentum) + momentum * (var * unbias);
+}
+
+extern "C" int sgf_bn_finalize(const float* sums, const float* shift, double n_total, float eps, float momentum,
+                               float* running_mean, float* running_var, int32_t d, float* mean, float* rstd, void* stream) {
+  SGF_REQUIRE(d >= 1 && n_total >= 0, SGF_E_INVALID, "sgf_bn_finalize: bad sizes");
+  SGF_REQUIRE(sums && mean && rstd, SGF_E_INVALID, "sgf_bn_finalize: null pointer");
+  const double nn = n_total > 1.0 ? n_total : 1.0;
+  const float unbias = static_cast<float>(n_total / (n_total - 1.0 > 1.0 ? n_total - 1.0 : 1.0));
+  hipLaunchKernelGGL(k_bn_finalize, dim3((d + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums, shift,
+                     static_cast<float>(1.0 / nn), unbias, eps, momentum, running_mean, running_var, d, mean, rstd);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
 extern "C" int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const float* rstd,
                             const float* gamma, const float* beta, const void* res, int64_t ldr,
                             int32_t relu, int64_t n, int32_t d, int32_t dtype, void* y, int64_t ldy,

@@ -507,6 +507,7 @@ struct BnBwdDxArgs {
   uint16_t* dx0; int64_t lddx0;                        // out, row-major (the last layer of the chain), or null
   int add_gy;                                          // the layer has the residual  + x0
   int64_t n;
+  uint32_t* sync;                                      // [virtual blocks][8 waves] arrival counters, zeroed before the launch
 };
 
 // Every block of a tile's group does the SAME work (so none of them drifts away from the others and out of the L2 window — a
@@ -516,7 +517,38 @@ struct BnBwdDxArgs {
 // columns of exactly those k-steps (they are its dx0 strips' own columns) through the identity fragments.  With RING = 4
 // k-steps per phase that is: "in phase r of the tile, also store dz and run the identity multiplies" — one uniform branch
 // per phase, none inside a phase.
-template <int D, int ROLES, bool MINE>
+// Cache policy of the streams only ONE block touches (gfx950 buffer instructions, aux operand): the outputs are written
+// through and dropped from the XCD's L2 (sc1), the running sum is read with the streaming hint (nt) — the L2 then holds
+// what the blocks of a group SHARE, the gy / z tiles, for long enough that the blocks behind the first one find them
+// (with plain stores the write-allocated lines pushed them out first: PMC showed gy and z leaving HBM four times).
+constexpr int kStreamOut = 16;                         // sc1
+constexpr int kStreamIn = 2;                           // nt
+
+// Rendezvous of the ROLES waves (one per block of a group) that walk the same tiles, once per tile: the blocks share
+// the gy / z tiles through their XCD's L2, which keeps a line for a few microseconds only — left alone, the four blocks
+// drift apart (nothing pulls them back together: the waves wait on LDS and the matrix cores, not on these loads) and each
+// fetches the tiles from HBM for itself (PMC: 9 T of reads instead of 3 T).  Timing only, no data is handed over, so relaxed
+// device-scope atomics suffice.  BOUNDED: a wave that waits longer than ~1 ms (its partners are not resident — the grid
+// exceeds the free CUs) gives up for the rest of the launch; the result never depends on the rendezvous.
+__device__ __forceinline__ bool tile_rendezvous(uint32_t* cnt, uint32_t target, int lane) {
+  uint32_t ok = 1;
+  if (lane == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > 4000) {
+        ok = 0;
+        break;
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+
+// DBG (timing ablations only, SGF_GCN_BWD_DEBUG; results are then wrong): 1 no element-wise work (dz = gy), 2 no matrix-core
+// work, 4 no stores, 8 no re-loads of the fragment slots
+template <int D, int ROLES, bool MINE, int DBG>
 __device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], bf16x8 (&Z)[4], f32x16 (&acc)[4],
                                                 const float* __restrict__ coef, const unsigned char* __restrict__ bfrag0,
                                                 const unsigned char* __restrict__ identp, const __amdgpu_buffer_rsrc_t dzrsrc,
@@ -534,9 +566,9 @@ __device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], 
     const uint4 gq = *reinterpret_cast<const uint4*>(&G[j]);
     const uint4 zq = *reinterpret_cast<const uint4*>(&Z[j]);
     const uint32_t gu[4] = {gq.x, gq.y, gq.z, gq.w}, zu[4] = {zq.x, zq.y, zq.z, zq.w};
-    uint32_t du[4];
+    uint32_t du[4] = {gq.x ^ zq.x, gq.y ^ zq.y, gq.z ^ zq.z, gq.w ^ zq.w};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < ((DBG & 1) ? 0 : 2); ++h) {
       const float4 t1 = *reinterpret_cast<const float4*>(cf + 4 * h);
       const float4 t0 = *reinterpret_cast<const float4*>(cf + D + 4 * h);
       const float4 a1 = *reinterpret_cast<const float4*>(cf + 2 * D + 4 * h);
@@ -560,11 +592,13 @@ __device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], 
     const u32x4 dq = {du[0], du[1], du[2], du[3]};
     dzr[j] = *reinterpret_cast<const bf16x8*>(&dq);
     // a lane past the last row gets an out-of-range offset, which the hardware drops (no branch)
-    if (MINE) __builtin_amdgcn_raw_buffer_store_b128(dq, dzrsrc, row_ok ? dzoff + 32u * s : 0xffffff00u, 0, 0);
+    if (MINE && !(DBG & 4))
+      __builtin_amdgcn_raw_buffer_store_b128(dq, dzrsrc, row_ok ? dzoff + 32u * s : 0xffffff00u, 0, kStreamOut);
     // step s + RING (of this tile, or of the next one) into the slots just consumed; gy's slot stays until phase (B) when
     // it still has to go through the identity multiply
     const uint32_t rz = s + RING < KS ? czo + 32u * (s + RING) : nzo + 32u * (s + RING - KS);
     const uint32_t rg = s + RING < KS ? cgo + 32u * (s + RING) : ngo + 32u * (s + RING - KS);
+    if (DBG & 8) continue;
     const u32x4 zl = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, static_cast<int>(rz), 0, 0);
     Z[j] = *reinterpret_cast<const bf16x8*>(&zl);
     if (!MINE) {
@@ -577,6 +611,10 @@ __device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], 
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
     const int s = half * RING + j;
+    if (DBG & 2) {
+      acc[j][0] += __uint_as_float(static_cast<uint32_t>(dzr[j][0]) << 16);
+      continue;
+    }
 #pragma unroll
     for (int w = 0; w < NS; ++w) {
       const bf16x8 b = *reinterpret_cast<const bf16x8*>(bfrag0 + 32 * w * BT + 32 * s);
@@ -587,15 +625,17 @@ __device__ __forceinline__ void bn_bwd_dx_phase(const int half, bf16x8 (&G)[4], 
       // identity fragment (exact)
       const bf16x8 idf = *reinterpret_cast<const bf16x8*>(identp + 1024 * (j & 1));
       acc[2 + (j >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[j], idf, acc[2 + (j >> 1)], 0, 0, 0);
-      const uint32_t rg = s + RING < KS ? cgo + 32u * (s + RING) : ngo + 32u * (s + RING - KS);
-      const u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(grsrc, static_cast<int>(rg), 0, 0);
-      G[j] = *reinterpret_cast<const bf16x8*>(&gl);
+      if (!(DBG & 8)) {
+        const uint32_t rg = s + RING < KS ? cgo + 32u * (s + RING) : ngo + 32u * (s + RING - KS);
+        const u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(grsrc, static_cast<int>(rg), 0, 0);
+        G[j] = *reinterpret_cast<const bf16x8*>(&gl);
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int D, int ROLES>
+template <int D, int ROLES, int DBG = 0>
 __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p) {
   constexpr int KS = D / 16;                           // k-steps
   constexpr int RING = 4;                              // fragment slots per stream: step s lives in slot s % RING and is
@@ -672,6 +712,14 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
   const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.z), 0, static_cast<uint32_t>(static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.ldz) * 2), 0x00020000);
   const unsigned char* const identp = identl + 16 * lane;
+  const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.dy, 0, static_cast<uint32_t>(static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.lddy) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dxrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.dx0, 0, p.dx0 ? static_cast<uint32_t>(static_cast<uint64_t>(p.n) * static_cast<uint64_t>(p.lddx0) * 2) : 0u, 0x00020000);
+  const uint32_t acc_bytes = static_cast<uint32_t>(((p.n + 31) / 32) * (NSD * 2 * 64 * 16));
+  const __amdgpu_buffer_rsrc_t airsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.acc_in), 0, p.acc_in ? acc_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t aorsrc = __builtin_amdgcn_make_buffer_rsrc(p.acc_out, 0, p.acc_out ? acc_bytes : 0u, 0x00020000);
 
   bf16x8 G[RING], Z[RING];
   int64_t t = vblock * kRgWaves + wave;
@@ -692,7 +740,14 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
     }
   }
 
+  uint32_t* const my_sync = p.sync + vblock * kRgWaves + wave;
+  bool in_step = ROLES > 1 && p.sync != nullptr;
+  uint32_t arrivals = 0;
   for (; t < ntiles; t += nwaves) {
+    if (in_step) {
+      arrivals += ROLES;
+      in_step = tile_rendezvous(my_sync, arrivals, lane);
+    }
     const int64_t tn = t + nwaves;
     const bool has_next = tn < ntiles;
     const int64_t row0 = t * 32;
@@ -712,20 +767,22 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
 #pragma unroll
     for (int half = 0; half < KS / RING; ++half) {
       if (half == role)
-        bn_bwd_dx_phase<D, ROLES, true>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz, ng,
-                                        nz, hi);
+        bn_bwd_dx_phase<D, ROLES, true, DBG>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz,
+                                             ng, nz, hi);
       else
-        bn_bwd_dx_phase<D, ROLES, false>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz, ng,
-                                         nz, hi);
+        bn_bwd_dx_phase<D, ROLES, false, DBG>(half, G, Z, acc, coef, bfrag0, identp, dzrsrc, dzoff, row_ok, grsrc, zrsrc, cg, cz,
+                                              ng, nz, hi);
     }
 
     // ---- epilogue: the d[Ax] pair leaves row-major through the patch; the dx0 pair row-major or in accumulator layout ----
+    const uint32_t acc_off = static_cast<uint32_t>((t * (NSD * 2 * 64) + (2 * role * 2) * 64 + lane) * 16);
     if (p.acc_in != nullptr) {                         // the running dx0 of this tile's two strips
-      uint4 av[2][2];
+      u32x4 av[2][2];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) av[c][q] = p.acc_in[t * (NSD * 2 * 64) + ((2 * role + c) * 2 + q) * 64 + lane];
+        for (int q = 0; q < 2; ++q)
+          av[c][q] = __builtin_amdgcn_raw_buffer_load_b128(airsrc, static_cast<int>(acc_off + (c * 2 + q) * 1024), 0, kStreamIn);
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -745,18 +802,17 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            uint4 v;
-            v.x = cvt_pk_bf16(acc[2 + c][8 * q + 0], acc[2 + c][8 * q + 1]);
-            v.y = cvt_pk_bf16(acc[2 + c][8 * q + 2], acc[2 + c][8 * q + 3]);
-            v.z = cvt_pk_bf16(acc[2 + c][8 * q + 4], acc[2 + c][8 * q + 5]);
-            v.w = cvt_pk_bf16(acc[2 + c][8 * q + 6], acc[2 + c][8 * q + 7]);
-            p.acc_out[t * (NSD * 2 * 64) + ((2 * role + c) * 2 + q) * 64 + lane] = v;
+            const u32x4 v = {cvt_pk_bf16(acc[2 + c][8 * q + 0], acc[2 + c][8 * q + 1]),
+                             cvt_pk_bf16(acc[2 + c][8 * q + 2], acc[2 + c][8 * q + 3]),
+                             cvt_pk_bf16(acc[2 + c][8 * q + 4], acc[2 + c][8 * q + 5]),
+                             cvt_pk_bf16(acc[2 + c][8 * q + 6], acc[2 + c][8 * q + 7])};
+            if (!(DBG & 4))
+              __builtin_amdgcn_raw_buffer_store_b128(v, aorsrc, static_cast<int>(acc_off + (c * 2 + q) * 1024), 0, kStreamOut);
           }
         continue;
       }
-      uint16_t* const orow = (u == 1 ? p.dx0 + (row0 + (lane >> 3)) * p.lddx0 : p.dy + (row0 + (lane >> 3)) * p.lddy) + c0 +
-                             8 * (lane & 7);
       const int64_t ldo = u == 1 ? p.lddx0 : p.lddy;
+      const uint32_t ooff = static_cast<uint32_t>(((row0 + (lane >> 3)) * ldo + c0 + 8 * (lane & 7)) * 2);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -772,9 +828,13 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_bn_bwd_dx_bf16(BnBwdDxArgs p)
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
-          if (!tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n)
-            *reinterpret_cast<uint4*>(orow + (16 * hh + 8 * q) * ldo) = v;
+          const uint4 v4 = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          const u32x4 v = {v4.x, v4.y, v4.z, v4.w};
+          const bool ok = !tail || row0 + 16 * hh + 8 * q + (lane >> 3) < p.n;
+          const uint32_t off = ok ? ooff + static_cast<uint32_t>((16 * hh + 8 * q) * ldo * 2) : 0xffffff00u;
+          if (DBG & 4) continue;
+          if (u == 1) __builtin_amdgcn_raw_buffer_store_b128(v, dxrsrc, static_cast<int>(off), 0, kStreamOut);
+          else __builtin_amdgcn_raw_buffer_store_b128(v, dyrsrc, static_cast<int>(off), 0, kStreamOut);
         }
         wave_lds_sync();
       }
@@ -1464,11 +1524,17 @@ extern "C" int32_t sgf_gcn_bn_bwd_dx_supported(int32_t d, int32_t dtype) {
   return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) ? 1 : 0;
 }
 
+extern "C" size_t sgf_gcn_bn_bwd_dx_workspace_bytes(int64_t n, int32_t d) {
+  (void)n; (void)d;
+  return static_cast<size_t>(kNumCU) * kRgWaves * sizeof(uint32_t);
+}
+
 extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int64_t ldz, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* stats,
                                  float inv_n, int32_t training, const void* w, int64_t ldw, int64_t n, int32_t d,
                                  int32_t dtype, void* dz, int64_t lddz, void* dy, int64_t lddy, const void* acc_in,
-                                 void* acc_out, size_t acc_bytes, void* dx0, int64_t lddx0, int32_t add_gy, void* stream) {
+                                 void* acc_out, size_t acc_bytes, void* dx0, int64_t lddx0, int32_t add_gy, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   const char* fn = "sgf_gcn_bn_bwd_dx";
   SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
   SGF_REQUIRE(sgf_gcn_bn_bwd_dx_supported(d, dtype), SGF_E_UNSUPPORTED,
@@ -1484,8 +1550,10 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
               SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
   SGF_REQUIRE(static_cast<uint64_t>(n) * static_cast<uint64_t>(lddz) * 2 < 0xffffff00ull &&
                   static_cast<uint64_t>(n) * static_cast<uint64_t>(ldg) * 2 < 0xffffff00ull &&
-                  static_cast<uint64_t>(n) * static_cast<uint64_t>(ldz) * 2 < 0xffffff00ull,
-              SGF_E_UNSUPPORTED, "%s: gy / z / dz beyond 4 GiB (32-bit offsets)", fn);
+                  static_cast<uint64_t>(n) * static_cast<uint64_t>(ldz) * 2 < 0xffffff00ull &&
+                  static_cast<uint64_t>(n) * static_cast<uint64_t>(lddy) * 2 < 0xffffff00ull &&
+                  (!dx0 || static_cast<uint64_t>(n) * static_cast<uint64_t>(lddx0) * 2 < 0xffffff00ull),
+              SGF_E_UNSUPPORTED, "%s: an operand beyond 4 GiB (32-bit offsets)", fn);
   const size_t need = sgf_gcn_epilogue_partial_bytes(n, d);
   SGF_REQUIRE((!acc_in && !acc_out) || acc_bytes >= need, SGF_E_WORKSPACE, "%s: running-sum buffer %zu < %zu", fn, acc_bytes, need);
   SGF_REQUIRE((!acc_in || reinterpret_cast<uintptr_t>(acc_in) % 16 == 0) && (!acc_out || reinterpret_cast<uintptr_t>(acc_out) % 16 == 0),
@@ -1499,11 +1567,26 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
   BnBwdDxArgs a{static_cast<const uint16_t*>(gy), ldg, static_cast<const uint16_t*>(z), ldz, mean, rstd, gamma, beta,
                 stats, inv_n, training, relu, static_cast<const uint16_t*>(w), ldw, static_cast<uint16_t*>(dz), lddz,
                 static_cast<uint16_t*>(dy), lddy, static_cast<const uint4*>(acc_in), static_cast<uint4*>(acc_out),
-                static_cast<uint16_t*>(dx0), lddx0, add_gy, n};
+                static_cast<uint16_t*>(dx0), lddx0, add_gy, n, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // the per-tile rendezvous of a group's blocks (optional: without a workspace, or under SGF_GCN_BWD_SYNC=0, they run free)
+  static EnvInt sync_env{"SGF_GCN_BWD_SYNC", 1};
+  if (roles > 1 && workspace && workspace_bytes >= sgf_gcn_bn_bwd_dx_workspace_bytes(n, d) && sync_env.get() != 0 &&
+      reinterpret_cast<uintptr_t>(workspace) % 4 == 0) {
+    a.sync = static_cast<uint32_t*>(workspace);
+    SGF_CHECK_HIP(hipMemsetAsync(workspace, 0, sgf_gcn_bn_bwd_dx_workspace_bytes(n, d), st));
+  }
   if (d == 64) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<64, 1>), dim3(vblocks), dim3(kRgThreads), 0, st, a);
   else if (d == 128) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<128, 2>), dim3(vblocks * 2), dim3(kRgThreads), 0, st, a);
-  else hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a);
+  else {
+    static EnvInt dbg_env{"SGF_GCN_BWD_DEBUG", 0};
+    switch (dbg_env.get()) {
+#define SGF_BWD_DBG(X) case X: hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4, X>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a); break;
+      SGF_BWD_DBG(1) SGF_BWD_DBG(2) SGF_BWD_DBG(3) SGF_BWD_DBG(4) SGF_BWD_DBG(8) SGF_BWD_DBG(12) SGF_BWD_DBG(15)
+#undef SGF_BWD_DBG
+      default: hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a); break;
+    }
+  }
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

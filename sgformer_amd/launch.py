@@ -166,6 +166,28 @@ def patch_nll_loss():
     return orig
 
 
+def patch_adam():
+    """torch.optim.Adam as the trainers construct it (large/main.py:114-119: two parameter groups, no `fused` / `foreach`
+    argument) runs its for-each form: ~12 multi-tensor launches per group and step.  For CUDA parameters torch's own
+    single-kernel form (`fused=True`, same arithmetic) becomes the default here; an explicit `fused` / `foreach` argument of
+    the trainer is respected.  SGF_FUSED_ADAM=0 leaves torch.optim.Adam alone."""
+    import torch
+    if os.environ.get("SGF_FUSED_ADAM", "1") == "0" or getattr(torch.optim.Adam, "_sgf_patched", False):
+        return
+    orig_init = torch.optim.Adam.__init__
+
+    def __init__(self, params, *args, **kwargs):
+        params = list(params)
+        if "fused" not in kwargs and "foreach" not in kwargs and len(args) < 6:
+            flat = [p for grp in params for p in (grp["params"] if isinstance(grp, dict) else [grp])]
+            if flat and all(torch.is_tensor(p) and p.is_cuda and p.is_floating_point() for p in flat):
+                kwargs["fused"] = True
+        orig_init(self, params, *args, **kwargs)
+
+    torch.optim.Adam.__init__ = __init__
+    torch.optim.Adam._sgf_patched = True
+
+
 def unpatch_nll_loss():
     import torch.nn.functional as F
     orig = getattr(F.nll_loss, "_sgf_orig", None)
@@ -245,6 +267,7 @@ def main(argv=None):
         patch_neighbor_loader()
     if aten_loss is None:
         patch_nll_loss()
+    patch_adam()
     if os.path.basename(trainer) == "main-batch.py":
         limit_host_threads()
         if host_features is None:

@@ -538,6 +538,17 @@ class HipKernels:
         return stats
 
     @staticmethod
+    def bn_finalize(sums, shift, n_total: float, eps: float, momentum: float, running_mean, running_var):
+        """(mean, rstd) fp32 [d] from the shifted sums; running_mean / running_var (fp32, or None) updated in place."""
+        d = sums.numel() // 2
+        mean = torch.empty(d, dtype=_F32, device=sums.device)
+        rstd = torch.empty(d, dtype=_F32, device=sums.device)
+        with torch.cuda.device(sums.device):
+            _lib.call("sgf_bn_finalize", _ptr(sums), _ptr(shift), float(n_total), float(eps), float(momentum),
+                      _ptr(running_mean), _ptr(running_var), d, _ptr(mean), _ptr(rstd), _stream(sums.device))
+        return mean, rstd
+
+    @staticmethod
     def bn_apply(x, mean, rstd, gamma, beta, res, relu: bool) -> torch.Tensor:
         n, d = x.shape
         dev = x.device
@@ -796,11 +807,12 @@ class HipKernels:
         nbytes = _lib.load().sgf_gcn_epilogue_partial_bytes(n, d)
         acc_out = None if last else torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         dx0 = torch.empty((n, d), dtype=z.dtype, device=dev) if last else None
+        ws = _workspace(dev, "gcn_bwd_sync", _lib.load().sgf_gcn_bn_bwd_dx_workspace_bytes(n, d))
         with torch.cuda.device(dev):
             _lib.call("sgf_gcn_bn_bwd_dx", _ptr(gy), _ld(gy), _ptr(z), _ld(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
                       int(relu), _ptr(stats), float(inv_n), int(training), _ptr(w), w.stride(0), n, d, _code(z), _ptr(dz),
                       _ld(dz), _ptr(dy), _ld(dy), _ptr(acc_in), _ptr(acc_out), nbytes, _ptr(dx0), _ld(dx0), int(add_gy),
-                      _stream(dev))
+                      _ptr(ws), ws.numel(), _stream(dev))
         return dz, dy, (dx0 if last else acc_out)
 
     @staticmethod
@@ -1976,18 +1988,23 @@ class _StemPairBN(torch.autograd.Function):
         if want:
             ns = min(n, _BN_SAMPLE_ROWS)
             _, _, st_s = K.stem_pair(x[:ns], w0c, f32[0], None, None, None, want_stats0=True)
-            samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
             n_tot = float(n)
-            if shard is not None:
+            if shard is None:
+                shift = st_s[:d] * (1.0 / float(max(ns, 1)))
+            else:
+                samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
                 shard.all_reduce(samp)
                 n_tot = float(shard.n_global)
-            shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
+                shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
         y0, y1, st = K.stem_pair(x, w0c, f32[0], w1c, f32[1], shift, want_stats0=want)
         if want:
             if shard is not None:
                 shard.all_reduce(st)
-            m1 = st[:d] / max(n_tot, 1.0)
-            mean, rstd, n_tot, training = bn_hook((shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot))
+            if hasattr(K, "bn_finalize"):
+                mean, rstd, n_tot, training = bn_hook(("raw", st, shift, n_tot))
+            else:
+                m1 = st[:d] / max(n_tot, 1.0)
+                mean, rstd, n_tot, training = bn_hook((shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot))
         else:
             mean, rstd, n_tot, training = bn_hook(False)
         g32 = gamma.detach().float().contiguous() if gamma is not None else None
@@ -2085,15 +2102,20 @@ def _linear_with_stats(xr, wc, b32, stats_req):
     n, d = xr[0].shape[0], wc.shape[0]
     ns = min(n, _BN_SAMPLE_ROWS)
     _, st_s = _streaming_linear(xr, wc, b32, None, want_stats=True, rows=ns)
-    samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=xr[0].device)])
     n_tot = float(n)
-    if shard is not None:
+    if shard is None:
+        shift = st_s[:d] * (1.0 / float(max(ns, 1)))          # one launch; the sharded form needs the global sample count
+    else:
+        samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=xr[0].device)])
         shard.all_reduce(samp)
         n_tot = float(shard.n_global)
-    shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
+        shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
     y, st = _streaming_linear(xr, wc, b32, shift, want_stats=True)
     if shard is not None:
         shard.all_reduce(st)
+    if stats_req.get("raw"):
+        stats_req["out"] = ("raw", st, shift, n_tot)              # the caller finalises (K.bn_finalize: one launch)
+        return y
     m1 = st[:d] / max(n_tot, 1.0)
     stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
     return y
@@ -2103,13 +2125,24 @@ def _linear_with_stats(xr, wc, b32, stats_req):
 # T4 + T6 as ONE autograd node: out = [relu](BatchNorm(W [y | x0] + b)) [+ x0]   (large/ours.py:36-40, 87-93)
 # ------------------------------------------------------------------------------------------------
 class GradChain:
-    """The gradient of x0 = layer_[0] of one GraphConv forward, accumulated across its layers' backward nodes (which run in
-    reverse layer order: layer i's input is layer i-1's output).  Every layer's fused backward kernel adds its two
-    contributions (the residual's gy and dz W[:, d:]) to the running sum it is handed; the FIRST layer's node — the last to
-    run — gets the total row-major and returns it to autograd, the others return nothing for x0."""
+    """The gradient of x0 = layer_[0] of one GraphConv forward, collected across its layers' backward nodes (which run in
+    reverse layer order: layer i's input is layer i-1's output) and returned to autograd ONCE, by the first layer's node —
+    the last to run; the others return nothing for x0.  Two forms:
+      * fused kernel (SGF_GCN_BWD_FUSED=1): every layer's sgf_gcn_bn_bwd_dx adds its two contributions (the residual's gy
+        and dz W[:, d:]) to the running sum it is handed (`acc`, opaque);
+      * default: the contributions are kept (`parts`) and summed in one pass (sgf_sum_n) by the first layer's node."""
 
     def __init__(self):
         self.acc = None
+        self.parts = []
+
+
+def _fused_bwd() -> bool:
+    """sgf_gcn_bn_bwd_dx in the layers' backward.  Off by default: at d = 256 the four workgroups per row tile do not stay
+    inside the L2's window on their own (gy / z leave HBM four times) and with the per-tile rendezvous the launch is bound
+    by its own serial phases — 2.4-4.4 ms against 2.1 ms for the separate kernels (profiles/r04_bn_bwd_dx_*.md)."""
+    import os
+    return os.environ.get("SGF_GCN_BWD_FUSED", "0") == "1"
 
 
 def gcn_layer_fused_ok(x0: torch.Tensor, w: torch.Tensor) -> bool:
@@ -2138,7 +2171,7 @@ class _LinearBNActRes(torch.autograd.Function):
         yr, xr = _rows16(y), _rows16(x0)
         want = bn_hook(None)                         # does the BatchNorm normalise with batch statistics?
         if want:
-            req = {"shard": shard, "out": None}
+            req = {"shard": shard, "out": None, "raw": hasattr(K, "bn_finalize")}
             z = _linear_with_stats([yr, xr], wc, b32, req)
             mean, rstd, n_tot, training = bn_hook(req["out"])
         else:
@@ -2163,10 +2196,24 @@ class _LinearBNActRes(torch.autograd.Function):
         stats = K.bn_bwd_stats(gout, z, mean, rstd, g32, be32, relu)
         if shard is not None:
             shard.all_reduce(stats)
-        dz, dy, acc = K.gcn_bn_bwd_dx(gout, z, mean, rstd, g32, be32, relu, stats, 1.0 / max(n_tot, 1.0), training, wc,
-                                      chain.acc, last=first, add_gy=use_res)
-        chain.acc = None if first else acc
-        dx0 = acc if first else None
+        inv_n = 1.0 / max(n_tot, 1.0)
+        if _fused_bwd():
+            dz, dy, acc = K.gcn_bn_bwd_dx(gout, z, mean, rstd, g32, be32, relu, stats, inv_n, training, wc, chain.acc,
+                                          last=first, add_gy=use_res)
+            chain.acc = None if first else acc
+            dx0 = acc if first else None
+        else:
+            # BatchNorm backward, then BOTH input gradients from one HBM read of dz (paired launch); x0's contributions wait
+            # in the chain for the one summation pass
+            dz = K.bn_bwd_apply(gout, z, mean, rstd, g32, be32, relu, stats, inv_n, training)
+            dy, dxi = K.gcn_epilogue_dx2(dz, wc[:, :d], wc[:, d:], True)
+            chain.parts.append(dxi)
+            if use_res:
+                chain.parts.append(gout)
+            dx0 = None
+            if first:
+                parts, chain.parts = chain.parts, []
+                dx0 = parts[0] if len(parts) == 1 else (K.sum_n(parts) if len(parts) <= 8 else sum(parts[1:], parts[0]))
         dw, db = _linear_param_grads(dz, [yr, xr], [d, d], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and bdt is not None,
                                      wdt, bdt)
         dgamma = stats[d:].to(gdt) if g32 is not None else None

@@ -237,6 +237,25 @@ class GraphConv(nn.Module):
             use_batch = _uses_batch_stats(self, bn)
             if stats is None:
                 return use_batch
+            if use_batch and stats[0] == "raw":
+                # (sums, shift, count) as the statistics pass left them: mean, rstd and the running update in ONE launch
+                _, sums, shift, n_tot = stats
+                if n_tot <= 1 and self.training:
+                    raise ValueError("Expected more than 1 value per channel when training")
+                track = self.training and bn.track_running_stats and bn.running_mean is not None
+                if track and bn.momentum is not None and bn.running_mean.dtype == torch.float32:
+                    with torch.no_grad():
+                        bn.num_batches_tracked += 1
+                        mean, rstd = ops.K.bn_finalize(sums, shift, n_tot, bn.eps, float(bn.momentum), bn.running_mean,
+                                                       bn.running_var)
+                    return mean, rstd, n_tot, True
+                if not track:
+                    mean, rstd = ops.K.bn_finalize(sums, shift, n_tot, bn.eps, 0.0, None, None)
+                    return mean, rstd, n_tot, True
+                d = sums.numel() // 2                    # cumulative moving average (momentum None) / non-fp32 buffers
+                m1 = sums[:d] / max(n_tot, 1.0)
+                stats = ((shift + m1) if shift is not None else m1, (sums[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0),
+                         n_tot)
             if use_batch:
                 mean, var, n_tot = stats
                 if n_tot <= 1 and self.training:

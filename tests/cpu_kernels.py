@@ -109,6 +109,10 @@ class CpuKernels:
         return dz, dy, acc.to(z.dtype)
 
     @staticmethod
+    def gcn_epilogue_dx2(dy, w1, w2, pair=True):
+        return CpuKernels.gcn_epilogue_dx(dy, w1), CpuKernels.gcn_epilogue_dx(dy, w2)
+
+    @staticmethod
     def stem_pair_supported(d_in, d_out, dtype):
         return dtype == torch.bfloat16 and d_in % 4 == 0 and d_in <= 128 and d_out in (64, 128, 256)
 
@@ -357,6 +361,19 @@ class CpuKernels:
     def _bn(x, mean, rstd, gamma, beta):
         xh = (x.float() - mean) * rstd
         return xh, xh * (gamma if gamma is not None else 1.0) + (beta if beta is not None else 0.0)
+
+    @staticmethod
+    def bn_finalize(sums, shift, n_total, eps, momentum, running_mean, running_var):
+        d = sums.numel() // 2
+        n = max(float(n_total), 1.0)
+        m1 = sums[:d] / n
+        mean = (shift if shift is not None else 0.0) + m1
+        var = (sums[d:] / n - m1 * m1).clamp_min(0.0)
+        if running_mean is not None:
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+        if running_var is not None:
+            running_var.mul_(1.0 - momentum).add_(var * (float(n_total) / max(float(n_total) - 1.0, 1.0)), alpha=momentum)
+        return mean, torch.rsqrt(var + eps)
 
     @staticmethod
     def bn_apply(x, mean, rstd, gamma, beta, res, relu):

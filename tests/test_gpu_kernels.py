@@ -946,6 +946,31 @@ def test_gcn_epilogue_cat_one_pass(cuda, n, d):
     assert _rel(st4[:d], y4.double().sum(0)) <= 2e-6 or float(y4.double().sum(0).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("d,shifted,track", [(64, True, True), (256, False, True), (100, True, False), (257, True, True)])
+def test_bn_finalize_matches_batchnorm_bookkeeping(cuda, d, shifted, track):
+    """sgf_bn_finalize = what nn.BatchNorm1d does between its two passes (large/ours.py:87-88): batch mean / biased variance
+    from the shifted sums, rstd = 1 / sqrt(var + eps), running_mean / running_var (unbiased) with momentum — against fp64."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(d)
+    n = 5000
+    x = torch.randn(n, d, generator=g, dtype=torch.float64) * 1.7 + 0.4
+    shift = x[:100].mean(0) if shifted else None
+    v = x - (shift if shifted else 0.0)
+    sums = torch.cat([v.sum(0), (v * v).sum(0)]).float().to(cuda)
+    rm = torch.randn(d, generator=g).to(cuda)
+    rv = (torch.rand(d, generator=g) + 0.5).to(cuda)
+    rm0, rv0 = rm.double().cpu(), rv.double().cpu()
+    mean, rstd = ops.K.bn_finalize(sums, shift.float().to(cuda) if shifted else None, float(n), 1e-5, 0.1,
+                                   rm if track else None, rv if track else None)
+    assert _rel(mean, x.mean(0)) <= 1e-6
+    assert _rel(rstd, 1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)) <= 1e-5
+    if track:
+        assert _rel(rm, 0.9 * rm0 + 0.1 * x.mean(0)) <= 1e-6
+        assert _rel(rv, 0.9 * rv0 + 0.1 * x.var(0, unbiased=True)) <= 1e-5
+    else:
+        assert torch.equal(rm.double().cpu(), rm0) and torch.equal(rv.double().cpu(), rv0)
+
+
 @pytest.mark.parametrize("n,m,k", [(1, 64, 32), (100, 256, 100), (4099, 128, 128), (50001, 256, 100), (20000, 64, 64)])
 @pytest.mark.parametrize("two", [False, True])
 def test_gram_bn_bwd_without_dz(cuda, n, m, k, two):
@@ -1034,9 +1059,12 @@ def test_gcn_bn_bwd_dx_chain(cuda, n, d, relu, training):
         add_gy = layer != 1
         dz, dy, acc = K.gcn_bn_bwd_dx(gy, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, w, acc,
                                       last=(layer == 2), add_gy=add_gy)
-        same = (dz == dz_ref).float().mean().item()
-        assert same >= 0.999, same
-        ulp = 2.0 ** -7 * dz_ref.float().abs() + 1e-30
+        differ = int((dz != dz_ref).sum())
+        assert differ <= max(2, int(1e-3 * dz.numel())), differ
+        # (the fused kernel evaluates the same expression with its coefficients folded — cs g' + z Z1 + Z0 — : fp32 rounding
+        # differs, so a result next to a bf16 rounding boundary may land on the other side, and a cancelling one moves by
+        # ~1e-6 of the operands' size)
+        ulp = 2.0 ** -7 * dz_ref.float().abs() + 2e-5
         assert bool(((dz.float() - dz_ref.float()).abs() <= ulp).all())
         dzd = dz.double().cpu()
         ref_dy = dzd @ w[:, :d].double().cpu()
@@ -1063,8 +1091,9 @@ def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):
     x = torch.randn(n, f).bfloat16().to(cuda)
     go = torch.randn(n, d).bfloat16().to(cuda)
     res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("SGF_GCN_FUSED", mode)
+    for mode in ("1", "0", "bwd"):
+        monkeypatch.setenv("SGF_GCN_FUSED", "1" if mode == "bwd" else mode)
+        monkeypatch.setenv("SGF_GCN_BWD_FUSED", "1" if mode == "bwd" else "0")
         torch.manual_seed(1)
         m = GraphConv(f, d, num_layers=3, dropout=0.0, use_bn=True, use_residual=True, use_weight=True, use_init=True,
                       use_act=True).to(cuda).train()
@@ -1072,13 +1101,14 @@ def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):
         (out.float() * go.float()).sum().backward()
         res[mode] = (out.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters()},
                      {k: b.detach().float().clone() for k, b in m.named_buffers()})
-    o1, g1, b1 = res["1"]
     o0, g0, b0 = res["0"]
-    assert _rel(o1, o0) <= 1e-2
-    for k in g0:
-        assert _rel(g1[k], g0[k]) <= 3e-2, (k, _rel(g1[k], g0[k]))
-    for k in b0:
-        assert _rel(b1[k], b0[k]) <= 1e-3 or "num_batches" in k, k
+    for mode in ("1", "bwd"):          # one node per layer with the separate backward kernels / with sgf_gcn_bn_bwd_dx
+        o1, g1, b1 = res[mode]
+        assert _rel(o1, o0) <= 1e-2
+        for k in g0:
+            assert _rel(g1[k], g0[k]) <= 3e-2, (mode, k, _rel(g1[k], g0[k]))
+        for k in b0:
+            assert _rel(b1[k], b0[k]) <= 1e-3 or "num_batches" in k, (mode, k)
 
 
 @pytest.mark.parametrize("n,d", [(1, 64), (33, 256), (1000, 128), (20001, 256)])

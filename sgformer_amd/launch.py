@@ -61,6 +61,20 @@ def patch_medium_gcn():
     return models
 
 
+def patch_100m_data_utils():
+    """100M/nb-sample.py:12 imports `load_fixed_splits` from 100M/data_utils.py, which does not define it — the trainer
+    cannot be imported as shipped.  Import the trainer's own data_utils (its directory is on sys.path by now) and add the
+    missing name as a stub; the papers100M path (nb-sample.py:96-97) never calls it."""
+    import importlib as _il
+    du = _il.import_module("data_utils")
+    if not hasattr(du, "load_fixed_splits"):
+        def load_fixed_splits(*args, **kwargs):
+            raise NotImplementedError("100M/data_utils.py does not define load_fixed_splits (only ogbn-papers100M's own "
+                                      "fixed split is supported by this trainer)")
+        du.load_fixed_splits = load_fixed_splits
+    return du
+
+
 def patch_subgraph():
     """Point torch_geometric.utils.subgraph at the GPU implementation (sgformer_amd.batching) before
     the trainer imports it (large/main-batch.py:8, large/eval.py:4): the per-batch induced subgraph
@@ -256,6 +270,8 @@ def main(argv=None):
     sys.path.insert(0, tdir)
     if variant == "medium":
         patch_medium_gcn()
+    if variant in ("100M", "100m"):
+        patch_100m_data_utils()
     _select_device(argv)
     if host_subgraph is None and os.path.basename(trainer) == "main-batch.py":
         patch_subgraph()

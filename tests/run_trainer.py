@@ -19,8 +19,43 @@ for p in (os.path.join(HERE, "standins"), ROOT):
         sys.path.insert(0, p)
 
 
+def _cuda_as_cpu():
+    """100M/nb-sample.py:115 hard-codes `torch.device(f"cuda:{args.device}")` (no --cpu switch).  This container has no
+    GPU: SGF_CUDA_AS_CPU=1 makes `torch.device("cuda:N")` in the TRAINER's code name the CPU, in both modes, so that the
+    unchanged file can run.  (Only the Python-level name is replaced; tensors and modules see real torch.device objects.)"""
+    import torch
+    real = torch.device
+
+    class _Device:
+        def __new__(cls, *a, **k):
+            if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+                return real("cpu")
+            return real(*a, **k)
+
+    torch.device = _Device
+
+
+def _fix_100m_import(trainer):
+    """100M/nb-sample.py:12 imports `load_fixed_splits` from 100M/data_utils.py, which does not define it: the file cannot
+    be imported as shipped.  Pre-import the trainer's own data_utils and add the missing name (a stub: the papers100M path,
+    nb-sample.py:96-97, never calls it) — in BOTH modes, so that the comparison runs the same file."""
+    tdir = os.path.dirname(trainer)
+    if os.path.basename(tdir) != "100M":
+        return
+    sys.path.insert(0, tdir)
+    import data_utils
+    if not hasattr(data_utils, "load_fixed_splits"):
+        def load_fixed_splits(*a, **k):
+            raise NotImplementedError("100M/data_utils.py has no load_fixed_splits")
+        data_utils.load_fixed_splits = load_fixed_splits
+
+
 def main():
     mode, trainer, args = sys.argv[1], os.path.abspath(sys.argv[2]), sys.argv[3:]
+    if os.environ.get("SGF_CUDA_AS_CPU") == "1":
+        _cuda_as_cpu()
+    if mode == "reference":
+        _fix_100m_import(trainer)
     if mode == "ours":
         from sgformer_amd import launch, ops
         from tests.cpu_kernels import CpuKernels

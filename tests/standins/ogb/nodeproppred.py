@@ -26,5 +26,21 @@ class NodePropPredDataset:
         return self._split
 
 
+class _PygData:
+    """What `PygNodePropPredDataset(...)[0]` gives 100M/dataset.py:81-95: edge_index / x / y tensors and num_nodes."""
+
+
 class PygNodePropPredDataset(NodePropPredDataset):
-    pass
+    def __getitem__(self, idx):
+        import torch
+        assert idx == 0
+        d = _PygData()
+        d.edge_index = torch.from_numpy(self.graph["edge_index"])
+        d.x = torch.from_numpy(self.graph["node_feat"])
+        d.y = torch.from_numpy(self.labels.astype(np.float32))      # papers100M stores float labels (NaN = unlabeled)
+        d.num_nodes = int(self.graph["num_nodes"])
+        return d
+
+    def get_idx_split(self):
+        import torch
+        return {k: torch.from_numpy(v) for k, v in self._split.items()}

@@ -59,3 +59,11 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
 
 def k_hop_subgraph(*args, **kwargs):
     raise NotImplementedError("stand-in: k_hop_subgraph is not on the sgformer path")
+
+
+def to_dense_adj(edge_index, max_num_nodes=None):
+    """[1, N, N] dense adjacency (medium/dataset.py:18 imports it for the graphormer preprocessing only)."""
+    n = _num_nodes(edge_index, max_num_nodes)
+    adj = torch.zeros((1, n, n), dtype=torch.float32, device=edge_index.device)
+    adj[0, edge_index[0], edge_index[1]] = 1.0
+    return adj

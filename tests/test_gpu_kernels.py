@@ -1106,6 +1106,10 @@ def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):
         o1, g1, b1 = res[mode]
         assert _rel(o1, o0) <= 1e-2
         for k in g0:
+            if k.endswith("W.bias") or k == "fcs.0.bias":
+                # a Linear bias in front of a BatchNorm has the exact gradient 0 (the mean is removed): both are rounding noise
+                assert float(g1[k].abs().max()) <= 1e-2 * max(1.0, float(g0["bns.1.bias"].abs().max())), k
+                continue
             assert _rel(g1[k], g0[k]) <= 3e-2, (mode, k, _rel(g1[k], g0[k]))
         for k in b0:
             assert _rel(b1[k], b0[k]) <= 1e-3 or "num_batches" in k, (mode, k)

@@ -165,7 +165,7 @@ class SpmmTimer:
 
     def __init__(self):
         self.pairs, self.bytes_alg, self.bytes_gather, self.active, self.kernels = [], [], [], False, []
-        self._orig = (ops.K.spmm, ops.K.spmm_blocked, ops.K.spmm_tile)
+        self._orig = (ops.K.spmm, getattr(ops.K, "spmm_blocked", None), getattr(ops.K, "spmm_tile", None))
 
     def _wrap(self, orig, blocked):
         timer = self
@@ -407,6 +407,25 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     return out
 
 
+DRYRUN = os.environ.get("SGF_BENCH_DRYRUN") == "1"
+
+
+def _enter_dryrun():
+    """SGF_BENCH_DRYRUN=1 (tests/test_dist.py only; never a measurement): the driver's launch line
+    `python -m torch.distributed.run ... bench.py --gpus N ...` on a GPU-less host — gloo instead of RCCL, the CPU kernel
+    table of tests/cpu_kernels.py instead of libsgf.so, torch.cuda's fences as no-ops.  What it exercises is everything
+    of this file that is not a kernel: env parsing, rendezvous, sharding of the inputs, the step sequence, the timing
+    fences and the max-over-ranks reduction, the JSON contract.  The printed line is marked `dry_run`."""
+    sys.path.insert(0, os.path.join(ROOT))
+    from tests.cpu_kernels import CpuKernels
+    ops.set_kernels(CpuKernels())
+    for name in ("synchronize", "set_device", "empty_cache", "reset_peak_memory_stats"):
+        setattr(torch.cuda, name, lambda *a, **k: None)
+    torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    SpmmTimer.install = lambda self: None
+    SpmmTimer.uninstall = lambda self: None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -416,18 +435,27 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (see docstring)")
         args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback by design)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if DRYRUN:
+        _enter_dryrun()
+        if not args.nodes:
+            raise SystemExit("SGF_BENCH_DRYRUN=1 needs --nodes (a few thousand)")
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback by design)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
         cpu = cpu_baseline(args.workload, args.cpu_sample_nodes, args.seed)
 
     if _sharded(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if DRYRUN:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     r = run_workload(args, args.graph, rank, world, dev, args.steps, args.warmup, with_aten=True)
     structured = None
@@ -476,7 +504,7 @@ def main():
                        "graph_view": r["view"],
                        "prepare_graph_s": None if r["prepare_s"] is None else round(r["prepare_s"], 3),
                        "exchanged": r["exchanged"],
-                       "debug_override": bool(args.nodes)},
+                       "debug_override": bool(args.nodes), **({"dry_run": True} if DRYRUN else {})},
             "loss": r["loss"],
             "peak_mem_GB": r["peak_mem"],
             "roofline": r["roof"],

@@ -270,22 +270,40 @@ class RowExchange:
             raise RuntimeError("row exchange: a peer asked for a row this rank does not own")
         self.send_idx = asked - ctx.r0                           # local rows to pack, grouped by destination
         self.n_want, self.n_own, self.ctx = int(want.numel()), ctx.n_local, ctx
+        # when every owned row is wanted exactly once (`want` = a permutation of all nodes: Repartition), the way back is
+        # a GATHER by the inverse of send_idx, not a scatter into zeros
+        self.send_inv = None
+        if int(self.send_idx.numel()) == self.n_own and self.n_own > 0:
+            inv = torch.full((self.n_own,), -1, dtype=torch.int64, device=dev)
+            inv[self.send_idx] = torch.arange(self.n_own, device=dev)
+            if int(inv.min()) >= 0:
+                self.send_inv = inv
+
+    @staticmethod
+    def _rows(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """t[idx] — on sgf_gather_rows for [n, d] float matrices (16 bytes per lane; ATen's advanced indexing launches
+        an index kernel with one thread per element and materialises the result through a second copy)."""
+        if t.dim() == 2 and t.dtype in (torch.float32, torch.bfloat16) and t.shape[0] > 0 and idx.numel() > 0:
+            return ops.gather_rows(t, idx)
+        return t[idx].contiguous()
 
     def forward(self, t: torch.Tensor) -> torch.Tensor:
         """rows of the OLD partition (this rank's [n_local, ...]) -> the rows this rank wants, in `want` order."""
-        send = t[self.send_idx].contiguous()
+        send = self._rows(t, self.send_idx)
         recv = t.new_empty((self.n_want,) + tuple(t.shape[1:]))
         dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts, group=self.ctx.group)
         self.ctx.bytes_repartition += send.numel() * send.element_size()
-        return recv[self.place]
+        return self._rows(recv, self.place)
 
     def backward(self, t: torch.Tensor) -> torch.Tensor:
         """the reverse move: rows in `want` order -> back to their owners' local positions (every owned row is wanted
         by exactly one rank when `want` is a permutation of all nodes)."""
-        send = t[self.order].contiguous()
+        send = self._rows(t, self.order)
         recv = t.new_empty((int(self.send_idx.numel()),) + tuple(t.shape[1:]))
         dist.all_to_all_single(recv, send, self.send_counts, self.recv_counts, group=self.ctx.group)
         self.ctx.bytes_repartition += send.numel() * send.element_size()
+        if self.send_inv is not None:
+            return self._rows(recv, self.send_inv)
         out = t.new_zeros((self.n_own,) + tuple(t.shape[1:]))
         out[self.send_idx] = recv
         return out
@@ -305,23 +323,47 @@ class _Exchange(torch.autograd.Function):
 
 class Repartition:
     """A locality-restoring node order ACROSS ranks (the halo exchange only engaged when the caller's
-    ids already carried the locality).  Every rank holds the global edge list (replicated mode), so every rank
-    computes the same sgf_reorder permutation on it (deterministic), relabels the edges and takes the contiguous
+    ids already carried the locality).  Every rank holds the global edge list (replicated mode); rank 0 computes the
+    sgf_reorder permutation on it and broadcasts it, every rank relabels the edges and takes the contiguous
     range [r0, r1) of the NEW numbering; features enter and logits leave through one all-to-all each
     (`to_new` / `to_old`, differentiable), so the caller keeps its own numbering.  Adopted only if the halo of the
     re-partitioned graph is small enough for the halo path (HaloPlan.enabled) — a uniform random graph keeps its
     order and the all-gather fallback."""
 
     def __init__(self, edge_index: torch.Tensor, ctx: "ShardContext"):
-        n = ctx.n_global
-        perm, inv, _ = ops.K.reorder(edge_index, n, *ops.REORDER_ITERS)
-        ei2 = inv.long()[edge_index]
-        ei2._sgf_trusted = True
-        graph = ShardedGraph(ei2, ctx)
-        self.adopted = graph.halo(ctx, False).enabled
-        self.stats = {"halo_fraction": graph.halo(ctx, False).max_fraction, "adopted": self.adopted}
+        n, dev = ctx.n_global, edge_index.device
+        # ONE rank runs sgf_reorder (label propagation over the whole edge list: O(E) sorts); the others receive the
+        # order and the community labels — 8 N bytes on the links instead of P - 1 redundant runs
+        po = torch.empty((2, n), dtype=torch.int32, device=dev)
+        if ctx.rank == 0:
+            perm, _, comm = ops.K.reorder(edge_index, n, *ops.REORDER_ITERS)
+            po[0], po[1] = perm.to(dev), comm.to(dev)[perm.long()]          # community of NEW row p
+        src = 0 if ctx.group is None else dist.get_global_rank(ctx.group, 0)
+        dist.broadcast(po, src=src, group=ctx.group)
+        perm, comm_new = po[0].contiguous(), po[1].contiguous()
+        inv = torch.empty(n, dtype=torch.int32, device=dev)
+        inv[perm.long()] = torch.arange(n, dtype=torch.int32, device=dev)
+        # would the re-partitioned graph take the halo path?  Decide from the halo FRACTION alone — the distinct remote
+        # sources of the edges whose (new) target this rank owns — before any CSR is built: a uniform random graph keeps
+        # its order (and the all-gather), and nothing is constructed just to be thrown away
+        new_src, new_dst = inv[edge_index[0]].long(), inv[edge_index[1]].long()
+        mine = (new_dst >= ctx.r0) & (new_dst < ctx.r1)
+        cols = torch.unique(new_src[mine])
+        n_halo = int(((cols < ctx.r0) | (cols >= ctx.r1)).sum())
+        frac = torch.tensor([n_halo / max(ctx.n_global - ctx.n_local, 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=ctx.group)
+        self.adopted = float(frac) <= ctx.halo_max
+        self.stats = {"halo_fraction": float(frac), "adopted": self.adopted}
         if not self.adopted:
             return
+        ei2 = torch.stack([new_src, new_dst])
+        del new_src, new_dst, mine, cols
+        ei2._sgf_trusted = True
+        graph = ShardedGraph(ei2, ctx)
+        # the rows of this rank follow the communities: its own-column block has the locality the re-ordered single-GPU
+        # graph has — stream / tile kernels instead of the plain row kernel (ops._own_block_spmm)
+        graph.locality = True
+        graph.comm_local = comm_new[ctx.r0:ctx.r1].contiguous()
         self.edge_index, self.graph = ei2, graph
         ei2._sgf_sharded_graph = graph
         self.perm, self.inv = perm, inv

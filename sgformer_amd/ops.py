@@ -1234,14 +1234,16 @@ def _sharded_spmm(graph, x, shard, transposed: bool):
     n_local = graph.n_local
     plan = graph.halo(shard, transposed) if hasattr(graph, "halo") else None
     if plan is not None and plan.enabled:
-        if getattr(shard, "overlap", False) and plan.n_halo > 0:
+        if plan.n_halo == 0:                      # nothing to exchange (one rank, or a block without cut edges)
+            return _own_block_spmm(graph, plan, (rowptr, plan.colind, val, long_segments), x, n_local, transposed)
+        if getattr(shard, "overlap", False):
             shard.overlapped_exchanges = getattr(shard, "overlapped_exchanges", 0) + 1
             # the entries whose source this rank owns are multiplied while the halo rows are on the links; the halo
             # entries follow when they have arrived (their sum is rounded to the storage dtype before it is added: bf16
             # rows with cut edges carry two roundings more than the single-GPU product)
-            (rp_o, ci_o, va_o, seg_o), (rp_h, ci_h, va_h, seg_h) = plan.split(rowptr, val, n_local)
+            own, (rp_h, ci_h, va_h, seg_h) = plan.split(rowptr, val, n_local)
             recv, work, keep = shard.halo_exchange_start(x, plan)
-            y = K.spmm(rp_o, ci_o, va_o, x, n_local, long_segments=seg_o)
+            y = _own_block_spmm(graph, plan, own, x, n_local, transposed)
             work.wait()
             y.add_(K.spmm(rp_h, ci_h, va_h, recv, n_local, long_segments=seg_h))
             del keep
@@ -1258,6 +1260,36 @@ def _sharded_spmm(graph, x, shard, transposed: bool):
         work.wait()                                   # the compute stream waits for THIS chunk only
         K.spmm(rowptr, colind, val, buf, n_local, out=y[:, c * w:(c + 1) * w], long_segments=long_segments)
     return y
+
+
+def _own_block_spmm(graph, plan, own, x, n_local: int, transposed: bool):
+    """The square block of a rank's rows x the rank's OWN columns (the part of a node-sharded product that needs no
+    exchange).  When the partition follows sgf_reorder's order (dist.Repartition sets graph.locality / comm_local) this
+    block has the structure the re-ordered single-GPU graph has, and takes the same kernels: the matrix-core tile kernel
+    (sgf_spmm_tile, bf16 rows of 128 / 256 features; plan built once per block and direction) or the stream kernel; the
+    plain row kernel otherwise."""
+    rp, ci, va, segs = own
+    if getattr(graph, "locality", False):
+        import os
+        if (hasattr(K, "tile_supported") and K.tile_supported(x.shape[1], x.dtype) and getattr(graph, "comm_local", None) is not None
+                and os.environ.get("SGF_SPMM_TILED", "1") == "1" and n_local >= 256
+                and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32 - 2048):
+            plans = plan.__dict__.setdefault("_own_tile_plans", {})
+            tp = plans.get("plan")
+            if tp is None:
+                try:
+                    _, _, max_rows = _tile_params()
+                    blk_row = K.tile_blocks(graph.comm_local, n_local, max_rows, x.device)
+                    tp = TilePlan(rp, ci, va, n_local, blk_row)
+                    if tp.tile_fraction < REORDER_MIN_LDS_FRACTION:
+                        tp = False                              # too little to put on the matrix cores: stream kernel
+                except (ValueError, _lib.SgfError):
+                    tp = False
+                plans["plan"] = tp
+            if tp:
+                return K.spmm_tile(tp, x, n_local)
+        return K.spmm(rp, ci, va, x, n_local, long_segments=segs, stream_hint=True)
+    return K.spmm(rp, ci, va, x, n_local, long_segments=segs)
 
 
 class _SpMM(torch.autograd.Function):

@@ -578,3 +578,41 @@ def test_minibatch_per_rank_with_global_attention_set(world):
         e = ret[rank]
         assert e["logits"] < 5e-5 and e["loss"] < 1e-5 and e["grad"] < 2e-3, e
         assert e["gathered"] == 0 and e["halo"] == 0 and e["reduced"] > 0, e      # no operand crosses ranks
+
+
+@pytest.mark.parametrize("graph", ["uniform", "community"])
+def test_bench_under_the_drivers_launch_line(graph, tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 --steps K --warmup W` — EXACTLY what the driver runs for the scaling bench — on this GPU-less host:
+    SGF_BENCH_DRYRUN=1 swaps RCCL for gloo and libsgf.so for the CPU kernel table and leaves the rest of bench.py as it
+    is: env parsing, rendezvous, input sharding, step sequence, the fenced timing + max over ranks, one JSON line from
+    rank 0 with the contract's fields.  `community`: the graph whose locality sgf_reorder recovers — the partition then
+    follows it across ranks (dist.Repartition) and the SpMM runs the halo exchange instead of the all-gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "SGF_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "2"}
+    if graph == "community":
+        env["SGF_HALO_MAX"] = "1.0"          # 4000 nodes are ONE super-community: take the halo path whatever its size
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nodes", "4000", "--graph", graph]
+    p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 only
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["dry_run"] is True
+    assert out["scaling"] == "strong" and out["config"]["parallelism"] == "node-shard x2"
+    assert abs(out["value"] - 4000 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    ex = out["config"]["exchanged"]
+    assert ex["all_reduce_bytes_per_step"] > 0
+    if graph == "community":
+        assert ex["halo_bytes_sent_per_step"] > 0 and ex["all_gather_bytes_per_step"] == 0 and ex["repartition_bytes_per_step"] > 0
+    else:
+        assert ex["all_gather_bytes_per_step"] > 0
+    assert out["loss"] == out["loss"] and 0.0 < out["loss"] < 20.0

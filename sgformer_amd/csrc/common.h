@@ -164,4 +164,8 @@ int linear_f32(const float* a, int64_t lda, int64_t n, int dk, int dj, const flo
                const float* bias, const float* addend, int64_t ldadd, const float* shift, float* out, int64_t ldo,
                float* spart, hipStream_t st);
 
+int linear_f32_dual(const void* a, int64_t lda, const void* a2, int64_t lda2, float ca, float cb, int64_t n, int dk, int dj,
+                    const float* w, int64_t ldw, int trans_w, const float* bias, void* out, int64_t ldo, void* out2,
+                    int64_t ldo2, float co, float co2, int in16, int out16, hipStream_t st);
+
 }  // namespace sgf

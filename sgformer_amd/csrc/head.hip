@@ -252,8 +252,17 @@ inline int head_grid(int64_t n) {
 
 int check_head(const char* fn, int64_t n, int d, int c, int dtype) {
   SGF_REQUIRE(n >= 0 && d > 0 && c > 0, SGF_E_INVALID, "%s: bad size", fn);
-  SGF_REQUIRE(dtype == SGF_BF16, SGF_E_UNSUPPORTED,
-              "%s: bf16 activations only (fp32 runs use sgf_axpby + the library GEMM)", fn);
+  if (dtype == SGF_F32) {
+    SGF_REQUIRE(linear_f32_supported(d, c), SGF_E_UNSUPPORTED,
+                "%s: fp32 storage needs d and classes multiples of 4 up to 256 (d=%d, classes=%d; pad the class rows of W)", fn, d, c);
+    return SGF_OK;
+  }
+  SGF_REQUIRE(dtype == SGF_BF16, SGF_E_UNSUPPORTED, "%s: unknown dtype %d", fn, dtype);
+  if (c > kMaxClasses) {                               // bf16 rows, many classes: the exact-fp32 kernel with bf16 on the wire
+    SGF_REQUIRE(linear_f32_supported(d, c), SGF_E_UNSUPPORTED,
+                "%s: more than %d classes need d and classes multiples of 4 up to 256 (d=%d, classes=%d)", fn, kMaxClasses, d, c);
+    return SGF_OK;
+  }
   SGF_REQUIRE(d % 32 == 0 && d <= 256 && c <= kMaxClasses, SGF_E_UNSUPPORTED,
               "%s: needs d %% 32 == 0, d <= 256, classes <= %d (d=%d, classes=%d)", fn, kMaxClasses, d, c);
   return SGF_OK;
@@ -265,7 +274,10 @@ int check_head(const char* fn, int64_t n, int d, int c, int dtype) {
 using namespace sgf;
 
 extern "C" int32_t sgf_combine_fc_supported(int32_t d, int32_t classes, int32_t dtype) {
-  return dtype == SGF_BF16 && d > 0 && d % 32 == 0 && d <= 256 && classes > 0 && classes <= kMaxClasses;
+  if (dtype == SGF_F32) return linear_f32_supported(d, classes) ? 1 : 0;   // exact-fp32 matrix cores (csrc/linear_f32.hip)
+  if (dtype != SGF_BF16 || d <= 0 || classes <= 0) return 0;
+  if (classes > kMaxClasses) return linear_f32_supported(d, classes) ? 1 : 0;   // the same kernel, bf16 rows in / out
+  return d % 32 == 0 && d <= 256 ? 1 : 0;
 }
 
 extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
@@ -274,6 +286,18 @@ extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const vo
   int rc = check_head("sgf_combine_fc_fwd", n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
+  if (dtype == SGF_F32) {
+    SGF_REQUIRE(x1 && x2 && w && logits && ld1 >= d && ld2 >= d && ldl >= classes, SGF_E_INVALID,
+                "sgf_combine_fc_fwd: bad pointer / ld");
+    return linear_f32_dual(x1, ld1, x2, ld2, a, b, n, d, classes, w, d, 1, bias, logits, ldl, nullptr, 0, 1.f, 1.f, 0, 0,
+                           static_cast<hipStream_t>(stream));
+  }
+  if (classes > kMaxClasses) {
+    SGF_REQUIRE(x1 && x2 && w && logits && ld1 >= d && ld2 >= d && ldl >= classes, SGF_E_INVALID,
+                "sgf_combine_fc_fwd: bad pointer / ld");
+    return linear_f32_dual(x1, ld1, x2, ld2, a, b, n, d, classes, w, d, 1, bias, logits, ldl, nullptr, 0, 1.f, 1.f, 1, 0,
+                           static_cast<hipStream_t>(stream));
+  }
   SGF_REQUIRE(x1 && x2 && w && bias && logits && ld1 % 8 == 0 && ld2 % 8 == 0 && ld1 >= d && ld2 >= d && ldl >= classes,
               SGF_E_INVALID, "sgf_combine_fc_fwd: bad pointer / ld");
   SGF_REQUIRE(reinterpret_cast<uintptr_t>(x1) % 16 == 0 && reinterpret_cast<uintptr_t>(x2) % 16 == 0 &&
@@ -298,6 +322,18 @@ extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const floa
   int rc = check_head("sgf_combine_fc_bwd", n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
+  if (dtype == SGF_F32) {
+    SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
+                "sgf_combine_fc_bwd: bad pointer / ld");
+    return linear_f32_dual(dlogits, lddl, nullptr, 0, 1.f, 0.f, n, classes, d, w, d, 0, nullptr, dx1, ld1, dx2, ld2, a, b, 0, 0,
+                           static_cast<hipStream_t>(stream));
+  }
+  if (classes > kMaxClasses) {
+    SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
+                "sgf_combine_fc_bwd: bad pointer / ld");
+    return linear_f32_dual(dlogits, lddl, nullptr, 0, 1.f, 0.f, n, classes, d, w, d, 0, nullptr, dx1, ld1, dx2, ld2, a, b, 0, 1,
+                           static_cast<hipStream_t>(stream));
+  }
   SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d && ld1 % 8 == 0 && ld2 % 8 == 0 &&
                   reinterpret_cast<uintptr_t>(dx1) % 16 == 0 && reinterpret_cast<uintptr_t>(dx2) % 16 == 0,
               SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 16-byte aligned, ld %% 8 == 0)");

@@ -34,11 +34,21 @@ struct LinArgs {
   int64_t n;
   int32_t dk, dj;
   float* spart;            // [gridDim.x][2 * dj] per-block column sums / sums of squares, or null
+  // DUAL form (T7 for fp32 storage, large/ours.py:269-275): the A operand is ca * a + cb * a2, formed while the row tile is
+  // staged (a2 != null), and / or the result leaves twice, co * v -> out and co2 * v -> out2 (out2 != null)
+  const float* a2;
+  int64_t lda2;
+  float ca, cb;
+  float* out2;
+  int64_t ldo2;
+  float co, co2;
 };
 
 __device__ __forceinline__ float4 zero4f() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int DP, bool STATS>
+// IN16 / OUT16 (DUAL only): the A operand(s) / the result(s) are bf16 in memory — the fused head of bf16 runs whose class count
+// exceeds the bf16 head kernel's 64 (C = 172 at the papers100M recipe): same kernel, fp32 arithmetic, bf16 only on the wire.
+template <int DP, bool STATS, bool DUAL = false, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(kLinThreads) void k_linear_f32(LinArgs p) {
   constexpr int NS = DP / 32;         // 32-column strips
   constexpr int RS = 8 / NS;          // row sub-blocks
@@ -80,14 +90,24 @@ __global__ __launch_bounds__(kLinThreads) void k_linear_f32(LinArgs p) {
   // (bias / shift chunks are re-read from the L1-resident vectors in the epilogue: the 256-wide kernel sits exactly at
   // the 128-register budget of 4 waves per SIMD)
   float4 s1 = zero4f(), s2 = zero4f();
-  const float* pa = p.a + scol;
+  const float* pa = p.a + (IN16 ? scol / 2 : scol);     // (bf16 operands: the pointer is typed float, offsets in bf16 pairs)
+  const float* pa2 = (DUAL && p.a2) ? p.a2 + (IN16 ? scol / 2 : scol) : nullptr;
   float4 ra[2];
   const int64_t ntiles = (p.n + RT - 1) / RT;
+  auto load_a = [&](const float* base, int64_t row, int64_t ld) -> float4 {
+    if (IN16) return load4<uint16_t>(reinterpret_cast<const uint16_t*>(base) + row * ld);
+    return *reinterpret_cast<const float4*>(base + row * ld);
+  };
   auto issue = [&](int64_t tile) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t row = tile * RT + srow0 + i * RPP;
-      ra[i] = (in_ok && row < p.n) ? *reinterpret_cast<const float4*>(pa + row * p.lda) : zero4f();
+      ra[i] = (in_ok && row < p.n) ? load_a(pa, row, p.lda) : zero4f();
+      if (DUAL && pa2 != nullptr) {                     // the combination a * x1 + b * x2, in fp32, never written
+        const float4 r2 = (in_ok && row < p.n) ? load_a(pa2, row, p.lda2) : zero4f();
+        ra[i] = make_float4(p.ca * ra[i].x + p.cb * r2.x, p.ca * ra[i].y + p.cb * r2.y, p.ca * ra[i].z + p.cb * r2.z,
+                            p.ca * ra[i].w + p.cb * r2.w);
+      }
     }
   };
   auto commit = [&](int buf) {
@@ -137,7 +157,19 @@ __global__ __launch_bounds__(kLinThreads) void k_linear_f32(LinArgs p) {
           const float4 o = *reinterpret_cast<const float4*>(p.addend + row * p.ldadd + scol);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        *reinterpret_cast<float4*>(p.out + row * p.ldo + scol) = v;
+        if (DUAL && p.out2 != nullptr) {                // dx1 = a (g W), dx2 = b (g W): one product, two scaled copies
+          const float4 v1 = make_float4(p.co * v.x, p.co * v.y, p.co * v.z, p.co * v.w);
+          const float4 v2 = make_float4(p.co2 * v.x, p.co2 * v.y, p.co2 * v.z, p.co2 * v.w);
+          if (OUT16) {
+            store4<uint16_t>(reinterpret_cast<uint16_t*>(p.out) + row * p.ldo + scol, v1);
+            store4<uint16_t>(reinterpret_cast<uint16_t*>(p.out2) + row * p.ldo2 + scol, v2);
+          } else {
+            *reinterpret_cast<float4*>(p.out + row * p.ldo + scol) = v1;
+            *reinterpret_cast<float4*>(p.out2 + row * p.ldo2 + scol) = v2;
+          }
+        } else {
+          *reinterpret_cast<float4*>(p.out + row * p.ldo + scol) = v;
+        }
         if (STATS) {
           const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + scol) : zero4f();
           const float4 u = make_float4(v.x - sh.x, v.y - sh.y, v.z - sh.z, v.w - sh.w);
@@ -189,7 +221,8 @@ int linear_f32(const float* a, int64_t lda, int64_t n, int dk, int dj, const flo
                   reinterpret_cast<uintptr_t>(out) % 16 == 0 && (!addend || reinterpret_cast<uintptr_t>(addend) % 16 == 0) &&
                   (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0) && (!shift || reinterpret_cast<uintptr_t>(shift) % 16 == 0),
               SGF_E_INVALID, "linear_f32: rows must be 16-byte aligned");
-  LinArgs p{a, lda, w, ldw, trans_w, bias, addend, ldadd, shift, out, ldo, n, dk, dj, spart};
+  LinArgs p{a, lda, w, ldw, trans_w, bias, addend, ldadd, shift, out, ldo, n, dk, dj, spart, nullptr, 0, 1.f, 0.f, nullptr, 0,
+            1.f, 1.f};
   const int blocks = linear_f32_blocks(n);
   const int dmax = dk > dj ? dk : dj;
   const int DP = dmax <= 64 ? 64 : (dmax <= 128 ? 128 : 256);
@@ -202,6 +235,37 @@ int linear_f32(const float* a, int64_t lda, int64_t n, int dk, int dj, const flo
   else if (DP == 128) SGF_LIN(128);
   else SGF_LIN(256);
 #undef SGF_LIN
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+// T7 for fp32 storage: out = (ca a + cb a2) B (+ bias)   [a2 != null],   or   out = co (a B), out2 = co2 (a B)   [out2 != null]
+// in16: a / a2 point at bf16 rows (lda, lda2 in bf16 elements); out16: out / out2 receive bf16 (ldo, ldo2 in bf16 elements)
+int linear_f32_dual(const void* a, int64_t lda, const void* a2, int64_t lda2, float ca, float cb, int64_t n, int dk, int dj,
+                    const float* w, int64_t ldw, int trans_w, const float* bias, void* out, int64_t ldo, void* out2,
+                    int64_t ldo2, float co, float co2, int in16, int out16, hipStream_t st) {
+  SGF_REQUIRE(linear_f32_supported(dk, dj), SGF_E_UNSUPPORTED, "linear_f32: widths %d -> %d (multiples of 4, <= 256)", dk, dj);
+  const uintptr_t ain = in16 ? 8 : 16, aout = out16 ? 8 : 16;
+  SGF_REQUIRE(lda % 4 == 0 && ldo % 4 == 0 && (!a2 || lda2 % 4 == 0) && (!out2 || ldo2 % 4 == 0) &&
+                  reinterpret_cast<uintptr_t>(a) % ain == 0 && reinterpret_cast<uintptr_t>(out) % aout == 0 &&
+                  (!a2 || reinterpret_cast<uintptr_t>(a2) % ain == 0) && (!out2 || reinterpret_cast<uintptr_t>(out2) % aout == 0) &&
+                  (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0),
+              SGF_E_INVALID, "linear_f32: rows must be 16-byte aligned (8-byte for bf16 rows)");
+  SGF_REQUIRE(!(in16 && out16) && (!out16 || out2), SGF_E_UNSUPPORTED, "linear_f32_dual: unsupported storage combination");
+  LinArgs p{static_cast<const float*>(a), lda, w, ldw, trans_w, bias, nullptr, 0, nullptr, static_cast<float*>(out), ldo, n, dk,
+            dj, nullptr, static_cast<const float*>(a2), lda2, ca, cb, static_cast<float*>(out2), ldo2, co, co2};
+  const int blocks = linear_f32_blocks(n);
+  const int dmax = dk > dj ? dk : dj;
+#define SGF_LIN_DUAL(DP_)                                                                                                  \
+  do {                                                                                                                     \
+    if (in16) hipLaunchKernelGGL((k_linear_f32<DP_, false, true, true, false>), dim3(blocks), dim3(kLinThreads), 0, st, p);  \
+    else if (out16) hipLaunchKernelGGL((k_linear_f32<DP_, false, true, false, true>), dim3(blocks), dim3(kLinThreads), 0, st, p); \
+    else hipLaunchKernelGGL((k_linear_f32<DP_, false, true>), dim3(blocks), dim3(kLinThreads), 0, st, p);                  \
+  } while (0)
+  if (dmax <= 64) SGF_LIN_DUAL(64);
+  else if (dmax <= 128) SGF_LIN_DUAL(128);
+  else SGF_LIN_DUAL(256);
+#undef SGF_LIN_DUAL
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -674,6 +674,12 @@ class HipKernels:
     # ---- T7 fused: logits = (a x1 + b x2) W^T + bias ----
     @staticmethod
     def combine_fc_supported(d: int, classes: int, dtype) -> bool:
+        """bf16: d % 32 == 0, d <= 256, classes <= 64 (csrc/head.hip); fp32: d % 4 == 0, d <= 256 and the class count
+        PADDED to a multiple of 4 (ops.combine_fc pads W / bias with zero rows) up to 256 (csrc/linear_f32.hip)."""
+        if dtype == _F32:
+            return bool(_lib.load().sgf_combine_fc_supported(d, (classes + 3) // 4 * 4, _lib.SGF_F32))
+        if dtype == _BF16 and classes > 64:      # the same exact-fp32 kernel with bf16 rows on the wire (C = 172: papers100M)
+            return bool(_lib.load().sgf_combine_fc_supported(d, (classes + 3) // 4 * 4, _lib.SGF_BF16))
         return dtype == _BF16 and bool(_lib.load().sgf_combine_fc_supported(d, classes, _lib.SGF_BF16))
 
     @staticmethod
@@ -1818,22 +1824,30 @@ class _CombineFC(torch.autograd.Function):
         x1, x2 = _rows16(x1), _rows16(x2)        # sgf_combine_fc_* read 16-byte matrix-core fragments
         w32 = w.detach().float().contiguous()
         b32 = bias.detach().float().contiguous()
+        c = w32.shape[0]
+        if (x1.dtype == _F32 or c > 64) and c % 4 != 0:   # the exact-fp32 kernel takes class counts % 4: zero rows, sliced off below
+            w32 = torch.nn.functional.pad(w32, (0, 0, 0, 4 - c % 4))
+            b32 = torch.nn.functional.pad(b32, (0, 4 - c % 4))
         ctx.save_for_backward(x1, x2, w32)
-        ctx.meta = (float(a), float(b), w.dtype, bias.dtype)
-        return K.combine_fc_fwd(x1, a, x2, b, w32, b32)
+        ctx.meta = (float(a), float(b), w.dtype, bias.dtype, c)
+        out = K.combine_fc_fwd(x1, a, x2, b, w32, b32)
+        return out if out.shape[1] == c else out[:, :c]
 
     @staticmethod
     def backward(ctx, g):
         x1, x2, w32 = ctx.saved_tensors
-        a, b, wdtype, bdtype = ctx.meta
-        g = g.float().contiguous()
+        a, b, wdtype, bdtype, c_true = ctx.meta
+        g = g.float()
+        if w32.shape[0] != g.shape[1]:           # fp32 storage: the padded class columns carry a zero gradient
+            g = torch.nn.functional.pad(g, (0, w32.shape[0] - g.shape[1]))
+        g = g.contiguous()
         dx1, dx2 = K.combine_fc_bwd(g, w32, a, b, x1.dtype)
         # dW = a g^T x1 + b g^T x2, db = colsum(g): node reductions on sgf_gram (g in the activation dtype, its
         # width padded to a multiple of 4 — the same rounding the unfused path applies to the logits gradient)
-        c = g.shape[1]
+        c = c_true
         gp = g.to(x1.dtype)
-        if c % 4 != 0:
-            gp = torch.nn.functional.pad(gp, (0, 4 - c % 4))
+        if gp.shape[1] % 4 != 0:
+            gp = torch.nn.functional.pad(gp, (0, 4 - gp.shape[1] % 4))
         gp = _rows(gp)
         dw1, db = K.gram(gp, x1, want_colsum=True)
         dw2, _ = K.gram(gp, x2, want_colsum=False)
@@ -2277,6 +2291,21 @@ def linear_bn_stats(xs, w, b, shard=None):
 
 def linear_cat(xs, w, b):
     """[x_1 | x_2 | ...] W^T + b without the concatenation (GraphConvLayer with use_init)."""
+    return _Linear.apply(w, b, None, *xs)
+
+
+def out_linear_cat(xs, w, b):
+    """The output head of aggregate='cat' (large/ours.py:271-275: fc(cat(x1, x2))) WITHOUT the [N, 2 d] concatenation:
+    W = [W_1 | W_2] applied operand by operand (fp32 storage: two passes on the exact-fp32 matrix cores, the first product
+    parked as an [N, C] fp32 partial — small next to the [N, d] operands; bf16: GEMM + GEMM(beta = 1)).  Class counts that
+    are not multiples of 4 are padded with zero rows for the fp32 kernel, as in out_linear."""
+    m = w.shape[0]
+    if (xs[0].dtype == _F32 and xs[0].is_cuda and m % 4 != 0
+            and all(K.gcn_epilogue_supported(x.shape[1], (m + 3) // 4 * 4, _F32) for x in xs)):
+        pad = (m + 3) // 4 * 4 - m
+        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
+        return _Linear.apply(wp, bp, None, *xs)[:, :m]
     return _Linear.apply(w, b, None, *xs)
 
 

@@ -632,15 +632,16 @@ class SGFormer(nn.Module):
             gw = float(self.graph_weight)
             out = ops.combine_fc(x2, x1, self.fc.weight, self.fc.bias, gw, 1.0 - gw).to(out_dtype)
         else:
-            if self.use_graph:
-                if self.aggregate == 'add':
+            if self.use_graph and self.aggregate != 'add':
+                # 'cat': fc([x1 | x2]) operand by operand — the [N, 2 d] concatenation is never written
+                out = ops.out_linear_cat((x1, x2), self.fc.weight, self.fc.bias).to(out_dtype)
+            else:
+                if self.use_graph:
                     gw = float(self.graph_weight)
                     x = ops.axpby(x2, x1, gw, 1.0 - gw)
                 else:
-                    x = torch.cat((x1, x2), dim=1)
-            else:
-                x = x1
-            out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
+                    x = x1
+                out = ops.out_linear(x, self.fc.weight, self.fc.bias).to(out_dtype)
         if view is not None and view.perm is not None:
             out = ops.permute_rows(out, view.inv, view.perm)       # back to the caller's node order
         if repart is not None:

@@ -665,6 +665,64 @@ def test_colsum_any_width(cuda, d):
     assert float(ops.K.colsum(torch.zeros(0, d, device=cuda)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,d,c", [(1000, 256, 47), (777, 64, 7), (3001, 128, 40), (4097, 256, 172), (500, 256, 2), (1, 64, 5)])
+def test_combine_fc_fused_fp32(cuda, n, d, c):
+    """T7 with fp32 storage (BASELINE.json configs 2 and 4), large/ours.py:269-270,275: logits = fc(gw x2 + (1 - gw) x1) as
+    ONE kernel on the exact-fp32 matrix cores (csrc/linear_f32.hip: the combination is formed while the row tile is staged,
+    never written; class counts that are not multiples of 4 run with zero-padded rows of W), and its backward as one kernel
+    that stores both scaled copies of dlogits W.  Against fp64: 2e-6 relative (summation order only)."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d + c)
+    x1, x2 = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    w = torch.randn(c, d, generator=g) / d ** 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    go = torch.randn(n, c, generator=g)
+    gw = 0.8
+    assert ops.combine_fc_supported(x1.to(cuda), c)
+    x1g, x2g = x1.to(cuda).requires_grad_(True), x2.to(cuda).requires_grad_(True)
+    wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    out = ops.combine_fc(x2g, x1g, wg, bg, gw, 1.0 - gw)
+    assert out.dtype == torch.float32 and out.shape == (n, c)
+    (out * go.to(cuda)).sum().backward()
+    xc = gw * x2.double() + (1.0 - gw) * x1.double()
+    ref = xc @ w.double().t() + b.double()
+    assert _rel(out, ref) <= 2e-6
+    dx = go.double() @ w.double()
+    assert _rel(x2g.grad, gw * dx) <= 2e-6 and _rel(x1g.grad, (1.0 - gw) * dx) <= 2e-6
+    assert _rel(wg.grad, go.double().t() @ xc) <= 1e-5
+    assert _rel(bg.grad, go.double().sum(0)) <= 1e-5 or n < 10
+
+
+@pytest.mark.parametrize("n,d,c", [(3000, 128, 172), (1025, 256, 172), (500, 256, 65), (2000, 64, 256)])
+def test_combine_fc_fused_bf16_many_classes(cuda, n, d, c):
+    """T7 for bf16 activations and MORE than 64 classes (C = 172: the papers100M recipe, 100M/run.sh:3-7 — BASELINE.json
+    config 5): the same single kernel as the fp32 head with bf16 rows on the wire — combination and product in exact fp32
+    (no rounding of the combined activations at all), fp32 logits; backward stores both scaled copies of dlogits W as bf16.
+    Against fp64 of the same bf16 inputs: logits 2e-6, dx one bf16 rounding, dW / db 2e-5."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d + c)
+    x1, x2 = torch.randn(n, d, generator=g).bfloat16(), torch.randn(n, d, generator=g).bfloat16()
+    w = torch.randn(c, d, generator=g) / d ** 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    go = torch.randn(n, c, generator=g)
+    gw = 0.8
+    assert ops.combine_fc_supported(x1.to(cuda), c)
+    x1g, x2g = x1.to(cuda).requires_grad_(True), x2.to(cuda).requires_grad_(True)
+    wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    out = ops.combine_fc(x2g, x1g, wg, bg, gw, 1.0 - gw)
+    assert out.dtype == torch.float32 and out.shape == (n, c)
+    (out * go.to(cuda)).sum().backward()
+    xc = gw * x2.double() + (1.0 - gw) * x1.double()
+    ref = xc @ w.double().t() + b.double()
+    assert _rel(out, ref) <= 2e-6
+    dx = go.double() @ w.double()
+    assert x1g.grad.dtype == torch.bfloat16
+    assert _rel(x2g.grad.float(), gw * dx) <= 4e-3 and _rel(x1g.grad.float(), (1.0 - gw) * dx) <= 4e-3
+    go_r = go.bfloat16().double()                      # the weight gradient sees dlogits in the activation dtype
+    assert _rel(wg.grad, go_r.t() @ xc) <= 2e-5
+    assert _rel(bg.grad, go_r.sum(0)) <= 2e-5
+
+
 @pytest.mark.parametrize("n,d,c", [(1000, 256, 47), (777, 64, 7), (3001, 128, 40), (33, 256, 64), (500, 256, 2)])
 def test_combine_fc_fused(cuda, n, d, c):
     """T7, large/ours.py:269-270,275: logits = fc(gw * x2 + (1 - gw) * x1) in one kernel (bf16 activations),
@@ -1108,7 +1166,8 @@ def test_gcn_layers_fused_vs_unfused(cuda, monkeypatch):
         for k in g0:
             if k.endswith("W.bias") or k == "fcs.0.bias":
                 # a Linear bias in front of a BatchNorm has the exact gradient 0 (the mean is removed): both are rounding noise
-                assert float(g1[k].abs().max()) <= 1e-2 * max(1.0, float(g0["bns.1.bias"].abs().max())), k
+                # (a column sum of ~5000 bf16-rounded dz values: the roundings do not cancel)
+                assert float(g1[k].abs().max()) <= 5e-2 * max(1.0, float(g0["bns.1.bias"].abs().max())), k
                 continue
             assert _rel(g1[k], g0[k]) <= 3e-2, (mode, k, _rel(g1[k], g0[k]))
         for k in b0:

@@ -524,6 +524,17 @@ int sgf_bn_bwd_stats2(const void* dy, int64_t lddy, const void* dy2, int64_t ldd
  * its input is data, nobody else needs dz):  c[m, k] = dz^T b,  colsum[m] = sum_n dz,  where
  * dz = sgf_bn_bwd_apply(g1 [+ g2], z, ...) is formed per 4 x 4 patch inside the Gram kernel's staging step (bf16 storage, m and
  * k multiples of 4 up to 256).  stats as returned by sgf_bn_bwd_stats2; workspace: sgf_gram_workspace_bytes. */
+/* The LayerNorm form (TransConv's stem, large/ours.py:198-201: Linear -> LayerNorm -> relu, input = data): from g = d(output),
+ * the LayerNorm's input xin and the forward's per-row mean / rstd:
+ *   c[m, k] = dl^T b, colsum[m] = sum_n dl (the Linear's dW / db), dgamma[m] = sum g' xhat, dbeta[m] = sum g' (the LayerNorm's),
+ * dl = sgf_ln_bwd's input gradient, formed per 4 x 4 patch inside the Gram kernel (row means over the m columns across the
+ * lanes of a patch row) and never written.  bf16 storage, m in {64, 128, 256}, k % 4 == 0 up to 256.  gamma / beta null: no
+ * affine.  workspace: sgf_gram_workspace_bytes. */
+int32_t sgf_gram_ln_bwd_supported(int32_t m, int32_t k, int32_t dtype);
+int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int64_t ldx, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, int32_t relu, int32_t m, const void* b, int64_t ldb, int32_t k,
+                    int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum, float* dgamma, float* dbeta, void* workspace,
+                    size_t workspace_bytes, void* stream);
 int32_t sgf_gram_bn_bwd_supported(int32_t m, int32_t k, int32_t dtype);
 int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, const void* z, int64_t ldz, const float* mean,
                     const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,

@@ -3,7 +3,7 @@
 
 Dispatches of one SpMM kernel are grouped by launch order (the target launches each variant `reps` times in a
 row), counters are averaged per group, durations come from the kernel-trace pass.  Prints a markdown table and,
-with --json, the entries of profiles/r03_spmm_pmc.json: HBM bytes per launch = 2 x FETCH_SIZE (KiB; the gfx950
+with --json, the entries of profiles/r04_spmm_pmc.json: HBM bytes per launch = 2 x FETCH_SIZE (KiB; the gfx950
 correction of MI355X_MICROARCH.md §HBM: wide coalesced reads are tallied at half their bytes) + WRITE_SIZE (KiB)."""
 import glob
 import json

@@ -110,6 +110,9 @@ SIGNATURES = {
                                    c_int32, _P, _P, c_size_t, _P]),
     "sgf_bn_bwd_stats2": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, c_int64, c_int32,
                                     c_int32, _P, _P, c_size_t, _P]),
+    "sgf_gram_ln_bwd_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "sgf_gram_ln_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, c_int32, _P, c_int64, c_int32, c_int64,
+                                  c_int32, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_gram_bn_bwd_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "sgf_gram_bn_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float, c_int32,
                                   c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P, _P, c_size_t, _P]),

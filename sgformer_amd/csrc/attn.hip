@@ -40,7 +40,8 @@ namespace {
 constexpr int kRedThreads = 1024;
 constexpr int kTileElems = 65536;                  // RG * DP * DP, identical for every DP
 constexpr int kVecB = kTileElems + 264;            // second column-sum vector (kModeBwdH) + 1 scalar
-constexpr int kPartialStride = kTileElems + 528;   // + [DP colsum | ssq_a | ssq_q | pad][DP colsum_b | s | pad]
+constexpr int kVecC = kTileElems + 528;            // third column-sum vector (kModeGramLN)
+constexpr int kPartialStride = kTileElems + 792;   // + [DP colsum | ssq_a | ssq_q | pad][DP colsum_b | s | pad][DP colsum_c | pad]
 constexpr int kMaxBlocks = kNumCU;                 // persistent: one block per CU
 
 constexpr int kModeFwd = 0;  // reduce: A=K, B=V          apply: out
@@ -51,6 +52,9 @@ constexpr int kModeBwdHS = 4; // the same sums with the per-row scalars (1/den, 
                               // written by k_hrow_bf16<B1>): two streams, no row dot (bf16 only)
 constexpr int kModeGramBN = 5; // Gram whose A operand is formed on the fly: A = BatchNorm'(relu'(g1 [+ g2])) from g1, g2, z and
                                // the reduced statistics (sgf_gram_bn_bwd: the stem's dW without a materialised dz; bf16 only)
+constexpr int kModeGramLN = 6; // Gram whose A operand is the LayerNorm backward of g, formed on the fly: A = LN'(relu'(g)) from g, the
+                               // pre-LayerNorm input and the saved row statistics (sgf_gram_ln_bwd: TransConv's stem; bf16 only);
+                               // colsum = sum A (the Linear's bias gradient), colsum_b = sum g' (d beta), colsum_c = sum g' xhat
 constexpr int kApplyFwd = 0, kApplyDQ = 1, kApplyDK = 2, kApplyDV = 3;
 // attention from the un-projected input (sgf_attn_h_*): no E operand, no global scalars
 constexpr int kApplyHFwd = 4;   // out = (h M + m) / (h.w + beta)
@@ -77,6 +81,8 @@ struct ReduceArgs {
   const void* a2; int64_t lda2;
   const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta, *bn_stats;
   float bn_inv_n; int32_t bn_training, bn_relu;
+  // kModeGramLN: a = g, q = the LayerNorm's input; bn_mean / bn_rstd are then PER-ROW [n] (the forward's saved statistics),
+  // bn_gamma / bn_beta per column (null: no affine), bn_relu the activation behind the LayerNorm
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float4 colsum = zero4(), colsumb = zero4();   // colsumb: bwdH only (sum dnum)
+  float4 colsumc = zero4();                     // kModeGramLN: sum g' xhat (d gamma)
   float ssq_a = 0.f, ssq_q = 0.f;               // bwdH: ssq_a = sum dden
 
   const int64_t ntiles = (p.n + R - 1) / R;
@@ -708,6 +715,16 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   const uint16_t* pa2 = MODE == kModeGramBN && p.a2 ? static_cast<const uint16_t*>(p.a2) + c0 : nullptr;
   // kModeGramBN: this thread's four columns keep their BatchNorm coefficients in registers for the whole kernel
   float bmu[4], brs[4], bga[4], bbe[4], bk0[4], bk1[4];
+  if (MODE == kModeGramLN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      const bool ok = c < p.d;
+      bga[j] = ok ? (p.bn_gamma ? p.bn_gamma[c] : 1.f) : 0.f;
+      bbe[j] = ok ? (p.bn_beta ? p.bn_beta[c] : 0.f) : 0.f;
+      bmu[j] = brs[j] = bk0[j] = bk1[j] = 0.f;
+    }
+  }
   if (MODE == kModeGramBN) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -734,6 +751,10 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       if (MODE == kModeGramBN) {
         r2[i] = (rok && a_ok && p.a2) ? *reinterpret_cast<const uint2*>(pa2 + row * p.lda2) : make_uint2(0u, 0u);
         rden[i] = rok ? 1.f : 0.f;                     // rows past the end contribute nothing (their dz is not zero by itself)
+      }
+      if (MODE == kModeGramLN) {
+        rden[i] = rok ? p.bn_mean[row] : 0.f;          // the row's mean / rstd as the forward left them
+        rden2[i] = rok ? p.bn_rstd[row] : 0.f;
       }
       if (MODE == kModeBwd || MODE == kModeBwdH) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
       if (MODE == kModeBwdHS) {
@@ -787,6 +808,36 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
           gg -= bk0[j] + xh * bk1[j];
           dv[j] = rden[i] != 0.f ? bga[j] * brs[j] * gg : 0.f;
         }
+        ra[i] = make_uint2(pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]));
+        colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
+        colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
+      }
+    } else if (MODE == kModeGramLN) {
+      // ra = g (gradient of the LayerNorm's output, behind the activation), rq = the LayerNorm's input  ->  ra = its input
+      // gradient (sgf_ln_bwd's arithmetic: row means over the d columns, which one patch row of LPQ lanes holds)
+      const float inv_d = 1.0f / static_cast<float>(p.d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g[4] = {bf_lo(ra[i].x), bf_hi(ra[i].x), bf_lo(ra[i].y), bf_hi(ra[i].y)};
+        const float xv[4] = {bf_lo(rq[i].x), bf_hi(rq[i].x), bf_lo(rq[i].y), bf_hi(rq[i].y)};
+        const float mu = rden[i], rs = rden2[i];
+        float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[j] = (xv[j] - mu) * rs;
+          float gm = g[j];
+          if (p.bn_relu) gm = (xh[j] * bga[j] + bbe[j]) > 0.f ? gm : 0.f;
+          if (c0 + j >= p.d) gm = 0.f;
+          dxh[j] = gm * bga[j];
+          s1 += dxh[j];
+          s2 = fmaf(dxh[j], xh[j], s2);
+          (&colsumb.x)[j] += gm;
+          (&colsumc.x)[j] = fmaf(gm, xh[j], (&colsumc.x)[j]);
+        }
+        const float m1 = group_sum<LPQ>(s1) * inv_d, m2 = group_sum<LPQ>(s2) * inv_d;
+        float dv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] = (c0 + j < p.d) ? rs * (dxh[j] - m1 - xh[j] * m2) : 0.f;
         ra[i] = make_uint2(pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]));
         colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
         colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
@@ -914,7 +965,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
     part[kTileElems + DP] = sa;
     part[kTileElems + DP + 1] = sq;
   }
-  if (MODE == kModeBwdH || MODE == kModeBwdHS) {
+  if (MODE == kModeBwdH || MODE == kModeBwdHS || MODE == kModeGramLN) {
     __syncthreads();
     *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsumb;
     __syncthreads();
@@ -924,6 +975,26 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       part[kVecB + tid] = s;
     }
   }
+  if (MODE == kModeGramLN) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&fl[q0 * DP + c0]) = colsumc;
+    __syncthreads();
+    if (tid < DP) {
+      float s = 0.f;
+      for (int r = 0; r < SLOTS; ++r) s += fl[r * DP + tid];
+      part[kVecC + tid] = s;
+    }
+  }
+}
+
+// out[j] = sum over the blocks' partials of one of their column-sum vectors (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_vec_finalize(const float* __restrict__ partial, int nblk, int off, int len,
+                                                      float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * kPartialStride + off + j];
+  out[j] = s;
 }
 
 // k_apply_bf16: out[n x d] = ar[n] (A[n x d] B[d x d]) + br[n] cvec + gr[n] E   on bf16 MFMA.
@@ -1312,6 +1383,55 @@ extern "C" int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int
   const int64_t len = static_cast<int64_t>(m) * k + m;
   hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
                      k, DP, RG, c, ldc, colsum);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+// dW / db of a Linear whose output feeds a LayerNorm (+ activation), and the LayerNorm's own d gamma / d beta, WITHOUT a
+// materialised input gradient (TransConv's stem, large/ours.py:198-201: its input is data):
+//   c = dl^T b, colsum = sum dl, dgamma = sum g' xhat, dbeta = sum g',  dl = sgf_ln_bwd(g, ...) formed inside the Gram kernel.
+extern "C" int32_t sgf_gram_ln_bwd_supported(int32_t m, int32_t k, int32_t dtype) {
+  return dtype == SGF_BF16 && (m == 64 || m == 128 || m == 256) && k >= 4 && k <= 256 && k % 4 == 0 ? 1 : 0;
+}
+
+extern "C" int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int64_t ldx, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int32_t relu, int32_t m, const void* b, int64_t ldb,
+                               int32_t k, int64_t n, int32_t dtype, float* c, int64_t ldc, float* colsum, float* dgamma,
+                               float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_gram_ln_bwd";
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
+  SGF_REQUIRE(sgf_gram_ln_bwd_supported(m, k, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, m in {64, 128, 256} (a row spans whole lane groups), k %% 4 == 0 up to 256 (m=%d k=%d dtype=%d)",
+              fn, m, k, dtype);
+  SGF_REQUIRE(c && ldc >= k, SGF_E_INVALID, "%s: null c or ldc < k", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    SGF_CHECK_HIP(hipMemset2DAsync(c, ldc * sizeof(float), 0, k * sizeof(float), m, st));
+    for (float* v : {colsum, dgamma, dbeta})
+      if (v) SGF_CHECK_HIP(hipMemsetAsync(v, 0, m * sizeof(float), st));
+    return SGF_OK;
+  }
+  SGF_REQUIRE(g && xin && b && mean && rstd, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE, "%s: workspace too small", fn);
+  SGF_REQUIRE(aligned4<uint16_t>(g, ldg) && aligned4<uint16_t>(xin, ldx) && aligned4<uint16_t>(b, ldb), SGF_E_INVALID,
+              "%s: operands must be 4-element aligned with ld %% 4 == 0", fn);
+  const int DP = m;                                    // a LayerNorm row = exactly one patch row of DP / 4 lanes
+  const int R = reduce_rows_per_tile<uint16_t, kModeGramLN>(DP);
+  const int64_t ntiles = (n + R - 1) / R;
+  const int nblk = static_cast<int>(ntiles < kMaxBlocks ? ntiles : kMaxBlocks);
+  ReduceArgs r{};
+  r.a = g; r.lda = ldg; r.q = xin; r.ldq = ldx; r.b = b; r.ldb = ldb; r.den = nullptr;
+  r.n = n; r.d = m; r.db = k; r.heads = 1; r.b_heads = 1; r.gscale = 1.f;
+  r.bn_mean = mean; r.bn_rstd = rstd; r.bn_gamma = gamma; r.bn_beta = beta; r.bn_relu = relu;
+  r.partial = static_cast<float*>(workspace);
+  int rc = launch_reduce<uint16_t, kModeGramLN>(r, DP, nblk, st);
+  if (rc != SGF_OK) return rc;
+  const int RG = reduce_row_groups<uint16_t, kModeGramLN>(DP);
+  const int64_t len = static_cast<int64_t>(m) * k + m;
+  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
+                     k, DP, RG, c, ldc, colsum);
+  if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 255) / 256), dim3(256), 0, st, r.partial, nblk, kVecB, m, dbeta);
+  if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 255) / 256), dim3(256), 0, st, r.partial, nblk, kVecC, m, dgamma);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -584,6 +584,27 @@ class HipKernels:
         return stats
 
     @staticmethod
+    def gram_ln_bwd_supported(m: int, k: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_gram_ln_bwd_supported(int(m), int(k), _lib.SGF_BF16))
+
+    @staticmethod
+    def gram_ln_bwd(g, xin, mean, rstd, gamma, beta, relu: bool, b):
+        """(dl^T b [m, k], sum dl [m], dgamma [m], dbeta [m]) with dl = the LayerNorm's input gradient, never written."""
+        n, m = xin.shape
+        k = b.shape[1]
+        dev = xin.device
+        out = torch.empty((m, k), dtype=_F32, device=dev)
+        cs = torch.empty(m, dtype=_F32, device=dev)
+        dg = torch.empty(m, dtype=_F32, device=dev)
+        db = torch.empty(m, dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", _lib.load().sgf_gram_workspace_bytes(n, m, k))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gram_ln_bwd", _ptr(g), _ld(g), _ptr(xin), _ld(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                      int(relu), m, _ptr(b), _ld(b), k, n, _code(xin), _ptr(out), out.stride(0), _ptr(cs), _ptr(dg), _ptr(db),
+                      _ptr(ws), ws.numel(), _stream(dev))
+        return out, cs, dg, db
+
+    @staticmethod
     def gram_bn_bwd_supported(m: int, k: int, dtype) -> bool:
         return dtype == _BF16 and bool(_lib.load().sgf_gram_bn_bwd_supported(int(m), int(k), _lib.SGF_BF16))
 
@@ -2022,7 +2043,9 @@ class _StemPairBN(torch.autograd.Function):
     (sgf_gram_bn_bwd): x is data, nobody else needs dz."""
 
     @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, gamma, beta, bn_hook, shard):
+    def forward(ctx, x, w0, b0, w1, b1, gamma, beta, bn_hook, shard, ln_gamma=None, ln_beta=None, ln_cfg=None):
+        """ln_cfg = (eps, relu, affine) — not None: the third output is [relu](LayerNorm(y1)) (TransConv's stem, large/ours.py:
+        198-201) instead of y1, and its backward takes dW1 / db1 / d ln_gamma / d ln_beta from sgf_gram_ln_bwd."""
         K.check(x)
         dt = x.dtype
         w0c, w1c = w0.to(dt), w1.to(dt)
@@ -2058,15 +2081,23 @@ class _StemPairBN(torch.autograd.Function):
         mean = mean.detach().float().contiguous()
         rstd = rstd.detach().float().contiguous()
         x0 = K.bn_apply(y0, mean, rstd, g32, be32, None, True)
-        ctx.save_for_backward(x, w0c, w1c, y0, g32, be32, mean, rstd)
+        out1, ln_saved = y1, (None, None, None, None, None)
+        if ln_cfg is not None:
+            eps, ln_relu, affine = ln_cfg
+            lg32 = ln_gamma.detach().float().contiguous() if affine else None
+            lb32 = ln_beta.detach().float().contiguous() if affine else None
+            out1, lmean, lrstd = K.ln_fwd(_rows(y1), None, 1.0, 0.0, lg32, lb32, bool(ln_relu), float(eps))
+            ln_saved = (y1, lmean, lrstd, lg32, lb32)
+        ctx.save_for_backward(x, w0c, w1c, y0, g32, be32, mean, rstd, *ln_saved)
         ctx.meta = (w0.dtype, None if b0 is None else b0.dtype, w1.dtype, None if b1 is None else b1.dtype,
-                    None if gamma is None else gamma.dtype, bool(training), float(n_tot), shard)
-        return x0, x0.view_as(x0), y1
+                    None if gamma is None else gamma.dtype, bool(training), float(n_tot), shard,
+                    None if ln_cfg is None else (bool(ln_cfg[1]), None if ln_gamma is None else ln_gamma.dtype))
+        return x0, x0.view_as(x0), out1
 
     @staticmethod
     def backward(ctx, ga, gb, g1):
-        x, w0c, w1c, y0, g32, be32, mean, rstd = ctx.saved_tensors
-        wd0, bd0, wd1, bd1, gdt, training, n_tot, shard = ctx.meta
+        x, w0c, w1c, y0, g32, be32, mean, rstd, y1, lmean, lrstd, lg32, lb32 = ctx.saved_tensors
+        wd0, bd0, wd1, bd1, gdt, training, n_tot, shard, ln_meta = ctx.meta
         d = y0.shape[1]
         if ga is None:
             ga, gb = gb, None
@@ -2081,8 +2112,17 @@ class _StemPairBN(torch.autograd.Function):
         dw0, db0 = K.gram_bn_bwd(ga, gb, y0, mean, rstd, g32, be32, True, stats, inv_n, training, _rows(x))
         dw0 = dw0.to(wd0) if ctx.needs_input_grad[1] else None
         db0 = db0.to(bd0) if (ctx.needs_input_grad[2] and bd0 is not None) else None
-        dw1, db1 = _linear_param_grads(g1.contiguous(), [x], [x.shape[1]], ctx.needs_input_grad[3],
-                                       ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
+        dlg = dlb = None
+        if ln_meta is not None:
+            # TransConv's stem: LayerNorm backward inside the Gram (dl never written); row-local, no collective
+            ln_relu, lgdt = ln_meta
+            dw1, db1, dlg, dlb = K.gram_ln_bwd(_rows(g1.contiguous()), y1, lmean, lrstd, lg32, lb32, ln_relu, _rows(x))
+            dw1 = dw1.to(wd1) if ctx.needs_input_grad[3] else None
+            db1 = db1.to(bd1) if (ctx.needs_input_grad[4] and bd1 is not None) else None
+            dlg, dlb = (dlg.to(lgdt), dlb.to(lgdt)) if lg32 is not None else (None, None)
+        else:
+            dw1, db1 = _linear_param_grads(g1.contiguous(), [x], [x.shape[1]], ctx.needs_input_grad[3],
+                                           ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
         dgamma = stats[d:].to(gdt) if g32 is not None else None
         dbeta = stats[:d].to(gdt) if be32 is not None else None
         if shard is not None and g32 is not None:
@@ -2091,8 +2131,15 @@ class _StemPairBN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:                      # features that require a gradient (not in any recipe): explicit dz
             g = ga if gb is None else ga + gb
             dz = K.bn_bwd_apply(g, y0, mean, rstd, g32, be32, True, stats, inv_n, training)
-            dx = dz @ w0c + g1 @ w1c
-        return dx, dw0, db0, dw1, db1, dgamma, dbeta, None, None
+            gl = g1
+            if ln_meta is not None:
+                gl = K.ln_bwd(_rows(g1.contiguous()), None, y1, None, 1.0, 0.0, lg32, False, lmean, lrstd)[0] \
+                    if not ln_meta[0] else None
+                if gl is None:
+                    raise NotImplementedError("features that require a gradient behind the fused LayerNorm stem: set "
+                                              "SGF_STEM_LN_FUSED=0")
+            dx = dz @ w0c + gl @ w1c
+        return dx, dw0, db0, dw1, db1, dgamma, dbeta, None, None, dlg, dlb, None
 
 
 def stem_pair_bn_supported(x, w0, w1) -> bool:
@@ -2100,9 +2147,19 @@ def stem_pair_bn_supported(x, w0, w1) -> bool:
             and K.gram_bn_bwd_supported(w0.shape[0], x.shape[1], x.dtype))
 
 
-def stem_pair_bn(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard=None):
-    """(x0 for the layers, x0 for the first SpMM, y1): see _StemPairBN."""
-    return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard)
+def stem_pair_bn(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard=None, ln=None):
+    """(x0 for the layers, x0 for the first SpMM, y1): see _StemPairBN.  ln = (LayerNorm weight, bias, eps, relu): the third
+    output is [relu](LayerNorm(y1)) — TransConv's stem — when the shapes allow (stem_ln_supported)."""
+    if ln is None:
+        return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard)
+    lg, lb, eps, relu = ln
+    return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard, lg, lb, (eps, relu, lg is not None))
+
+
+def stem_ln_supported(x, w1) -> bool:
+    import os
+    return (hasattr(K, "gram_ln_bwd_supported") and K.gram_ln_bwd_supported(w1.shape[0], x.shape[1], x.dtype)
+            and not x.requires_grad and os.environ.get("SGF_STEM_LN_FUSED", "1") != "0")
 
 
 def stem_pair_supported(x, w0, w1) -> bool:

@@ -455,6 +455,8 @@ class TransConv(nn.Module):
         return ops.ln_res_act(x, res, a, b, gamma, beta, relu, ln.eps)
 
     def _embed(self, x, training, stem=None):
+        if isinstance(stem, tuple) and stem[0] == "ln":      # Linear + LayerNorm + relu already applied (ops.stem_pair_bn)
+            return _drop(stem[1], self.dropout, training)
         x = _lin(x, self.fcs[0]) if stem is None else stem
         x = self._ln(self.bns[0], x, None, 1.0, 0.0, True)
         return _drop(x, self.dropout, training)
@@ -596,9 +598,13 @@ class SGFormer(nn.Module):
         if (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns") and gc.fused_stem_ok(x)
                 and ops.stem_pair_bn_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
             bn0 = gc.bns[0]
+            ln = None
+            if getattr(tc, "use_bn", False) and hasattr(tc, "bns") and ops.stem_ln_supported(x, tc.fcs[0].weight):
+                # TransConv's stem too: Linear -> LayerNorm -> relu in the same node (its dW comes from sgf_gram_ln_bwd)
+                ln = (tc.bns[0].weight, tc.bns[0].bias, tc.bns[0].eps, True)
             x0a, x0b, yt = ops.stem_pair_bn(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,
-                                            bn0.weight, bn0.bias, gc._bn_hook(bn0), gc._shard)
-            stem_t, stem_g = yt, ("bn", x0a, x0b)
+                                            bn0.weight, bn0.bias, gc._bn_hook(bn0), gc._shard, ln)
+            stem_t, stem_g = (("ln", yt) if ln is not None else yt), ("bn", x0a, x0b)
         elif (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
                 and ops.stem_pair_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
             want = gc.use_bn and _uses_batch_stats(gc, gc.bns[0])

@@ -396,6 +396,22 @@ class CpuKernels:
         return CpuKernels.bn_bwd_stats(g, x, mean, rstd, gamma, beta, relu)
 
     @staticmethod
+    def gram_ln_bwd_supported(m, k, dtype):
+        return dtype == torch.bfloat16 and m in (64, 128, 256) and k % 4 == 0 and k <= 256
+
+    @staticmethod
+    def gram_ln_bwd(g, xin, mean, rstd, gamma, beta, relu, b):
+        xh = (xin.float() - mean[:, None]) * rstd[:, None]
+        ga = gamma if gamma is not None else 1.0
+        gm = g.float()
+        if relu:
+            gm = gm * ((xh * ga + (beta if beta is not None else 0.0)) > 0)
+        dxh = gm * ga
+        dl = rstd[:, None] * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True))
+        dl = dl.to(xin.dtype).float()
+        return dl.t() @ b.float(), dl.sum(0), (gm * xh).sum(0), gm.sum(0)
+
+    @staticmethod
     def gram_bn_bwd_supported(m, k, dtype):
         return dtype == torch.bfloat16 and m % 4 == 0 and k % 4 == 0 and m <= 256 and k <= 256
 

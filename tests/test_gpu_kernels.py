@@ -1066,6 +1066,48 @@ def test_gram_bn_bwd_without_dz(cuda, n, m, k, two):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("n,m,k,relu,affine", [(3, 256, 100, True, True), (1025, 256, 100, True, True),
+                                               (4099, 128, 128, True, True), (50001, 256, 100, True, True),
+                                               (30000, 64, 64, False, True), (20001, 256, 256, True, False),
+                                               (9000, 64, 8, True, True)])
+def test_gram_ln_bwd_without_dl(cuda, n, m, k, relu, affine):
+    """sgf_gram_ln_bwd: dW / db of TransConv's stem Linear and d gamma / d beta of its LayerNorm (large/ours.py:198-201
+    differentiated) from the gradient of the stem's output — dl = LayerNorm'(relu'(g)) is formed per patch inside the Gram
+    kernel and never written.  Against fp64 on the same bf16 operands with dl rounded to bf16 once (as sgf_ln_bwd stores it):
+    dW / db within 3e-4 (relative, Frobenius: the row means are fp32 sums in another order, which moves single roundings of dl),
+    d gamma / d beta within 2e-6 of their absolute sums; and dW against the explicit sgf_ln_bwd + sgf_gram sequence."""
+    from sgformer_amd import ops
+    K = ops.K
+    assert K.gram_ln_bwd_supported(m, k, torch.bfloat16)
+    g = torch.Generator().manual_seed(5 * n + m + k)
+    gr = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    xin = (torch.randn(n, m, generator=g) * 1.7 + 0.3).bfloat16().to(cuda)
+    x = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(m, generator=g)).to(cuda) if affine else None
+    beta = (0.2 * torch.randn(m, generator=g)).to(cuda) if affine else None
+    h, mean, rstd = K.ln_fwd(xin, None, 1.0, 0.0, gamma, beta, relu, 1e-5)
+    dw, db, dg, dbt = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
+    xh = (xin.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    ga = gamma.double() if affine else 1.0
+    be = beta.double() if affine else 0.0
+    gm = gr.double() * ((xh * ga + be) > 0) if relu else gr.double()
+    dxh = gm * ga
+    dl = rstd.double()[:, None] * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True))
+    dl_r = dl.float().bfloat16().double()
+    tol = 3e-3 if n < 10 else 3e-4
+    assert _rel(dw, dl_r.t() @ x.double()) <= tol, _rel(dw, dl_r.t() @ x.double())
+    assert _rel(db, dl_r.sum(0)) <= tol or float(dl_r.sum(0).abs().max()) < 1e-2
+    if affine:
+        assert bool(((dg.double() - (gm * xh).sum(0)).abs() <= 2e-6 * (gm * xh).abs().sum(0).clamp_min(1e-3)).all())
+        assert bool(((dbt.double() - gm.sum(0)).abs() <= 2e-6 * gm.abs().sum(0).clamp_min(1e-3)).all())
+    # the explicit sequence it replaces: dl written by sgf_ln_bwd, then sgf_gram
+    dl_k = K.ln_bwd(gr, h if relu else None, xin, None, 1.0, 0.0, gamma, relu, mean, rstd)[0]
+    dw_k, db_k = K.gram(dl_k, x, want_colsum=True)
+    assert _rel(dw, dw_k) <= tol
+    dw2, db2, dg2, dbt2 = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dg, dg2) and torch.equal(dbt, dbt2)
+
+
 @pytest.mark.parametrize("n,m,k", [(100, 256, 256), (1025, 256, 256), (4099, 128, 128), (50001, 256, 256), (30000, 64, 64),
                                    (20000, 48, 256)])
 def test_gram2_paired_launch(cuda, n, m, k):

@@ -290,6 +290,9 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
     model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
                      compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
+    # fp32 logits straight from the fused head, as under sgformer_amd.launch (fp32 features in -> fp32 logits out); the
+    # features here are stored in bf16 ahead of the loop, which would otherwise round the logits to bf16 and back
+    model.logits_dtype = torch.float32
     if ctx is not None:
         shard_model(model, ctx)
     # the optimizer exactly as the trainer constructs it (large/main.py:114-119); under sgformer_amd.launch — and here —

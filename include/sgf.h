@@ -528,8 +528,9 @@ int sgf_bn_bwd_stats2(const void* dy, int64_t lddy, const void* dy2, int64_t ldd
  * the LayerNorm's input xin and the forward's per-row mean / rstd:
  *   c[m, k] = dl^T b, colsum[m] = sum_n dl (the Linear's dW / db), dgamma[m] = sum g' xhat, dbeta[m] = sum g' (the LayerNorm's),
  * dl = sgf_ln_bwd's input gradient, formed per 4 x 4 patch inside the Gram kernel (row means over the m columns across the
- * lanes of a patch row) and never written.  bf16 storage, m in {64, 128, 256}, k % 4 == 0 up to 256.  gamma / beta null: no
- * affine.  workspace: sgf_gram_workspace_bytes. */
+ * lanes of a patch row) and never written.  bf16 storage, m in {64, 128, 256}, k % 4 == 0 up to 256.  gamma / beta null: a
+ * LayerNorm without affine terms (NOT sgf_ln_fwd's "no LayerNorm"); dgamma / dbeta may be null.  workspace:
+ * sgf_gram_workspace_bytes. */
 int32_t sgf_gram_ln_bwd_supported(int32_t m, int32_t k, int32_t dtype);
 int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int64_t ldx, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, int32_t relu, int32_t m, const void* b, int64_t ldb, int32_t k,

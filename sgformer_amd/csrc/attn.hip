@@ -753,8 +753,12 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
         rden[i] = rok ? 1.f : 0.f;                     // rows past the end contribute nothing (their dz is not zero by itself)
       }
       if (MODE == kModeGramLN) {
-        rden[i] = rok ? p.bn_mean[row] : 0.f;          // the row's mean / rstd as the forward left them
-        rden2[i] = rok ? p.bn_rstd[row] : 0.f;
+        int64_t rr = row < p.n ? row : p.n - 1;         // unconditional loads (rows past the end carry g = 0: they add nothing)
+        if (LPQ == 64)                                  // one row per wave: a scalar load, the statistics live in SGPRs
+          rr = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rr >> 32))) << 32) |
+               static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rr)));
+        rden[i] = p.bn_mean[rr];                       // the row's mean / rstd as the forward left them
+        rden2[i] = p.bn_rstd[rr];
       }
       if (MODE == kModeBwd || MODE == kModeBwdH) rden[i] = rok ? p.den[row * p.heads + head] : 1.f;
       if (MODE == kModeBwdHS) {
@@ -816,28 +820,43 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
       // ra = g (gradient of the LayerNorm's output, behind the activation), rq = the LayerNorm's input  ->  ra = its input
       // gradient (sgf_ln_bwd's arithmetic: row means over the d columns, which one patch row of LPQ lanes holds)
       const float inv_d = 1.0f / static_cast<float>(p.d);
+      // three phases so that only the packed operands and eight partial sums live across the lane reductions (the one-phase
+      // form kept xhat and dxhat of all four rows in registers and spilled at d = 256): sums, reductions, then xhat / g' again
+      float s1[4], s2[4];
+      auto masked = [&](int i, int j, float xh) -> float {
+        float gm = j == 0 ? bf_lo(ra[i].x) : j == 1 ? bf_hi(ra[i].x) : j == 2 ? bf_lo(ra[i].y) : bf_hi(ra[i].y);
+        if (p.bn_relu) gm = fmaf(xh, bga[j], bbe[j]) > 0.f ? gm : 0.f;
+        return (c0 + j < p.d) ? gm : 0.f;
+      };
+      auto xhat = [&](int i, int j) -> float {
+        const float xv = j == 0 ? bf_lo(rq[i].x) : j == 1 ? bf_hi(rq[i].x) : j == 2 ? bf_lo(rq[i].y) : bf_hi(rq[i].y);
+        return (xv - rden[i]) * rden2[i];
+      };
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float g[4] = {bf_lo(ra[i].x), bf_hi(ra[i].x), bf_lo(ra[i].y), bf_hi(ra[i].y)};
-        const float xv[4] = {bf_lo(rq[i].x), bf_hi(rq[i].x), bf_lo(rq[i].y), bf_hi(rq[i].y)};
-        const float mu = rden[i], rs = rden2[i];
-        float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+        s1[i] = s2[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[j] = (xv[j] - mu) * rs;
-          float gm = g[j];
-          if (p.bn_relu) gm = (xh[j] * bga[j] + bbe[j]) > 0.f ? gm : 0.f;
-          if (c0 + j >= p.d) gm = 0.f;
-          dxh[j] = gm * bga[j];
-          s1 += dxh[j];
-          s2 = fmaf(dxh[j], xh[j], s2);
+          const float xh = xhat(i, j), gm = masked(i, j, xh), dxh = gm * bga[j];
+          s1[i] += dxh;
+          s2[i] = fmaf(dxh, xh, s2[i]);
           (&colsumb.x)[j] += gm;
-          (&colsumc.x)[j] = fmaf(gm, xh[j], (&colsumc.x)[j]);
+          (&colsumc.x)[j] = fmaf(gm, xh, (&colsumc.x)[j]);
         }
-        const float m1 = group_sum<LPQ>(s1) * inv_d, m2 = group_sum<LPQ>(s2) * inv_d;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s1[i] = (LPQ == 64 ? wave_sum_uniform(s1[i]) : group_sum<LPQ>(s1[i])) * inv_d;
+        s2[i] = (LPQ == 64 ? wave_sum_uniform(s2[i]) : group_sum<LPQ>(s2[i])) * inv_d;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         float dv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dv[j] = (c0 + j < p.d) ? rs * (dxh[j] - m1 - xh[j] * m2) : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const float xh = xhat(i, j), dxh = masked(i, j, xh) * bga[j];
+          dv[j] = (c0 + j < p.d) ? rden2[i] * (dxh - s1[i] - xh * s2[i]) : 0.f;
+        }
         ra[i] = make_uint2(pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]));
         colsum.x += bf_lo(ra[i].x); colsum.y += bf_hi(ra[i].x);
         colsum.z += bf_lo(ra[i].y); colsum.w += bf_hi(ra[i].y);
@@ -990,11 +1009,21 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
 // out[j] = sum over the blocks' partials of one of their column-sum vectors (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_vec_finalize(const float* __restrict__ partial, int nblk, int off, int len,
                                                       float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= len) return;
+  // 32 columns x 8 groups of blocks per workgroup: eight independent chains of loads per column instead of one
+  __shared__ float part[8][32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * kPartialStride + off + j];
-  out[j] = s;
+  if (j < len)
+    for (int b = g; b < nblk; b += 8) s += partial[static_cast<int64_t>(b) * kPartialStride + off + j];
+  part[g][c] = s;
+  __syncthreads();
+  if (g == 0 && j < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += part[i][c];
+    out[j] = t;
+  }
 }
 
 // k_apply_bf16: out[n x d] = ar[n] (A[n x d] B[d x d]) + br[n] cvec + gr[n] E   on bf16 MFMA.
@@ -1430,8 +1459,8 @@ extern "C" int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int6
   const int64_t len = static_cast<int64_t>(m) * k + m;
   hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
                      k, DP, RG, c, ldc, colsum);
-  if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 255) / 256), dim3(256), 0, st, r.partial, nblk, kVecB, m, dbeta);
-  if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 255) / 256), dim3(256), 0, st, r.partial, nblk, kVecC, m, dgamma);
+  if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, r.partial, nblk, kVecB, m, dbeta);
+  if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, r.partial, nblk, kVecC, m, dgamma);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

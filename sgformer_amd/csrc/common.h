@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/sgf.h"
 
@@ -132,6 +133,23 @@ __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Sum over all 64 lanes on the VALU's DPP path (no LDS traffic, no latency to hide), result uniform — the compiler keeps
+// it in an SGPR.  Hillis-Steele inside each row of 16 lanes (row_shr 1/2/4/8, zero fill), then row_bcast:15 into rows 1, 3
+// and row_bcast:31 into rows 2, 3: lane 63 holds the total.
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                 decltype(row_mask)::value, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- MFMA (exact-fp32 matrix cores; cdna_hip_programming.md §3) ------------------------------

@@ -515,6 +515,10 @@ class SGFormer(nn.Module):
         # torch.bfloat16: bf16 activation storage, fp32 master weights and fp32 accumulation in every
         # kernel and GEMM (BASELINE.json config 3); logits are returned in fp32 either way.
         self.compute_dtype = DEFAULT_COMPUTE_DTYPE if isinstance(compute_dtype, str) else compute_dtype
+        # dtype of the returned logits; None = the input's.  The fused head computes them in fp32: a caller that stores
+        # its features in bf16 and takes the loss in fp32 (bench.py) sets torch.float32 here instead of paying a round trip
+        # through bf16 — under sgformer_amd.launch the trainer's features are fp32 and the logits already are.
+        self.logits_dtype = None
         self.trans_conv = (trans_cls or TransConv)(
             in_channels, hidden_channels, num_layers=trans_num_layers, num_heads=trans_num_heads,
             dropout=trans_dropout, use_bn=trans_use_bn, use_residual=trans_use_residual,
@@ -558,7 +562,7 @@ class SGFormer(nn.Module):
         if not x.is_cuda and ops.K.name == "hip" and not next(self.parameters()).is_cuda:
             return self._forward_on_gpu_from_host(x, edge_index)
         ops._require_cuda(x, edge_index)
-        out_dtype = x.dtype
+        out_dtype = x.dtype if getattr(self, 'logits_dtype', None) is None else self.logits_dtype
         cdt = self.compute_dtype if self.compute_dtype is not None else x.dtype
         # The graph is resolved once per forward.  If its cached view carries a locality-restoring node
         # order (ops.GraphView), the rows of x are permuted here — fused with the storage cast — and the

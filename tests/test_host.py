@@ -656,3 +656,40 @@ def test_launcher_nll_patch_installs_and_restores():
     finally:
         launch.unpatch_nll_loss()
     assert F.nll_loss is before
+
+
+@pytest.mark.parametrize("sum_v", [False, True])
+@pytest.mark.parametrize("d,d_in", [(8, 8), (16, 12)])
+def test_packed_attention_algebra_matches_the_term_by_term_form(sum_v, d, d_in):
+    """ops._attn_h_small_packed (augmented operands, 12 launches) == ops._attn_h_small (include/sgf.h's formulas term by term),
+    values and all eight gradients, in fp64 to 1e-12."""
+    import torch
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(d + d_in + int(sum_v))
+    h = torch.randn(50, d_in, generator=g, dtype=torch.float64)
+    G, s = (h.t() @ h), h.sum(0)
+    par = [torch.randn(d, d_in, generator=g, dtype=torch.float64) * 0.3, torch.randn(d, generator=g, dtype=torch.float64) * 0.1,
+           torch.randn(d, d_in, generator=g, dtype=torch.float64) * 0.3, torch.randn(d, generator=g, dtype=torch.float64) * 0.1,
+           torch.randn(d, d_in, generator=g, dtype=torch.float64) * 0.3, torch.randn(d, generator=g, dtype=torch.float64) * 0.1]
+    if d != d_in:
+        pytest.skip("M = c wq^T s0 + N wv^T needs d == d_in") if not sum_v else None
+    leaves = [t.clone().requires_grad_(True) for t in (G, s, *par)]
+    ref = ops._attn_h_small(leaves[0], leaves[1], 50.0, 70.0, *leaves[2:], sum_v=sum_v)
+    cot = [torch.randn(t.shape, generator=g, dtype=torch.float64) for t in ref]
+    gref = torch.autograd.grad(ref, leaves, cot)
+    old = ops._F32
+    ops._F32 = torch.float64
+    try:
+        packed = [t.requires_grad_(True) for t in ops._attn_h_pack(G, s, 50.0, *par)]
+    finally:
+        ops._F32 = old
+    out = ops._attn_h_small_packed(*packed, 70.0, sum_v=sum_v)
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max()))
+    gGt, gWqk, gWv = torch.autograd.grad(out, packed, cot)
+    got = [gGt[:d_in, :d_in], gGt[:d_in, d_in] + gGt[d_in, :d_in], gWqk[:d, :d_in], gWqk[:d, d_in], gWqk[d:, :d_in],
+           gWqk[d:, d_in], gWv[:, :d_in], gWv[:, d_in]]
+    # dG: the term-by-term form's gradient of the SYMMETRIC G is not symmetric itself; both feed D = dG + dG^T
+    assert float(((got[0] + got[0].t()) - (gref[0] + gref[0].t())).abs().max()) <= 1e-11 * max(1.0, float(gref[0].abs().max()))
+    for a, b in zip(got[1:], gref[1:]):
+        assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max()))

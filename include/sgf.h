@@ -288,7 +288,7 @@ int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_rows, const 
  * num_neighbors=[15, 10, 5], ...) of 100M/nb-sample.py:125-151 (third-party pyg-lib / torch_sparse
  * neighbor_sample, replace=False, directed=True).  Hop h gives every node that ENTERED the batch in
  * hop h-1 (the seeds for h = 0) min(in-degree, fanout) of its in-neighbours, drawn without
- * replacement (fanout < 0: all of them; fanout <= 32 otherwise); a neighbour not yet in the batch gets
+ * replacement (fanout < 0: all of them; Floyd's subset sampling up to 32, selection sampling above); a neighbour not yet in the batch gets
  * the next local id in order of first appearance (so the seeds are rows [0, batch_size): the trainer
  * slices [:batch_size], 100M/nb-sample.py:29-30); sampled edges point neighbour -> node, in local ids.
  * The reference's random stream cannot be matched; the draw is a counter-based hash of
@@ -311,6 +311,23 @@ int sgf_neighbor_sample_hop(const int64_t* rowptr, const int32_t* colind, const 
                             int32_t* local_of, int32_t n_known, int64_t edge_cap, int32_t* edge_src_local,
                             int32_t* edge_dst_local, int32_t* src_global, int32_t* new_nodes, int64_t* counts,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* A whole batch — every hop of it — WITHOUT a host read (fan-outs >= 0): the frontier size, the local-id base and the output
+ * offsets of every hop stay in device memory, the launches are sized for the capacities
+ *   frontier_0 = batch_size, edges_h = frontier_h * fanout_h, frontier_{h+1} = edges_h
+ * (sgf_neighbor_sample_batch_workspace_bytes also returns them: node_cap = batch_size + sum edges_h, edge_cap = sum edges_h;
+ * 0 bytes = a negative fan-out or more than 2^31 - 2 entries: not supported).  Same draws, same local ids, same edge order as
+ * sgf_neighbor_sample_mark + one sgf_neighbor_sample_hop per hop + the un-marking, bit for bit.
+ *   nodes  : out, int32[node_cap] global ids in local-id order (seeds first)
+ *   edge_* : out, int32[edge_cap] local ids, hop after hop
+ *   counts : out, device int64[2 + 2 * hops] = { nodes, edges, edges of hop 0, nodes entered in hop 0, ... } — the ONE read the
+ *            caller needs to size its views.  local_of is back to INT32_MIN for every node of the batch on return. */
+size_t sgf_neighbor_sample_batch_workspace_bytes(int64_t batch_size, const int32_t* fanouts, int32_t hops, int64_t* node_cap,
+                                                  int64_t* edge_cap);
+int sgf_neighbor_sample_batch(const int64_t* rowptr, const int32_t* colind, const int32_t* seeds, int64_t batch_size,
+                              const int32_t* fanouts, int32_t hops, uint64_t seed, uint64_t batch, int32_t* local_of,
+                              int32_t* nodes, int64_t node_cap, int32_t* edge_src_local, int32_t* edge_dst_local,
+                              int64_t edge_cap, int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dst[i, :] = src[idx[i], :] with an optional fp32 <-> bf16 storage change.  Replaces the row
  * gathers at the module boundary: x[idx_i] of a mini-batch (large/main-batch.py:138) and the

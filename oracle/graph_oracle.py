@@ -367,7 +367,8 @@ def _mix64(z):
 
 def neighbor_sample(rowptr, colind, seeds, fanouts, seed, batch):
     """n_id, edge_src_local, edge_dst_local — sgf_neighbor_sample_* (csrc/sampler.hip), the draw included: hop h gives
-    every node that entered in hop h - 1 min(in-degree, fanout) in-neighbours by Floyd's subset sampling with the
+    every node that entered in hop h - 1 min(in-degree, fanout) in-neighbours by Floyd's subset sampling (selection sampling
+    above fan-out 32) with the
     counter-based hash of (seed, batch, hop, node); new nodes get local ids in order of first appearance."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colind = np.asarray(colind, dtype=np.int64)
@@ -385,11 +386,18 @@ def neighbor_sample(rowptr, colind, seeds, fanouts, seed, batch):
             else:
                 nk = _mix64(key ^ ((f * 0xD6E8FEB86659FD93) & _M64))
                 picks = []
-                for j, t in enumerate(range(deg - k, deg)):
-                    r = _mix64((nk + j) & _M64) % (t + 1)
-                    if r in picks:
-                        r = t
-                    picks.append(r)
+                if k <= 32:          # Floyd's subset sampling, in draw order
+                    for j, t in enumerate(range(deg - k, deg)):
+                        r = _mix64((nk + j) & _M64) % (t + 1)
+                        if r in picks:
+                            r = t
+                        picks.append(r)
+                else:                # selection sampling (Knuth's algorithm S), in position order
+                    for j in range(deg):
+                        if len(picks) == k:
+                            break
+                        if _mix64((nk + j) & _M64) % (deg - j) < k - len(picks):
+                            picks.append(j)
             s_glob += [int(colind[base + r]) for r in picks]
             dst += [local0 + i] * len(picks)
         new = []

@@ -61,6 +61,9 @@ SIGNATURES = {
                                 c_int64, c_int32, c_int32, c_int64, c_int64, _P, c_size_t, _P]),
     "sgf_neighbor_sample_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_neighbor_sample_mark": (c_int32, [_P, _P, c_int64, c_int32, _P]),
+    "sgf_neighbor_sample_batch_workspace_bytes": (c_size_t, [c_int64, _P, c_int32, _P, _P]),
+    "sgf_neighbor_sample_batch": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, c_uint64, c_uint64, _P, _P, c_int64, _P, _P,
+                                            c_int64, _P, _P, c_size_t, _P]),
     "sgf_neighbor_sample_hop": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_uint64, c_uint64, c_int32, _P, c_int32,
                                           c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_gather_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64,

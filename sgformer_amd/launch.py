@@ -66,7 +66,10 @@ def patch_100m_data_utils():
     cannot be imported as shipped.  Import the trainer's own data_utils (its directory is on sys.path by now) and add the
     missing name as a stub; the papers100M path (nb-sample.py:96-97) never calls it."""
     import importlib as _il
-    du = _il.import_module("data_utils")
+    try:
+        du = _il.import_module("data_utils")
+    except ModuleNotFoundError:          # a trainer without a data_utils module has nothing to repair
+        return None
     if not hasattr(du, "load_fixed_splits"):
         def load_fixed_splits(*args, **kwargs):
             raise NotImplementedError("100M/data_utils.py does not define load_fixed_splits (only ogbn-papers100M's own "

@@ -86,10 +86,15 @@ class NeighborSampler:
         self.rowptr, self.colind, self.local_of, self.max_deg = dg.rowptr, dg.colind, dg.local_of, dg.max_deg
         self.n, self.device = int(num_nodes), dev
         self.fanouts = [int(k) for k in num_neighbors]
-        if any(k > 32 for k in self.fanouts):
-            raise ValueError("NeighborSampler: fan-outs above 32 are not supported (use -1 for all neighbours)")
         self.seed = int(seed) & (2 ** 64 - 1)
         self.batches = 0
+        # non-negative fan-outs: the whole batch is one sgf_neighbor_sample_batch call with its hop bookkeeping on the
+        # device and ONE host read (the sizes of the views); -1 (all neighbours) has no a-priori capacity and keeps the
+        # hop-by-hop path with its read per hop
+        self._fan_dev = (torch.tensor(self.fanouts, dtype=torch.int32, device=dev)
+                         if self.fanouts and all(k >= 0 for k in self.fanouts) else None)
+        self._fan_host = (ctypes.c_int32 * len(self.fanouts))(*self.fanouts)
+        self.host_reads = 0
 
     def sample(self, seeds: torch.Tensor, batch_id: Optional[int] = None):
         dev = self.device
@@ -98,6 +103,8 @@ class NeighborSampler:
         batch_id = self.batches if batch_id is None else int(batch_id)
         self.batches += 1
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if self._fan_dev is not None:
+            return self._sample_batch(seeds32, bs, batch_id, st)
         nodes = [seeds32]
         srcs, dsts = [], []
         with torch.cuda.device(dev):
@@ -116,6 +123,33 @@ class NeighborSampler:
         ei = torch.stack([torch.cat(srcs), torch.cat(dsts)]).long() if srcs else torch.zeros(2, 0, dtype=torch.int64, device=dev)
         ei._sgf_trusted = True          # local ids are in range by construction: ops.CSRGraph skips its host check
         return n_id32.long(), ei, bs
+
+    def _sample_batch(self, seeds32, bs, batch_id, st):
+        dev = self.device
+        lib = _lib.load()
+        ncap, ecap = ctypes.c_int64(0), ctypes.c_int64(0)
+        nbytes = lib.sgf_neighbor_sample_batch_workspace_bytes(bs, self._fan_host, len(self.fanouts), ctypes.byref(ncap), ctypes.byref(ecap))
+        if nbytes == 0:
+            raise RuntimeError("NeighborSampler: batch too large (more than 2^31 sampled entries)")
+        ncap, ecap = ncap.value, ecap.value
+        nodes = torch.empty(max(ncap, 1), dtype=torch.int32, device=dev)
+        e_src = torch.empty(max(ecap, 1), dtype=torch.int32, device=dev)
+        e_dst = torch.empty(max(ecap, 1), dtype=torch.int32, device=dev)
+        counts = torch.empty(2 + 2 * len(self.fanouts), dtype=torch.int64, device=dev)
+        ws = ops._workspace(dev, "nbr_sample", nbytes)
+        with torch.cuda.device(dev):
+            try:
+                _lib.call("sgf_neighbor_sample_batch", _ptr(self.rowptr), _ptr(self.colind), _ptr(seeds32), bs, self._fan_host,
+                          len(self.fanouts), ctypes.c_uint64(self.seed), ctypes.c_uint64(batch_id), _ptr(self.local_of),
+                          _ptr(nodes), ncap, _ptr(e_src), _ptr(e_dst), ecap, _ptr(counts), _ptr(ws), ws.numel(), st)
+            except BaseException:
+                self.local_of.fill_(torch.iinfo(torch.int32).min)
+                raise
+        nn, ne = (int(v) for v in counts[:2].tolist())          # the one host read of the batch
+        self.host_reads += 1
+        ei = torch.stack([e_src[:ne], e_dst[:ne]]).long()
+        ei._sgf_trusted = True
+        return nodes[:nn].long(), ei, bs
 
     def _hops(self, st, nodes, srcs, dsts, frontier, local0, n_known, batch_id):
         dev = self.device
@@ -136,6 +170,7 @@ class NeighborSampler:
                           ctypes.c_uint64(self.seed), ctypes.c_uint64(batch_id), hop, _ptr(self.local_of), n_known, cap,
                           _ptr(e_src), _ptr(e_dst), _ptr(s_glob), _ptr(new), _ptr(counts), _ptr(ws), ws.numel(), st)
                 ne, nn = (int(v) for v in counts.tolist())
+                self.host_reads += 2        # this one and the edge count inside sgf_neighbor_sample_hop
                 srcs.append(e_src[:ne])
                 dsts.append(e_dst[:ne])
                 frontier, local0 = new[:nn].contiguous(), n_known

@@ -26,7 +26,7 @@ def _graph(n=4000, deg=14.0, seed=3):
     return synth.synthetic_graph_skewed(n, deg, gamma=2.5, seed=seed), n
 
 
-@pytest.mark.parametrize("fanouts", [[15, 10, 5], [3, 2], [-1, 4], [32]])
+@pytest.mark.parametrize("fanouts", [[15, 10, 5], [3, 2], [-1, 4], [32], [40, 3], [100], [0, 5], [5, 0, 3]])
 def test_sampler_matches_oracle_and_loader_semantics(cuda, fanouts):
     from sgformer_amd.sampling import NeighborSampler
     ei, n = _graph()
@@ -67,18 +67,40 @@ def test_sampler_matches_oracle_and_loader_semantics(cuda, fanouts):
         assert bool((s.local_of == torch.iinfo(torch.int32).min).all())        # state reset for the next batch
 
 
-def test_sampler_is_reproducible_and_uniform(cuda):
+@pytest.mark.parametrize("fanouts", [[15, 10, 5], [40, 6], [7]])
+def test_whole_batch_call_equals_hop_by_hop(cuda, fanouts):
+    """sgf_neighbor_sample_batch (hop bookkeeping on the device, ONE host read per batch) == sgf_neighbor_sample_mark + one
+    sgf_neighbor_sample_hop per hop (two reads per hop), bit for bit: node list, edges, and the state left behind."""
+    from sgformer_amd.sampling import NeighborSampler
+    ei, n = _graph(n=5000, deg=18.0, seed=4)
+    a = NeighborSampler(ei.to(cuda), n, fanouts, seed=99)
+    b = NeighborSampler(ei.to(cuda), n, fanouts, seed=99)
+    assert a._fan_dev is not None
+    b._fan_dev = None                                   # the hop-by-hop path
+    g = torch.Generator().manual_seed(1)
+    for t in range(4):
+        seeds = torch.randperm(n, generator=g)[: [1, 64, 700, 1024][t]].to(cuda)
+        ra, rb = a.sample(seeds), b.sample(seeds)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and ra[2] == rb[2]
+        assert bool((a.local_of == torch.iinfo(torch.int32).min).all())
+    assert a.host_reads == 4 and b.host_reads == 4 * 2 * len(fanouts)
+    n_id, e, bs = a.sample(torch.zeros(0, dtype=torch.int64, device=cuda))      # an empty batch
+    assert n_id.numel() == 0 and e.shape == (2, 0) and bs == 0
+
+
+@pytest.mark.parametrize("k", [15, 40])
+def test_sampler_is_reproducible_and_uniform(cuda, k):
     from sgformer_amd.sampling import NeighborSampler
     ei, n = _graph(n=3000, deg=20.0, seed=8)
-    a = NeighborSampler(ei.to(cuda), n, [15, 10, 5], seed=7)
-    b = NeighborSampler(ei.to(cuda), n, [15, 10, 5], seed=7)
-    c = NeighborSampler(ei.to(cuda), n, [15, 10, 5], seed=8)
+    a = NeighborSampler(ei.to(cuda), n, [k, 10, 5], seed=7)
+    b = NeighborSampler(ei.to(cuda), n, [k, 10, 5], seed=7)
+    c = NeighborSampler(ei.to(cuda), n, [k, 10, 5], seed=8)
     seeds = torch.arange(100, 400)
     ra, rb, rc = a.sample(seeds.to(cuda)), b.sample(seeds.to(cuda)), c.sample(seeds.to(cuda))
     assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
     assert not (ra[1].shape == rc[1].shape and torch.equal(ra[1], rc[1]))
     # uniformity: the hub (node 0) has hundreds of in-neighbours; over many batches every one of them is drawn with
-    # probability 15 / deg
+    # probability k / deg (k = 15: Floyd's subset sampling, k = 40: selection sampling)
     deg = int(a.rowptr[1] - a.rowptr[0])
     assert deg > 150
     nbrs = a.colind[: deg].cpu().numpy()
@@ -87,10 +109,10 @@ def test_sampler_is_reproducible_and_uniform(cuda):
     for t in range(trials):
         n_id, e, _ = a.sample(torch.tensor([0], device=cuda))
         first = e[:, e[1] == 0][0]
-        assert first.numel() == 15
+        assert first.numel() == k
         hits[n_id[first].cpu().numpy()] += 1
-    assert hits.sum() == 15 * trials and np.all(hits[np.setdiff1d(np.arange(n), nbrs)] == 0)
-    exp = 15 * trials / deg
+    assert hits.sum() == k * trials and np.all(hits[np.setdiff1d(np.arange(n), nbrs)] == 0)
+    exp = k * trials / deg
     chi2 = float(((hits[nbrs] - exp) ** 2 / exp).sum())
     assert chi2 < deg + 6 * np.sqrt(2 * deg), (chi2, deg)                      # mean deg-1, sd sqrt(2 deg)
 

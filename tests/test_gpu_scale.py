@@ -130,10 +130,7 @@ def test_products_recipe_auto_policy_bf16(cuda, products_case):
         g = k["g64"][name]
         report["grad/" + name] = [float((gt[name] - g).norm() / g.norm()), float((gp[name] - g).norm() / g.norm())]
     _report("products-170k bf16 auto-reorder (tiled vs plain):", report)
-    assert e_t <= 3e-2 and e_t <= 2.0 * e_p + 1e-3, report
-    assert abs(loss_t - k["loss_ref"]) <= 3e-2 * abs(k["loss_ref"]), report
-    for name, (r_t, r_p) in ((n_, v) for n_, v in report.items() if n_.startswith("grad/")):
-        assert r_t <= 0.15 and r_t <= 2.0 * r_p + 2e-2, (name, report)
+    _check_bf16(report, e_t, e_p, loss_t, k["loss_ref"])
 
 
 def test_products_recipe_powerlaw_graph_with_hubs_bf16(cuda):
@@ -168,11 +165,8 @@ def test_products_recipe_powerlaw_graph_with_hubs_bf16(cuda):
     for name in ["fc.weight", "graph_conv.convs.2.W.weight", "graph_conv.fcs.0.weight", "trans_conv.fcs.0.weight"]:
         g = g64[name]
         report["grad/" + name] = [float((gt[name] - g).norm() / g.norm()), float((gp[name] - g).norm() / g.norm())]
-    print("products-recipe power-law 150k bf16 (tiled vs plain):", json.dumps(report))
-    assert e_t <= 3e-2 and e_t <= 2.0 * e_p + 1e-3, report
-    assert abs(loss_t - loss_ref) <= 3e-2 * abs(loss_ref), report
-    for name, (r_t, r_p) in ((n_, v) for n_, v in report.items() if n_.startswith("grad/")):
-        assert r_t <= 0.15 and r_t <= 2.0 * r_p + 2e-2, (name, report)
+    _report("products-recipe power-law 150k bf16 (tiled vs plain):", report)
+    _check_bf16(report, e_t, e_p, loss_t, loss_ref, grad_rel=BF16_GRAD_REL_POWERLAW)
 
 
 def test_pokec_recipe_fp32_with_unlabeled_nodes(cuda):
@@ -232,11 +226,32 @@ def test_100m_recipe_bf16_d128(cuda):
     for name in ["fc.weight", "graph_conv.convs.2.W.weight", "graph_conv.fcs.0.weight", "trans_conv.fcs.0.weight"]:
         g = g64[name]
         report["grad/" + name] = [float((gt[name] - g).norm() / g.norm()), float((gp[name] - g).norm() / g.norm())]
-    print("100M-recipe 120k bf16 d=128:", json.dumps(report))
-    assert e_t <= 3e-2 and e_t <= 2.0 * e_p + 1e-3, report
-    assert abs(loss_t - loss_ref) <= 3e-2 * abs(loss_ref), report
+    _report("100M-recipe 120k bf16 d=128:", report)
+    _check_bf16(report, e_t, e_p, loss_t, loss_ref, grad_rel=BF16_GRAD_REL_100M)
+
+
+# bf16 bounds = 2 x the error measured on MI355X in round 4 (gpurun_out/scale_reports.jsonl -> profiles/r04_scale_reports.jsonl),
+# relative Frobenius distance to the fp64 oracle; VERDICT r03 item 3c.  The earlier blanket bounds were 3e-2 / 0.15.
+BF16_LOGITS_REL = 1.0e-2            # measured 4.8e-3 (170 k), 5.1e-3 (2.45 M)
+BF16_LOSS_REL = 2.0e-5              # measured 1.8e-6 .. 3.0e-6
+BF16_GRAD_REL = {                   # measured (tiled, plain) per test in the report file
+    "fc.weight": 4.0e-3, "graph_conv.convs.2.W.weight": 9.0e-2, "graph_conv.convs.0.W.weight": 1.7e-1,
+    "graph_conv.fcs.0.weight": 9.5e-2, "trans_conv.fcs.0.weight": 5.2e-2, "trans_conv.convs.0.Wv.weight": 4.2e-3,
+}
+
+
+BF16_GRAD_REL_POWERLAW = {"fc.weight": 4.8e-3, "graph_conv.convs.2.W.weight": 9.1e-2, "graph_conv.fcs.0.weight": 9.7e-2,
+                          "trans_conv.fcs.0.weight": 5.3e-2}
+BF16_GRAD_REL_100M = {"fc.weight": 4.0e-3, "graph_conv.convs.2.W.weight": 9.7e-2, "graph_conv.fcs.0.weight": 1.17e-1,
+                      "trans_conv.fcs.0.weight": 6.8e-2}
+
+
+def _check_bf16(report, e_t, e_p, loss_t, loss_ref, logits_rel=BF16_LOGITS_REL, grad_rel=None):
+    grad_rel = grad_rel or BF16_GRAD_REL
+    assert e_t <= logits_rel and e_t <= 2.0 * e_p + 1e-3, report
+    assert abs(loss_t - loss_ref) <= BF16_LOSS_REL * abs(loss_ref), report
     for name, (r_t, r_p) in ((n_, v) for n_, v in report.items() if n_.startswith("grad/")):
-        assert r_t <= 0.15 and r_t <= 2.0 * r_p + 2e-2, (name, report)
+        assert r_t <= grad_rel[name[5:]] and r_t <= 2.0 * r_p + 2e-2, (name, report)
 
 
 def _report(tag, report):
@@ -293,5 +308,5 @@ def test_products_recipe_at_full_size_bf16(cuda, graph):
     _report("products-2.45M bf16 full size:", report)
     assert report["finite"]
     assert (view.perm is not None) == (graph == "community"), report
-    assert rel <= 2e-2 and worst <= 0.25 * scale, report
-    assert abs(loss - loss_ref) <= 2e-2 * abs(loss_ref), report
+    assert rel <= BF16_LOGITS_REL and worst <= 6e-3 * scale, report     # measured 5.06e-3 and 0.0147 / 5.09 = 2.9e-3
+    assert abs(loss - loss_ref) <= BF16_LOSS_REL * abs(loss_ref), report   # measured 2.5e-6 / 3.0e-6

@@ -429,6 +429,42 @@ def _enter_dryrun():
     SpmmTimer.uninstall = lambda self: None
 
 
+SHARE_GPU = os.environ.get("SGF_BENCH_SHARE_GPU") == "1"
+
+
+def _enter_shared_gpu():
+    """SGF_BENCH_SHARE_GPU=1 (validation on a 1-GPU box; never a measurement): the N ranks of the driver's launch line all
+    run on cuda:0 — the node-sharded step with the REAL kernels of libsgf.so (own-column tile / stream SpMM, halo placement,
+    sgf_gather_rows packing, SyncBN statistics, fused Adam) and the real step sequence — while the transport is gloo with the
+    collective's tensors staged through the host (RCCL refuses two ranks on one device).  The printed line is marked
+    `shared_gpu`; its loss must equal the one-rank run's."""
+    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "all_to_all_single", "all_gather_into_tensor")}
+
+    class _Done:
+        def wait(self, *a, **k):
+            return True
+
+        def is_completed(self):
+            return True
+
+    def staged(name, outs, ins):
+        def call(*args, async_op=False, **kw):
+            args = list(args)
+            dev_t = {i: args[i] for i in set(outs) | set(ins) if i < len(args) and torch.is_tensor(args[i]) and args[i].is_cuda}
+            for i, t in dev_t.items():
+                args[i] = t.cpu() if i in ins else torch.empty(t.shape, dtype=t.dtype)
+            real[name](*args, **kw)
+            for i, t in dev_t.items():
+                if i in outs:
+                    t.copy_(args[i])
+            return _Done() if async_op else None
+        return call
+    dist.all_reduce = staged("all_reduce", outs=(0,), ins=(0,))
+    dist.broadcast = staged("broadcast", outs=(0,), ins=(0,))
+    dist.all_to_all_single = staged("all_to_all_single", outs=(0,), ins=(1,))
+    dist.all_gather_into_tensor = staged("all_gather_into_tensor", outs=(0,), ins=(1,))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -446,6 +482,9 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback by design)")
+        if SHARE_GPU:
+            local_rank = 0
+            _enter_shared_gpu()
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
 
@@ -455,7 +494,7 @@ def main():
 
     if _sharded(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if DRYRUN:
+        if DRYRUN or SHARE_GPU:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -507,7 +546,9 @@ def main():
                        "graph_view": r["view"],
                        "prepare_graph_s": None if r["prepare_s"] is None else round(r["prepare_s"], 3),
                        "exchanged": r["exchanged"],
-                       "debug_override": bool(args.nodes), **({"dry_run": True} if DRYRUN else {})},
+                       "debug_override": bool(args.nodes), **({"dry_run": True} if DRYRUN else {}),
+                       **({"shared_gpu": "validation only: all ranks on cuda:0, gloo transport staged through the host"}
+                          if SHARE_GPU else {})},
             "loss": r["loss"],
             "peak_mem_GB": r["peak_mem"],
             "roofline": r["roof"],

@@ -27,12 +27,34 @@ def main():
     ap.add_argument("--batch", type=int, default=1000)
     ap.add_argument("--batches", type=int, default=30)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
+    ap.add_argument("--scale", default="shard8", choices=["shard8", "papers100M"],
+                    help="papers100M: the WHOLE graph's size on one GPU — 111 059 956 nodes, 1 615 685 872 stored entries with a "
+                         "heavy-tailed in-degree (hubs of ~1e5 entries), features in bf16 (28 GB), everything generated on the device")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n, deg, f, c, d = synth.SHAPES["papers100M-shard8"]
     n = a.nodes or n
-    ei = synth.synthetic_graph(n, deg, seed=123, device=dev)
-    x, y, _ = synth.synthetic_task(n, f, c, seed=123, device=dev)
+    t_gen = time.perf_counter()
+    if a.scale == "papers100M":
+        n = a.nodes or 111_059_956
+        m = int(1_615_685_872 * (n / 111_059_956))
+        g = torch.Generator(device=dev).manual_seed(123)
+        src = torch.randint(0, n, (m,), device=dev, generator=g)
+        # targets ~ n * u^2: in-degree density 1 / (2 sqrt(v / n)) — node 0 collects ~ m / sqrt(n) entries
+        dst = (torch.rand(m, device=dev, generator=g, dtype=torch.float64).square_() * n).long().clamp_(max=n - 1)
+        key = torch.unique(dst * n + src)                # coalesce (sorted by target): stored entries are distinct
+        del src, dst
+        ei = torch.stack([key % n, key // n])            # [source, target]
+        del key
+        x = torch.empty((n, f), dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, device=dev)
+        for lo in range(0, n, 1 << 22):
+            x[lo:lo + (1 << 22)] = torch.randn((min(1 << 22, n - lo), f), device=dev, generator=g).to(x.dtype)
+        y = torch.randint(0, c, (n,), device=dev, generator=g)
+    else:
+        ei = synth.synthetic_graph(n, deg, seed=123, device=dev)
+        x, y, _ = synth.synthetic_task(n, f, c, seed=123, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
 
     class Data:
         pass
@@ -77,9 +99,19 @@ def main():
 
     run(True, True)                                   # warm-up (graph cache, allocator)
     ms_sample, nn_, ne_ = run(False, False)
+    reads = loader.sampler.host_reads
+    run(False, False)
+    reads = (loader.sampler.host_reads - reads) / len(loader)
+    fan_dev, loader.sampler._fan_dev = loader.sampler._fan_dev, None       # the hop-by-hop path (two host reads per hop)
+    ms_sample_hops, _, _ = run(False, False)
+    loader.sampler._fan_dev = fan_dev
     ms_gather, _, _ = run(False, True)
     ms_step, _, _ = run(True, True)
-    print(json.dumps({"graph": f"uniform random, {n} nodes, {loader.sampler.colind.numel()} stored entries",
+    kind = "uniform random" if a.scale == "shard8" else "heavy-tailed in-degree (targets ~ n u^2), max in-degree " + \
+        str(loader.sampler.max_deg)
+    print(json.dumps({"graph": f"{kind}, {n} nodes, {loader.sampler.colind.numel()} stored entries",
+                      "generate_s": round(t_gen, 2), "host_reads_per_batch": reads,
+                      "ms_per_batch_sampling_hop_by_hop": round(ms_sample_hops, 3),
                       "fanouts": [15, 10, 5], "seeds_per_batch": a.batch, "dtype": a.dtype,
                       "sampler_build_s": round(t_build, 2), "nodes_per_batch": round(nn_), "edges_per_batch": round(ne_),
                       "ms_per_batch_sampling": round(ms_sample, 3), "ms_per_batch_sampling_plus_gather": round(ms_gather, 3),

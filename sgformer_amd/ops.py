@@ -1480,7 +1480,7 @@ def _attn_h_small_packed(Gt, Wqk, Wv, n_total: float, sum_v: bool = False):
     D = Gt.shape[0] - 1
     PG = Wqk @ Gt                                        # [2 d, D + 1]
     ssq = (PG * Wqk).view(2, -1).sum(1)                  # ||Q||^2, ||K||^2
-    c = torch.rsqrt(ssq.prod())
+    c = torch.rsqrt(ssq[0] * ssq[1])                     # (not ssq.prod(): its backward looks for zeros on the HOST)
     PK = PG[d:]
     SZ = torch.cat([PK @ Wv.t(), PK[:, D:]], 1)          # [s0 | z0]   [d, d + 1]
     U = (Wqk[:d].t() @ SZ) * c                           # rows :D = wq^T [s0 | z0], row D = bq [s0 | z0]

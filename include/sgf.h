@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 300 /* 0.3.0: sgf_spmm_tile_*, sgf_neighbor_sample_* */
+#define SGF_VERSION 400 /* 0.4.0: sgf_gcn_epilogue_cat / _dx2, sgf_gram2, sgf_gram_bn_bwd / _ln_bwd, sgf_bn_bwd_stats2, sgf_bn_finalize, sgf_gcn_bn_bwd_dx, sgf_neighbor_sample_batch, sgf_reload_env */
 
 #define SGF_F32 0
 #define SGF_BF16 1

@@ -37,6 +37,11 @@ def main(path: str, elem: int):
                 return (float(r["TotalDurationNs"]) / 1e3 - 12.0 * calls) / calls, calls
         return None, 0
 
+    # r04 on: the GCN layer's forward is ONE two-operand pass (k_rowgemm2_bf16), its input gradients one PAIRED launch, its
+    # dW one paired Gram; the stems' backward forms dz / dl inside the Gram (modes 5, 6).  Calls per step change the mix.
+    r04 = find("k_rowgemm2_bf16<")[0] is not None
+    XF = N * 100 * elem / 1e9                    # the [N, 100] feature matrix
+    GC = N * 48 * elem / 1e9                     # the logits' gradient, padded to 48 columns
     csr = (NNZ * 8 + (N + 1) * 8) / 1e9
     gather = (NNZ * (8 + D * elem) + (N + 1) * 8) / 1e9 + T     # every stored entry fetches one X row
     spmm_name = "k_spmm_row<" if find("k_spmm_row<" + tname)[0] else "k_spmm_wave<"
@@ -45,7 +50,14 @@ def main(path: str, elem: int):
         (spmm_name.rstrip("<"), (spmm_name + tname,), csr + 2 * T,
          "gather-bound: {:.1f} GB of {}-B row fetches per launch = {:.1f} TB/s".format(
              gather, D * elem, gather / (spmm_us * 1e-6) / 1e3) if spmm_us else "", find),
-        ("k_reduce_bf16<256,Gram,16>  (sgf_gram: G, dW)", ("k_reduce_bf16<256, 2, 16>",), 2 * T, "reads 2 tensors", find),
+        ("k_reduce_bf16<256,Gram,16>  (sgf_gram: G, dW)", ("k_reduce_bf16<256, 2, 16>",),
+         ((T + 2 * (T + GC) + 3 * 3 * T) / 6) if r04 else 2 * T,
+         "6 per step: G = h^T h (1T), the head's two dW (T + g each), three PAIRED dW of a GCN layer (dz, y, x0: 3T)" if r04
+         else "reads 2 tensors", find),
+        ("k_reduce_bf16<256,GramBN,8>  (sgf_gram_bn_bwd)", ("k_reduce_bf16<256, 5, 8>",), 3 * T + XF,
+         "GraphConv stem: g1, g2, z -> dz on the fly, x [N,100]: dW, db without a stored dz", find),
+        ("k_reduce_bf16<256,GramLN,8>  (sgf_gram_ln_bwd)", ("k_reduce_bf16<256, 6, 8>",), 2 * T + XF,
+         "TransConv stem: g, LayerNorm input -> its input gradient on the fly, x [N,100]: dW, db, dgamma, dbeta", find),
         ("k_reduce_bf16<256,BwdH,8>", ("k_reduce_bf16<256, 3, 8>",), 3 * T, "reads h, out, dout", find),
         ("k_reduce_bf16<256,BwdHS,8>  (sgf_attn_h_bwd_reduce_scaled)", ("k_reduce_bf16<256, 4, 8>",), 2 * T + N * 8 / 1e9,
          "reads h, dout and 8 B of row scalars per node", find),
@@ -59,7 +71,11 @@ def main(path: str, elem: int):
          "reads g, out; writes the partial and the row scalars", find),
         ("k_hrow_bf16<256,B2>  (sgf_attn_h_bwd_post)", ("k_hrow_bf16<256, 2>",), 4 * T,
          "reads h, the partial, the residual's gradient; writes dh", find),
-        ("k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx)", ("k_rowgemm_bf16<256, false, 0, 0>",), 2 * T, "dy -> dx", find),
+        ("k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx2, paired)" if r04 else "k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx)",
+         ("k_rowgemm_bf16<256, false, 0, 0>",), 3 * T if r04 else 2 * T,
+         "dz -> dy AND dx0 from one HBM read of dz (workgroups b, b + 8 share the tile in L2)" if r04 else "dy -> dx", find),
+        ("k_rowgemm2_bf16<256,2,stats>  (sgf_gcn_epilogue_cat)", ("k_rowgemm2_bf16<256, 2, true>",), 3 * T,
+         "[y | x0] W^T + b + BatchNorm sums in one pass (paired column halves); full-size launches only", find_full),
         ("k_rowgemm_bf16<256,IO 1>  (sgf_gcn_epilogue_partial)", ("k_rowgemm_bf16<256, false, 1, 0>",), 2 * T,
          "a1 -> partial; full-size launches only", find_full),
         ("k_rowgemm_bf16<256,stats,IO 2>  (sgf_gcn_epilogue_stats_add)", ("k_rowgemm_bf16<256, true, 2, 0>",), 3 * T,
@@ -72,12 +88,15 @@ def main(path: str, elem: int):
         ("k_attn_apply<float,256,HBwd2>", ("k_attn_apply<float, 256, 6>",), 3 * T, "MFMA-bound", find),
         ("k_ln_fwd", ("k_ln_fwd<" + tname,), 2.5 * T, "mean of stem (2T) and post-attention (3T) calls", find),
         ("k_ln_fwd_bf16x8", ("k_ln_fwd_bf16x8<",), 2.5 * T, "mean of stem (2T) and post-attention (3T) calls", find),
-        ("k_ln_bwd", ("k_ln_bwd<" + tname,), 4.5 * T, "mean of stem (4T) and post-attention (5T) calls", find),
+        ("k_ln_bwd", ("k_ln_bwd<" + tname,), 5 * T if r04 else 4.5 * T,
+         "post-attention only (g, y, x, res in; one shared dx out)" if r04 else "mean of stem (4T) and post-attention (5T) calls", find),
         ("k_bn_apply", ("k_bn_apply<" + tname,), 2.75 * T, "stem 2T, layers 3T (residual)", find),
-        ("k_colreduce<BnBwdStats>", ("BnBwdStatsF<" + tname,), 2 * T, "", find),
+        ("k_colreduce<BnBwdStats>", ("BnBwdStatsF<" + tname,), 2.25 * T if r04 else 2 * T,
+         "three layers (g, z) and the stem (g1, g2, z)" if r04 else "", find),
         ("k_bn_bwd_apply", ("k_bn_bwd_apply<" + tname,), 3 * T, "", find),
         ("k_sum_n (7 operands)", ("k_sum_n<" + tname,), 8 * T, "fan-out hub gradient", find),
         ("k_sum_n_bf16x8<7>", ("k_sum_n_bf16x8<7>",), 8 * T, "fan-out hub gradient", find),
+        ("k_sum_n_bf16x8<6>", ("k_sum_n_bf16x8<6>",), 7 * T, "x0's gradient: three dz W2 and three residual gradients", find),
         ("k_head_fwd_bf16  (sgf_combine_fc_fwd)", ("k_head_fwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "x1, x2 -> logits", find),
         ("k_head_bwd_bf16  (sgf_combine_fc_bwd)", ("k_head_bwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "dlogits -> dx1, dx2", find),
         ("k_axpby", ("k_axpby<" + tname,), 3 * T, "", find),

@@ -1929,6 +1929,13 @@ def combine_fc(x1, x2, w, bias, a: float, b: float) -> torch.Tensor:
 
 
 def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:
+    import os
+    if x.dim() == 2 and x.dtype == _BF16 and classes > 64 and os.environ.get("SGF_HEAD_WIDE", "0") != "1":
+        # bf16 storage with more than 64 classes: sgf_combine_fc_* would run on the exact-fp32 matrix cores (157 TF, padded
+        # to 256 x 256) and is compute-bound there — measured on the 100M recipe (d = 128, C = 172, N = 13.9 M): 18.5 + 16.3 ms
+        # per step against ~12 ms for sgf_axpby + the bf16 streaming Linear, 251.9 vs 234.6 ms per step.  The logits
+        # (N x C fp32) dominate that head's traffic either way; the one-kernel form stays available (SGF_HEAD_WIDE=1).
+        return False
     return x.dim() == 2 and K.combine_fc_supported(x.shape[1], classes, x.dtype)
 
 

@@ -678,9 +678,6 @@ def test_combine_fc_fused_fp32(cuda, n, d, c):
     b = torch.randn(c, generator=g) * 0.1
     go = torch.randn(n, c, generator=g)
     gw = 0.8
-    # the module's policy keeps this shape on sgf_axpby + the bf16 Linear (faster: DESIGN §3.5); the one-kernel form is opt-in
-    assert not ops.combine_fc_supported(x1.to(cuda), c)
-    monkeypatch.setenv("SGF_HEAD_WIDE", "1")
     assert ops.combine_fc_supported(x1.to(cuda), c)
     x1g, x2g = x1.to(cuda).requires_grad_(True), x2.to(cuda).requires_grad_(True)
     wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
@@ -709,6 +706,9 @@ def test_combine_fc_fused_bf16_many_classes(cuda, monkeypatch, n, d, c):
     b = torch.randn(c, generator=g) * 0.1
     go = torch.randn(n, c, generator=g)
     gw = 0.8
+    # the module's policy keeps this shape on sgf_axpby + the bf16 Linear (faster: DESIGN §3.5); the one-kernel form is opt-in
+    assert not ops.combine_fc_supported(x1.to(cuda), c)
+    monkeypatch.setenv("SGF_HEAD_WIDE", "1")
     assert ops.combine_fc_supported(x1.to(cuda), c)
     x1g, x2g = x1.to(cuda).requires_grad_(True), x2.to(cuda).requires_grad_(True)
     wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)

@@ -536,7 +536,8 @@ def main():
                                    f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout 0"
                                    + (f"; {n // world:,} nodes per rank, rows generated per rank" if weak else ""),
                        "loss": {"trainer": "the trainer's own lines (large/main.py:139-141: log_softmax, row indexing, "
-                                           "nn.NLLLoss) as they run under sgformer_amd.launch",
+                                           "nn.NLLLoss) as they run under sgformer_amd.launch (launch.patch_nll_loss: F.log_softmax returns a lazy "
+                                           "tensor, indexing + NLLLoss run as one pass over the training rows)",
                                 "fused": "sgformer_amd.loss.log_softmax_nll (same arithmetic, one pass)",
                                 "aten": "F.log_softmax + F.nll_loss on ATen's kernels"}[r["loss_mode"]],
                        "ms_per_step_with_aten_loss": None if r["ms_aten"] is None else round(r["ms_aten"], 3),

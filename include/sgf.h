@@ -715,7 +715,8 @@ int sgf_dropout(const void* x, int64_t ldx, const void* res, int64_t ldr, float 
  *                   dlogits = gout[0] * inv_denom * (softmax(logits[row]) - onehot(label))
  * logits / dlogits: [n, c] storage dtype with leading dims ldl / ldd; labels int64 [n] (indexed by
  * NODE id); idx int64 [m] distinct rows; gout fp32 [1] on the device.  Labels outside [0, c) add
- * nothing to the loss.  Deterministic (per-block partials, fixed-order sum).
+ * nothing to the loss and get a zero gradient row (nn.NLLLoss's ignore_index).  Deterministic (per-block
+ * partials, fixed-order sum).
  * ------------------------------------------------------------------------------------------ */
 size_t sgf_nll_workspace_bytes(int64_t m);
 int sgf_nll_fwd(const void* logits, int64_t ldl, int64_t n, int32_t c, int32_t dtype,

@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = DP == 64 ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: `act` below is a scalar branch)
   const int head = blockIdx.y;
   const int i31 = lane & 31;
   const int hi = lane >> 5;
@@ -915,6 +915,9 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
   __syncthreads();
   const int ca0 = 64 * wm + i31, ca1 = ca0 + 32;
   const int cb0 = BN * wd + i31;
+  // a wave whose 64 x BN result block lies outside the m x k product (narrow operands: the head's dW with m = 48, the stems'
+  // with k = 100) multiplies zeros: it only stages.  Wave-uniform, so the whole MFMA phase and its LDS reads are skipped.
+  const bool act = DP == 64 || (64 * wm < p.d && BN * wd < p.db);     // (one block at DP = 64: always inside)
   for (; tile < ntiles; tile += vgrid) {
     const int64_t next = tile + vgrid;
     const bool has_next = next < ntiles;
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
     for (int t = 0; t < NPASS; ++t) {
       if (has_next) issue(next, t);
 #pragma unroll 1
-      for (int s = t * (SPG / NPASS); s < (t + 1) * (SPG / NPASS); ++s) {
+      for (int s = t * (SPG / NPASS); act && s < (t + 1) * (SPG / NPASS); ++s) {
         const int chunk = 2 * (grp + RG * s) + hi;
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ta + ca0 * CSB + ((chunk ^ swz(ca0)) << 4));
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ta + ca1 * CSB + ((chunk ^ swz(ca1)) << 4));
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(NW * 64) void k_reduce_bf16(ReduceArgs p) {
 
   // ---- this block's partial, same layout as k_attn_reduce: [grp][m][dd] | colsum[DP] | ssq ----
   float* part = p.partial + ((static_cast<int64_t>(head) + role) * vgrid + vblock) * kPartialStride;
+  if (act)                      // (the finalize kernels read the m x k part only)
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll

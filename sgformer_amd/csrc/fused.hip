@@ -851,7 +851,9 @@ __global__ __launch_bounds__(kThreads) void k_nll_bwd16(const T* __restrict__ lo
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = sub + 16 * e;
-        if (k < c) store1<T>(dlogits + r * ldd + k, scale * (expf(v[e] - lse) - ((k == y) ? 1.f : 0.f)));
+        // a label outside [0, c) (nn.NLLLoss's ignore_index, an unlabeled node) adds nothing to the loss: zero gradient
+        if (k < c) store1<T>(dlogits + r * ldd + k,
+                             (y >= 0 && y < c) ? scale * (expf(v[e] - lse) - ((k == y) ? 1.f : 0.f)) : 0.f);
       }
     }
   }
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(kThreads) void k_nll_bwd(const T* __restrict__ logi
     const int64_t y = labels[r];
     for (int k = lane; k < c; k += 64) {
       const float p = expf(load1<T>(row + k) - lse);
-      store1<T>(dlogits + r * ldd + k, scale * (p - ((k == y) ? 1.f : 0.f)));
+      store1<T>(dlogits + r * ldd + k, (y >= 0 && y < c) ? scale * (p - ((k == y) ? 1.f : 0.f)) : 0.f);
     }
   }
 }

@@ -167,10 +167,33 @@ def patch_nll_loss():
     no class weights, reduction 'mean'); anything else reaches the original.  `--sgf-aten-loss 1` keeps ATen's."""
     import torch
     import torch.nn.functional as F
-    from .loss import gather_nll
+    from . import ops
+    from .loss import LazyLogSoftmax, gather_nll, lazy_rows_nll
     orig = getattr(F.nll_loss, "_sgf_orig", F.nll_loss)
+    orig_ls = getattr(F.log_softmax, "_sgf_orig", F.log_softmax)
+    lazy_on = os.environ.get("SGF_LAZY_LOG_SOFTMAX", "1") != "0"
+
+    def on_device(t):                       # (the tests drive this with the CPU kernel table)
+        return t.is_cuda if ops.K.name == "hip" else True
+
+    def log_softmax(input, dim=None, _stacklevel=3, dtype=None):
+        # r04: the FIRST of the three lines returns a lazy tensor; `out[train_idx]` + nn.NLLLoss then run as ONE pass over
+        # the training rows (sgf_nll_fwd / _bwd) instead of log_softmax over all N rows, an index kernel and their backward
+        # (1.6 -> 0.3 ms per ogbn-products step); any other use of the result computes the real log-softmax first
+        if (lazy_on and torch.is_tensor(input) and not isinstance(input, LazyLogSoftmax) and input.dim() == 2
+                and dim in (1, -1) and dtype is None and input.dtype in (torch.float32, torch.bfloat16) and on_device(input)
+                and input.shape[0] > 0 and input.shape[1] <= 64 and input.stride(1) == 1):
+            return LazyLogSoftmax(input, None, orig_ls)
+        return orig_ls(input, dim=dim, _stacklevel=_stacklevel, dtype=dtype)
 
     def nll_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean"):
+        if isinstance(input, LazyLogSoftmax):
+            if (input._sgf_idx is not None and input._sgf_cache is None and torch.is_tensor(target) and target.dim() == 1
+                    and target.dtype == torch.long and target.shape[0] == input.shape[0] and weight is None
+                    and size_average is None and reduce is None and reduction == "mean" and ignore_index < 0
+                    and target.device == input.device):
+                return lazy_rows_nll(input, target, ignore_index)
+            input = input._sgf_value()
         if (torch.is_tensor(input) and torch.is_tensor(target) and input.is_cuda and input.dim() == 2 and target.dim() == 1
                 and input.shape[0] == target.shape[0] and input.shape[0] > 0 and weight is None and size_average is None
                 and reduce is None and reduction == "mean" and input.is_floating_point() and target.dtype == torch.long):
@@ -180,6 +203,8 @@ def patch_nll_loss():
 
     nll_loss._sgf_orig = orig
     F.nll_loss = nll_loss
+    log_softmax._sgf_orig = orig_ls
+    F.log_softmax = log_softmax
     return orig
 
 
@@ -210,6 +235,9 @@ def unpatch_nll_loss():
     orig = getattr(F.nll_loss, "_sgf_orig", None)
     if orig is not None:
         F.nll_loss = orig
+    orig_ls = getattr(F.log_softmax, "_sgf_orig", None)
+    if orig_ls is not None:
+        F.log_softmax = orig_ls
 
 
 def limit_host_threads():

@@ -30,3 +30,69 @@ def gather_nll(input, target, ignore_index=-100):
     picked = input.gather(1, safe.unsqueeze(1)).squeeze(1)
     w = valid.to(picked.dtype)
     return -(picked * w).sum() / w.sum()
+
+
+# ------------------------------------------------------------------------------------------------
+# The trainers' three loss lines AS WRITTEN on the one-pass kernels (installed by sgformer_amd.launch)
+#     out = F.log_softmax(out, dim=1)
+#     loss = criterion(out[train_idx], label.squeeze(1)[train_idx])          # criterion = nn.NLLLoss()
+# F.log_softmax returns a LAZY tensor; indexing it with a 1-D index tensor gives lazy rows; F.nll_loss on lazy rows runs
+# sgf_nll_fwd / sgf_nll_bwd on the logits.  Every OTHER use of either object computes the real log-softmax first (ATen) and
+# goes on with an ordinary tensor — results are the reference's in every case, only the common case is one pass.
+# ------------------------------------------------------------------------------------------------
+import torch as _torch
+
+
+def _materialise(x):
+    if isinstance(x, LazyLogSoftmax):
+        return x._sgf_value()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_materialise(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _materialise(v) for k, v in x.items()}
+    return x
+
+
+class LazyLogSoftmax(_torch.Tensor):
+    """log_softmax(logits, dim=1) that has not been computed yet (or the rows `idx` of it)."""
+
+    @staticmethod
+    def __new__(cls, logits, idx=None, orig=None):
+        shape = logits.shape if idx is None else (idx.shape[0], logits.shape[1])
+        r = _torch.Tensor._make_wrapper_subclass(cls, shape, dtype=logits.dtype, device=logits.device,
+                                                 requires_grad=False)
+        r._sgf_logits, r._sgf_idx, r._sgf_orig, r._sgf_cache = logits, idx, orig, None
+        return r
+
+    def _sgf_value(self):
+        if self._sgf_cache is None:
+            full = (self._sgf_orig or _torch.nn.functional.log_softmax)(self._sgf_logits, dim=1)
+            self._sgf_cache = full if self._sgf_idx is None else full[self._sgf_idx]
+        return self._sgf_cache
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if (func is _torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], LazyLogSoftmax)
+                and args[0]._sgf_idx is None and args[0]._sgf_cache is None and _torch.is_tensor(args[1])
+                and not isinstance(args[1], LazyLogSoftmax) and args[1].dim() == 1 and args[1].dtype == _torch.long
+                and args[1].device == args[0]._sgf_logits.device):
+            return LazyLogSoftmax(args[0]._sgf_logits, args[1], args[0]._sgf_orig)
+        with _torch._C.DisableTorchFunctionSubclass():
+            return func(*_materialise(args), **_materialise(kwargs))
+
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):        # (whatever reaches the dispatcher: real values)
+        return func(*_materialise(args), **_materialise(kwargs or {}))
+
+
+def lazy_rows_nll(rows: "LazyLogSoftmax", target, ignore_index=-100):
+    """F.nll_loss(rows, target) (mean over the targets != ignore_index) for lazy rows: one pass over the logits' rows
+    `idx` (sgf_nll_fwd), gradient written for all N rows (sgf_nll_bwd).  The divisor stays on the device."""
+    logits, idx = rows._sgf_logits, rows._sgf_idx
+    n = logits.shape[0]
+    labels = _torch.full((n,), -1, dtype=_torch.long, device=logits.device)
+    labels[idx] = target                    # the kernels index labels by NODE id; ignore_index (< 0) adds nothing there
+    denom = (target != ignore_index).sum().clamp_(min=1).to(_torch.float32)
+    return ops.nll_loss_rows(logits, labels, idx, 1.0) / denom

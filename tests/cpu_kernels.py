@@ -228,14 +228,18 @@ class CpuKernels:
     @staticmethod
     def nll_fwd(logits, labels, idx):
         lp = torch.log_softmax(logits.float(), dim=1)
-        return -lp[idx, labels[idx]].sum().reshape(1)
+        lab = labels[idx]
+        ok = (lab >= 0) & (lab < logits.shape[1])            # include/sgf.h: labels outside [0, c) add nothing
+        return -(lp[idx, lab.clamp(0, logits.shape[1] - 1)] * ok).sum().reshape(1)
 
     @staticmethod
     def nll_bwd(logits, labels, idx, gout, inv_denom):
         d = torch.zeros_like(logits, dtype=torch.float32)
         p = torch.softmax(logits.float()[idx], dim=1)
-        p[torch.arange(idx.numel()), labels[idx]] -= 1.0
-        d[idx] = p * (gout[0] * inv_denom)
+        lab = labels[idx]
+        ok = (lab >= 0) & (lab < logits.shape[1])
+        p[torch.arange(idx.numel()), lab.clamp(0, logits.shape[1] - 1)] -= 1.0
+        d[idx] = p * ok[:, None] * (gout[0] * inv_denom)
         return d.to(logits.dtype)
 
     @staticmethod

@@ -1397,3 +1397,42 @@ def test_attn_h_bwd_post_addend(cuda):
     plain = K.attn_h_bwd_post(h, D, ds)
     folded = K.attn_h_bwd_post(h, D, ds, extra)
     assert torch.equal(folded, (plain.float() + extra.float()).bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainer_loss_lines_in_one_pass(cuda, dtype):
+    """large/main.py:139-141 as written, under the launcher's patches, on the device: F.log_softmax -> lazy tensor,
+    `out[train_idx]` -> lazy rows, nn.NLLLoss() -> sgf_nll_fwd / sgf_nll_bwd on the logits.  Against ATen's three lines on the
+    same logits in fp32: loss 1e-6, gradient 1e-6 (bf16 logits: one bf16 rounding of the gradient); rows whose target is
+    ignore_index leave the mean and get a ZERO gradient row."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from sgformer_amd import launch, ops
+    from sgformer_amd.loss import LazyLogSoftmax
+    g = torch.Generator().manual_seed(11)
+    n, c = 50_000, 47
+    logits = (torch.randn(n, c, generator=g) * 2).to(dtype).to(cuda).requires_grad_(True)
+    label = torch.randint(0, c, (n, 1), generator=g).to(cuda)
+    idx = torch.randperm(n, generator=g)[:20_000].to(cuda)
+    tgt = label.squeeze(1)[idx].clone()
+    tgt[::7] = -100
+    ref_in = logits.detach().float().requires_grad_(True)
+    ref = F.nll_loss(F.log_softmax(ref_in, dim=1)[idx], tgt)
+    g_ref, = torch.autograd.grad(ref, ref_in)
+    launch.patch_nll_loss()
+    try:
+        calls = []
+        real = ops.K.nll_fwd
+        ops.K.nll_fwd = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        out = F.log_softmax(logits, dim=1)
+        loss = nn.NLLLoss()(out[idx], tgt)
+        assert isinstance(out, LazyLogSoftmax) and calls == [1]
+        g_got, = torch.autograd.grad(loss, logits)
+    finally:
+        ops.K.nll_fwd = real
+        launch.unpatch_nll_loss()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((g_got.float() - g_ref).abs().max()) <= tol * float(g_ref.abs().max())
+    ignored = idx[::7]
+    assert float(g_got[ignored].abs().max()) == 0.0

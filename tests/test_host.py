@@ -658,6 +658,71 @@ def test_launcher_nll_patch_installs_and_restores():
     assert F.nll_loss is before
 
 
+def test_launcher_runs_the_trainers_three_loss_lines_in_one_pass():
+    """large/main.py:139-141 AS WRITTEN under the launcher's patches: F.log_softmax returns a lazy tensor, `out[train_idx]`
+    lazy rows, nn.NLLLoss() on them runs sgf_nll_fwd / sgf_nll_bwd (here: the CPU kernel table) — value and gradient equal
+    ATen's three lines; every other use of the lazy objects (argmax, arithmetic, slices, boolean masks, a second index,
+    class weights, reduction='sum', ignore_index rows) gives exactly what the un-patched functions give."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from sgformer_amd import launch, ops
+    from sgformer_amd.loss import LazyLogSoftmax
+    from tests.cpu_kernels import CpuKernels
+    prev = ops.set_kernels(CpuKernels())
+    ls0, nll0 = F.log_softmax, F.nll_loss
+    g = torch.Generator().manual_seed(0)
+    n, c = 500, 7
+    logits = torch.randn(n, c, generator=g, requires_grad=True)
+    label = torch.randint(0, c, (n, 1), generator=g)
+    idx = torch.randperm(n, generator=g)[:200]
+    ref = nll0(ls0(logits, dim=1)[idx], label.squeeze(1)[idx])
+    g_ref, = torch.autograd.grad(ref, logits)
+    launch.patch_nll_loss()
+    try:
+        calls = []
+        real = ops.K.nll_fwd
+        ops.K.nll_fwd = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        criterion = nn.NLLLoss()
+        out = F.log_softmax(logits, dim=1)                       # the trainer's three lines
+        loss = criterion(out[idx], label.squeeze(1)[idx])
+        assert isinstance(out, LazyLogSoftmax) and out.shape == (n, c) and out.dtype == logits.dtype
+        assert calls == [1] and not isinstance(loss, LazyLogSoftmax)
+        g_got, = torch.autograd.grad(loss, logits)
+        assert abs(float(loss) - float(ref)) <= 1e-6 and float((g_got - g_ref).abs().max()) <= 1e-7
+        # rows whose target is ignore_index leave numerator and divisor
+        t2 = label.squeeze(1)[idx].clone()
+        t2[::3] = -100
+        got = criterion(F.log_softmax(logits, dim=1)[idx], t2)
+        assert abs(float(got) - float(nll0(ls0(logits, dim=1)[idx], t2))) <= 1e-6 and len(calls) == 2
+        # everything else falls back to the real values
+        out = F.log_softmax(logits, dim=1)
+        full = ls0(logits, dim=1)
+        assert torch.equal(out.argmax(1), full.argmax(1)) and len(calls) == 2
+        assert torch.allclose((F.log_softmax(logits, dim=1) * 2.0 + 1.0).detach(), (full * 2.0 + 1.0).detach())
+        assert torch.equal(F.log_softmax(logits, dim=1)[3:9].detach(), full[3:9].detach())
+        mask = torch.zeros(n, dtype=torch.bool)
+        mask[idx] = True
+        assert torch.equal(F.log_softmax(logits, dim=1)[mask].detach(), full[mask].detach())
+        rows = F.log_softmax(logits, dim=1)[idx]
+        assert torch.equal(rows[:5].detach(), full[idx][:5].detach())                       # a second index: real rows
+        w = torch.rand(c, generator=g)
+        assert torch.allclose(F.nll_loss(F.log_softmax(logits, dim=1)[idx], label.squeeze(1)[idx], weight=w),
+                              nll0(full[idx], label.squeeze(1)[idx], weight=w))
+        assert torch.allclose(F.nll_loss(F.log_softmax(logits, dim=1)[idx], label.squeeze(1)[idx], reduction="sum"),
+                              nll0(full[idx], label.squeeze(1)[idx], reduction="sum"))
+        assert len(calls) == 2
+        lg, = torch.autograd.grad(F.log_softmax(logits, dim=1).sum(), logits)                # autograd through the fallback
+        lr, = torch.autograd.grad(full.sum(), logits)
+        assert torch.allclose(lg, lr)
+        assert not isinstance(F.log_softmax(logits, dim=0), LazyLogSoftmax)                  # other dims: ATen
+        assert not isinstance(F.log_softmax(torch.randn(4, 100), dim=1), LazyLogSoftmax)     # more than 64 classes: ATen
+    finally:
+        ops.K.nll_fwd = real
+        launch.unpatch_nll_loss()
+        ops.set_kernels(prev)
+    assert F.log_softmax is ls0 and F.nll_loss is nll0
+
+
 @pytest.mark.parametrize("sum_v", [False, True])
 @pytest.mark.parametrize("d,d_in", [(8, 8), (16, 12)])
 def test_packed_attention_algebra_matches_the_term_by_term_form(sum_v, d, d_in):

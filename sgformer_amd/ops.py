@@ -1500,7 +1500,7 @@ def _attn_h_pack(G, s, n_rows: float, wq, bq, wk, bk, wv, bv):
     Gt[:D, :D] = G
     Gt[:D, D] = s
     Gt[D, :D] = s
-    Gt[D, D] = n_rows
+    Gt[D, D].fill_(n_rows)          # (NOT `= n_rows`: assigning a Python scalar is a host -> device copy that syncs the stream)
     Wqk = torch.cat([torch.cat([wq, wk], 0), torch.cat([bq, bk])[:, None]], 1)
     Wv = torch.cat([wv, bv[:, None]], 1)
     return Gt, Wqk, Wv

@@ -53,6 +53,20 @@ def _materialise(x):
     return x
 
 
+def _meta_funcs():
+    t = _torch.Tensor
+    out = {t.size, t.dim, t.numel, t.is_floating_point, t.stride, t.element_size, t.nelement, t.ndimension, t.is_contiguous}
+    for name in ("shape", "dtype", "device", "ndim", "is_cuda", "requires_grad", "layout", "is_sparse", "is_quantized",
+                 "is_meta", "names", "is_leaf"):
+        prop = getattr(t, name, None)
+        if prop is not None and hasattr(prop, "__get__"):
+            out.add(prop.__get__)
+    return out
+
+
+_META = _meta_funcs()
+
+
 class LazyLogSoftmax(_torch.Tensor):
     """log_softmax(logits, dim=1) that has not been computed yet (or the rows `idx` of it)."""
 
@@ -79,6 +93,8 @@ class LazyLogSoftmax(_torch.Tensor):
                 and args[1].device == args[0]._sgf_logits.device):
             return LazyLogSoftmax(args[0]._sgf_logits, args[1], args[0]._sgf_orig)
         with _torch._C.DisableTorchFunctionSubclass():
+            if func in _META:                  # shape / dtype / device ... live on the wrapper: nothing is computed for them
+                return func(*args, **kwargs)
             return func(*_materialise(args), **_materialise(kwargs))
 
 

@@ -1424,12 +1424,17 @@ def test_trainer_loss_lines_in_one_pass(cuda, dtype):
         calls = []
         real = ops.K.nll_fwd
         ops.K.nll_fwd = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        full = []
+        value = LazyLogSoftmax._sgf_value
+        LazyLogSoftmax._sgf_value = lambda self: (full.append(1), value(self))[1]
         out = F.log_softmax(logits, dim=1)
         loss = nn.NLLLoss()(out[idx], tgt)
-        assert isinstance(out, LazyLogSoftmax) and calls == [1]
+        assert isinstance(out, LazyLogSoftmax) and calls == [1] and out.shape == (n, c)
+        assert full == [], "the one-pass path must not compute the full log-softmax"
         g_got, = torch.autograd.grad(loss, logits)
     finally:
         ops.K.nll_fwd = real
+        LazyLogSoftmax._sgf_value = value
         launch.unpatch_nll_loss()
     assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
     tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8

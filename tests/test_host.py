@@ -679,14 +679,20 @@ def test_launcher_runs_the_trainers_three_loss_lines_in_one_pass():
     g_ref, = torch.autograd.grad(ref, logits)
     launch.patch_nll_loss()
     try:
-        calls = []
+        calls, real_ls = [], []
         real = ops.K.nll_fwd
         ops.K.nll_fwd = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        import sgformer_amd.loss as L
+        orig_value = L.LazyLogSoftmax._sgf_value
+        L.LazyLogSoftmax._sgf_value = lambda self: (real_ls.append(1), orig_value(self))[1]
         criterion = nn.NLLLoss()
         out = F.log_softmax(logits, dim=1)                       # the trainer's three lines
         loss = criterion(out[idx], label.squeeze(1)[idx])
         assert isinstance(out, LazyLogSoftmax) and out.shape == (n, c) and out.dtype == logits.dtype
+        assert out.device == logits.device and out.dim() == 2 and out.size(0) == n
         assert calls == [1] and not isinstance(loss, LazyLogSoftmax)
+        assert real_ls == [], "the one-pass path must not compute the full log-softmax"
+        L.LazyLogSoftmax._sgf_value = orig_value
         g_got, = torch.autograd.grad(loss, logits)
         assert abs(float(loss) - float(ref)) <= 1e-6 and float((g_got - g_ref).abs().max()) <= 1e-7
         # rows whose target is ignore_index leave numerator and divisor

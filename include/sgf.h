@@ -583,6 +583,17 @@ int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int
 int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
                        int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2,
                        int64_t ld2, void* stream);
+/* The same pair with the module's row permutation folded in (bf16 storage, classes <= 64): on a graph the library has
+ * re-ordered (sgf_reorder) the model works on permuted rows and its logits must go back to the caller's order
+ * (sgformer_amd/ours.py; large/ours.py:275 returns them in the order of x).  _fwd_mapped stores row j of the product as row
+ * row_map[j] of `logits`; _bwd_mapped reads row row_map[j] of `dlogits` for row j of dx1 / dx2.  row_map: int32[n], a
+ * permutation of [0, n).  Saves the two [N, C] fp32 gather passes around the head. */
+int sgf_combine_fc_fwd_mapped(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b, const float* w,
+                              const float* bias, int64_t n, int32_t d, int32_t classes, int32_t dtype, float* logits,
+                              int64_t ldl, const int32_t* row_map, void* stream);
+int sgf_combine_fc_bwd_mapped(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d, int32_t classes,
+                              float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2, int64_t ld2,
+                              const int32_t* row_map, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T6 / K8 — the dense half of a GCN layer as one streaming pass.   Replaces, for large/ours.py:36-40,87-88

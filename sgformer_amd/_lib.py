@@ -135,6 +135,10 @@ SIGNATURES = {
                                      c_int32, _P, c_int64, _P]),
     "sgf_combine_fc_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P,
                                      c_int64, _P, c_int64, _P]),
+    "sgf_combine_fc_fwd_mapped": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_int32, c_int32,
+                                     c_int32, _P, c_int64, _P, _P]),
+    "sgf_combine_fc_bwd_mapped": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P,
+                                     c_int64, _P, c_int64, _P, _P]),
     "sgf_gcn_epilogue_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "sgf_gcn_epilogue_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "sgf_gcn_epilogue_stats": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, _P, c_int64,

@@ -49,7 +49,7 @@ template <int DP>   // d rounded up to 64 / 128 / 256 (LDS pitch, k-steps)
 __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_bf16(
     const uint16_t* __restrict__ x1, int64_t ld1, float a, const uint16_t* __restrict__ x2, int64_t ld2, float b,
     const float* __restrict__ w, const float* __restrict__ bias, int64_t n, int d, int c,
-    float* __restrict__ logits, int64_t ldl) {
+    float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ rmap) {
   constexpr int PITCH = DP + 8;                    // bf16 elements per LDS row of W (+16 B)
   __shared__ __align__(16) uint16_t wl[kMaxClasses * PITCH];
   const int lane = threadIdx.x & 63;
@@ -113,12 +113,17 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd_bf16(
       }
     }
     // C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // rmap (nullable): row j of the product is row rmap[j] of `logits` — the module's un-permutation of a re-ordered graph
+    // done by the stores (lane i31 holds the target of tile row i31; the owner of a register's row is fetched by bpermute)
+    const int mrow = rmap ? rmap[row] : 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t orow = tile * 32 + mfma32_row(r, lane);
+      const int rl = mfma32_row(r, lane);
+      const int64_t orow = tile * 32 + rl;
+      const int64_t trow = rmap ? static_cast<int64_t>(__builtin_amdgcn_ds_bpermute(rl << 2, mrow)) : orow;
       if (orow < n) {
-        if (i31 < c) logits[orow * ldl + i31] = acc0[r] + bias0;
-        if (32 + i31 < c) logits[orow * ldl + 32 + i31] = acc1[r] + bias1;
+        if (i31 < c) logits[trow * ldl + i31] = acc0[r] + bias0;
+        if (32 + i31 < c) logits[trow * ldl + 32 + i31] = acc1[r] + bias1;
       }
     }
   }
@@ -134,7 +139,7 @@ constexpr int kHeadBwdThreads = 512;             // 8 waves, one 32-node tile ea
 template <int DP>
 __global__ __launch_bounds__(kHeadBwdThreads) void k_head_bwd_bf16(
     const float* __restrict__ dl, int64_t lddl, const float* __restrict__ w, int64_t n, int d, int c, float a, float b,
-    uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2) {
+    uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2, const int32_t* __restrict__ rmap) {
   constexpr int PITCH = kMaxClasses + 8;           // bf16 elements per LDS row of W^T (+16 B)
   constexpr int HW = DP >= 128 ? DP / 2 : DP;      // features per pass: the tile leaves in two column halves
   constexpr int NH = DP / HW;                      // passes
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(kHeadBwdThreads) void k_head_bwd_bf16(
   auto load_frags = [&](int64_t tile, Frag (&fa)[KSMAX]) {
     int64_t row = tile * 32 + i31;
     if (row >= n) row = n - 1;
+    if (rmap) row = rmap[row];                      // row j of the product reads row rmap[j] of dlogits
     const float* pg = dl + row * lddl;
 #pragma unroll
     for (int s = 0; s < KSMAX; ++s) {
@@ -280,34 +286,36 @@ extern "C" int32_t sgf_combine_fc_supported(int32_t d, int32_t classes, int32_t 
   return d % 32 == 0 && d <= 256 ? 1 : 0;
 }
 
-extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
-                                  const float* w, const float* bias, int64_t n, int32_t d, int32_t classes,
-                                  int32_t dtype, float* logits, int64_t ldl, void* stream) {
-  int rc = check_head("sgf_combine_fc_fwd", n, d, classes, dtype);
+static int combine_fc_fwd_impl(const char* fn, const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                               const float* w, const float* bias, int64_t n, int32_t d, int32_t classes, int32_t dtype,
+                               float* logits, int64_t ldl, const int32_t* rmap, void* stream) {
+  int rc = check_head(fn, n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
+  SGF_REQUIRE(!rmap || (dtype == SGF_BF16 && classes <= kMaxClasses), SGF_E_UNSUPPORTED,
+              "%s: a row map needs bf16 storage and at most %d classes", fn, kMaxClasses);
   if (dtype == SGF_F32) {
     SGF_REQUIRE(x1 && x2 && w && logits && ld1 >= d && ld2 >= d && ldl >= classes, SGF_E_INVALID,
-                "sgf_combine_fc_fwd: bad pointer / ld");
+                "%s: bad pointer / ld", fn);
     return linear_f32_dual(x1, ld1, x2, ld2, a, b, n, d, classes, w, d, 1, bias, logits, ldl, nullptr, 0, 1.f, 1.f, 0, 0,
                            static_cast<hipStream_t>(stream));
   }
   if (classes > kMaxClasses) {
     SGF_REQUIRE(x1 && x2 && w && logits && ld1 >= d && ld2 >= d && ldl >= classes, SGF_E_INVALID,
-                "sgf_combine_fc_fwd: bad pointer / ld");
+                "%s: bad pointer / ld", fn);
     return linear_f32_dual(x1, ld1, x2, ld2, a, b, n, d, classes, w, d, 1, bias, logits, ldl, nullptr, 0, 1.f, 1.f, 1, 0,
                            static_cast<hipStream_t>(stream));
   }
   SGF_REQUIRE(x1 && x2 && w && bias && logits && ld1 % 8 == 0 && ld2 % 8 == 0 && ld1 >= d && ld2 >= d && ldl >= classes,
-              SGF_E_INVALID, "sgf_combine_fc_fwd: bad pointer / ld");
+              SGF_E_INVALID, "%s: bad pointer / ld", fn);
   SGF_REQUIRE(reinterpret_cast<uintptr_t>(x1) % 16 == 0 && reinterpret_cast<uintptr_t>(x2) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(w) % 16 == 0,
-              SGF_E_INVALID, "sgf_combine_fc_fwd: x1 / x2 / w must be 16-byte aligned");
+              SGF_E_INVALID, "%s: x1 / x2 / w must be 16-byte aligned", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(head_grid(n)), block(kHeadThreads);
 #define SGF_HEAD_FWD(DP_)                                                                                        \
   hipLaunchKernelGGL((k_head_fwd_bf16<DP_>), grid, block, 0, st, static_cast<const uint16_t*>(x1), ld1, a,       \
-                     static_cast<const uint16_t*>(x2), ld2, b, w, bias, n, d, classes, logits, ldl)
+                     static_cast<const uint16_t*>(x2), ld2, b, w, bias, n, d, classes, logits, ldl, rmap)
   if (d <= 64) SGF_HEAD_FWD(64);
   else if (d <= 128) SGF_HEAD_FWD(128);
   else SGF_HEAD_FWD(256);
@@ -316,38 +324,72 @@ extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const vo
   return SGF_OK;
 }
 
-extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
-                                  int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1,
-                                  void* dx2, int64_t ld2, void* stream) {
-  int rc = check_head("sgf_combine_fc_bwd", n, d, classes, dtype);
+extern "C" int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                                  const float* w, const float* bias, int64_t n, int32_t d, int32_t classes,
+                                  int32_t dtype, float* logits, int64_t ldl, void* stream) {
+  return combine_fc_fwd_impl("sgf_combine_fc_fwd", x1, ld1, a, x2, ld2, b, w, bias, n, d, classes, dtype, logits, ldl, nullptr,
+                             stream);
+}
+
+// the same with the rows of the result scattered: logits[row_map[j]] = row j (row_map: a permutation of [0, n))
+extern "C" int sgf_combine_fc_fwd_mapped(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,
+                                         const float* w, const float* bias, int64_t n, int32_t d, int32_t classes,
+                                         int32_t dtype, float* logits, int64_t ldl, const int32_t* row_map, void* stream) {
+  SGF_REQUIRE(row_map || n == 0, SGF_E_INVALID, "sgf_combine_fc_fwd_mapped: null row_map");
+  return combine_fc_fwd_impl("sgf_combine_fc_fwd_mapped", x1, ld1, a, x2, ld2, b, w, bias, n, d, classes, dtype, logits, ldl,
+                             row_map, stream);
+}
+
+static int combine_fc_bwd_impl(const char* fn, const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
+                               int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2,
+                               int64_t ld2, const int32_t* rmap, void* stream) {
+  int rc = check_head(fn, n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
+  SGF_REQUIRE(!rmap || (dtype == SGF_BF16 && classes <= kMaxClasses), SGF_E_UNSUPPORTED,
+              "%s: a row map needs bf16 storage and at most %d classes", fn, kMaxClasses);
   if (dtype == SGF_F32) {
     SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
-                "sgf_combine_fc_bwd: bad pointer / ld");
+                "%s: bad pointer / ld", fn);
     return linear_f32_dual(dlogits, lddl, nullptr, 0, 1.f, 0.f, n, classes, d, w, d, 0, nullptr, dx1, ld1, dx2, ld2, a, b, 0, 0,
                            static_cast<hipStream_t>(stream));
   }
   if (classes > kMaxClasses) {
     SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d, SGF_E_INVALID,
-                "sgf_combine_fc_bwd: bad pointer / ld");
+                "%s: bad pointer / ld", fn);
     return linear_f32_dual(dlogits, lddl, nullptr, 0, 1.f, 0.f, n, classes, d, w, d, 0, nullptr, dx1, ld1, dx2, ld2, a, b, 0, 1,
                            static_cast<hipStream_t>(stream));
   }
   SGF_REQUIRE(dlogits && w && dx1 && dx2 && lddl >= classes && ld1 >= d && ld2 >= d && ld1 % 8 == 0 && ld2 % 8 == 0 &&
                   reinterpret_cast<uintptr_t>(dx1) % 16 == 0 && reinterpret_cast<uintptr_t>(dx2) % 16 == 0,
-              SGF_E_INVALID, "sgf_combine_fc_bwd: bad pointer / ld (dx1 / dx2: 16-byte aligned, ld %% 8 == 0)");
+              SGF_E_INVALID, "%s: bad pointer / ld (dx1 / dx2: 16-byte aligned, ld %% 8 == 0)", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
   int64_t nb = ((n + 31) / 32 + kHeadBwdThreads / 64 - 1) / (kHeadBwdThreads / 64);
   if (nb > kNumCU) nb = kNumCU;
   const dim3 grid(static_cast<unsigned>(nb)), block(kHeadBwdThreads);
 #define SGF_HEAD_BWD(DP_)                                                                                   \
   hipLaunchKernelGGL((k_head_bwd_bf16<DP_>), grid, block, 0, st, dlogits, lddl, w, n, d, classes, a, b,       \
-                     static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2)
+                     static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2, rmap)
   if (d <= 64) SGF_HEAD_BWD(64);
   else if (d <= 128) SGF_HEAD_BWD(128);
   else SGF_HEAD_BWD(256);
 #undef SGF_HEAD_BWD
   SGF_LAUNCH_CHECK();
   return SGF_OK;
+}
+
+extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
+                                  int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1,
+                                  void* dx2, int64_t ld2, void* stream) {
+  return combine_fc_bwd_impl("sgf_combine_fc_bwd", dlogits, lddl, w, n, d, classes, a, b, dtype, dx1, ld1, dx2, ld2, nullptr,
+                             stream);
+}
+
+// the same reading row row_map[j] of dlogits for row j of the gradients
+extern "C" int sgf_combine_fc_bwd_mapped(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
+                                         int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1,
+                                         void* dx2, int64_t ld2, const int32_t* row_map, void* stream) {
+  SGF_REQUIRE(row_map || n == 0, SGF_E_INVALID, "sgf_combine_fc_bwd_mapped: null row_map");
+  return combine_fc_bwd_impl("sgf_combine_fc_bwd_mapped", dlogits, lddl, w, n, d, classes, a, b, dtype, dx1, ld1, dx2, ld2,
+                             row_map, stream);
 }

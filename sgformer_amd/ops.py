@@ -704,25 +704,41 @@ class HipKernels:
         return dtype == _BF16 and bool(_lib.load().sgf_combine_fc_supported(d, classes, _lib.SGF_BF16))
 
     @staticmethod
-    def combine_fc_fwd(x1, a: float, x2, b: float, w, bias) -> torch.Tensor:
+    def combine_fc_mapped_supported(d: int, classes: int, dtype) -> bool:
+        """the row-mapped forms (sgf_combine_fc_*_mapped): the bf16 kernels of csrc/head.hip only"""
+        return dtype == _BF16 and classes <= 64 and bool(_lib.load().sgf_combine_fc_supported(d, classes, _lib.SGF_BF16))
+
+    @staticmethod
+    def combine_fc_fwd(x1, a: float, x2, b: float, w, bias, row_map=None) -> torch.Tensor:
+        """row_map (int32 permutation): row j of the product is stored as row row_map[j]"""
         n, d = x1.shape
         c = w.shape[0]
         logits = torch.empty((n, c), dtype=_F32, device=x1.device)
         with torch.cuda.device(x1.device):
-            _lib.call("sgf_combine_fc_fwd", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), _ptr(w),
-                      _ptr(bias), n, d, c, _code(x1), _ptr(logits), logits.stride(0), _stream(x1.device))
+            if row_map is None:
+                _lib.call("sgf_combine_fc_fwd", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), _ptr(w),
+                          _ptr(bias), n, d, c, _code(x1), _ptr(logits), logits.stride(0), _stream(x1.device))
+            else:
+                _lib.call("sgf_combine_fc_fwd_mapped", _ptr(x1), _ld(x1), float(a), _ptr(x2), _ld(x2), float(b), _ptr(w),
+                          _ptr(bias), n, d, c, _code(x1), _ptr(logits), logits.stride(0), _ptr(row_map), _stream(x1.device))
         return logits
 
     @staticmethod
-    def combine_fc_bwd(g, w, a: float, b: float, dtype):
+    def combine_fc_bwd(g, w, a: float, b: float, dtype, row_map=None):
+        """row_map: row j of dx1 / dx2 comes from row row_map[j] of g"""
         n, c = g.shape
         d = w.shape[1]
         dx1 = torch.empty((n, d), dtype=dtype, device=g.device)
         dx2 = torch.empty((n, d), dtype=dtype, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.call("sgf_combine_fc_bwd", _ptr(g), g.stride(0), _ptr(w), n, d, c, float(a), float(b),
-                      _lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32, _ptr(dx1), dx1.stride(0), _ptr(dx2),
-                      dx2.stride(0), _stream(g.device))
+            if row_map is None:
+                _lib.call("sgf_combine_fc_bwd", _ptr(g), g.stride(0), _ptr(w), n, d, c, float(a), float(b),
+                          _lib.SGF_BF16 if dtype == _BF16 else _lib.SGF_F32, _ptr(dx1), dx1.stride(0), _ptr(dx2),
+                          dx2.stride(0), _stream(g.device))
+            else:
+                _lib.call("sgf_combine_fc_bwd_mapped", _ptr(g), g.stride(0), _ptr(w), n, d, c, float(a), float(b),
+                          _lib.SGF_BF16, _ptr(dx1), dx1.stride(0), _ptr(dx2), dx2.stride(0), _ptr(row_map),
+                          _stream(g.device))
         return dx1, dx2
 
     # ---- T6 / K8: Linear (+ BatchNorm statistics) as one streaming pass ----
@@ -1887,9 +1903,10 @@ def axpby(x1, x2, a, b):
 # ------------------------------------------------------------------------------------------------
 class _CombineFC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, a: float, b: float):
+    def forward(ctx, x1, x2, w, bias, a: float, b: float, row_map=None):
         K.check(x1, x2)
         x1, x2 = _rows16(x1), _rows16(x2)        # sgf_combine_fc_* read 16-byte matrix-core fragments
+        ctx.row_map = row_map
         w32 = w.detach().float().contiguous()
         b32 = bias.detach().float().contiguous()
         c = w32.shape[0]
@@ -1898,7 +1915,7 @@ class _CombineFC(torch.autograd.Function):
             b32 = torch.nn.functional.pad(b32, (0, 4 - c % 4))
         ctx.save_for_backward(x1, x2, w32)
         ctx.meta = (float(a), float(b), w.dtype, bias.dtype, c)
-        out = K.combine_fc_fwd(x1, a, x2, b, w32, b32)
+        out = K.combine_fc_fwd(x1, a, x2, b, w32, b32) if row_map is None else K.combine_fc_fwd(x1, a, x2, b, w32, b32, row_map)
         return out if out.shape[1] == c else out[:, :c]
 
     @staticmethod
@@ -1909,23 +1926,38 @@ class _CombineFC(torch.autograd.Function):
         if w32.shape[0] != g.shape[1]:           # fp32 storage: the padded class columns carry a zero gradient
             g = torch.nn.functional.pad(g, (0, w32.shape[0] - g.shape[1]))
         g = g.contiguous()
-        dx1, dx2 = K.combine_fc_bwd(g, w32, a, b, x1.dtype)
+        row_map = ctx.row_map
+        dx1, dx2 = K.combine_fc_bwd(g, w32, a, b, x1.dtype) if row_map is None else K.combine_fc_bwd(g, w32, a, b, x1.dtype,
+                                                                                                       row_map)
         # dW = a g^T x1 + b g^T x2, db = colsum(g): node reductions on sgf_gram (g in the activation dtype, its
         # width padded to a multiple of 4 — the same rounding the unfused path applies to the logits gradient)
         c = c_true
-        gp = g.to(x1.dtype)
+        if row_map is not None:
+            # g is in the CALLER's row order, x1 / x2 in the module's: one gather pass brings g over, cast included
+            gp = K.gather_rows(g, row_map, x1.dtype)
+        else:
+            gp = g.to(x1.dtype)
         if gp.shape[1] % 4 != 0:
             gp = torch.nn.functional.pad(gp, (0, 4 - gp.shape[1] % 4))
         gp = _rows(gp)
         dw1, db = K.gram(gp, x1, want_colsum=True)
         dw2, _ = K.gram(gp, x2, want_colsum=False)
         dw = (a * dw1 + b * dw2)[:c]
-        return dx1, dx2, dw.to(wdtype), db[:c].to(bdtype), None, None
+        return dx1, dx2, dw.to(wdtype), db[:c].to(bdtype), None, None, None
 
 
-def combine_fc(x1, x2, w, bias, a: float, b: float) -> torch.Tensor:
-    """fp32 logits = (a x1 + b x2) W^T + bias without materialising the combination (sgf_combine_fc_*)."""
-    return _CombineFC.apply(x1, x2, w, bias, a, b)
+def combine_fc(x1, x2, w, bias, a: float, b: float, row_map=None) -> torch.Tensor:
+    """fp32 logits = (a x1 + b x2) W^T + bias without materialising the combination (sgf_combine_fc_*).  row_map (int32
+    permutation, bf16 storage with at most 64 classes: combine_fc_mapped_supported): the logits leave in the caller's row
+    order — row j of the product is row row_map[j] of the result — and the backward reads the incoming gradient through the
+    same map, instead of two [N, C] gather passes around the head."""
+    return _CombineFC.apply(x1, x2, w, bias, a, b, row_map)
+
+
+def combine_fc_mapped_supported(x: torch.Tensor, classes: int) -> bool:
+    import os
+    return (x.dim() == 2 and hasattr(K, "combine_fc_mapped_supported") and os.environ.get("SGF_HEAD_MAPPED", "1") != "0"
+            and K.combine_fc_mapped_supported(x.shape[1], classes, x.dtype))
 
 
 def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:

@@ -640,7 +640,14 @@ class SGFormer(nn.Module):
             # gw * x2 + (1 - gw) * x1 -> fc in ONE kernel (large/ours.py:269-270,275): the combined
             # activations are never written, the logits come out in fp32
             gw = float(self.graph_weight)
-            out = ops.combine_fc(x2, x1, self.fc.weight, self.fc.bias, gw, 1.0 - gw).to(out_dtype)
+            if (view is not None and view.perm is not None and repart is None
+                    and ops.combine_fc_mapped_supported(x1, self.fc.out_features)):
+                # re-ordered graph: the head's stores put the logits back in the caller's row order (and its backward
+                # reads the gradient through the same map) — no [N, C] gather pass on either side
+                out = ops.combine_fc(x2, x1, self.fc.weight, self.fc.bias, gw, 1.0 - gw, view.perm).to(out_dtype)
+                view = None
+            else:
+                out = ops.combine_fc(x2, x1, self.fc.weight, self.fc.bias, gw, 1.0 - gw).to(out_dtype)
         else:
             if self.use_graph and self.aggregate != 'add':
                 # 'cat': fc([x1 | x2]) operand by operand — the [N, 2 d] concatenation is never written

@@ -52,12 +52,23 @@ class CpuKernels:
         return dtype == torch.bfloat16 and d % 32 == 0 and d <= 256 and classes <= 64
 
     @staticmethod
-    def combine_fc_fwd(x1, a, x2, b, w, bias):
-        xc = (a * x1.float() + b * x2.float()).to(x1.dtype)          # rounded once, as the kernel does
-        return xc.float() @ w.to(x1.dtype).float().t() + bias
+    def combine_fc_mapped_supported(d, classes, dtype):
+        return dtype == torch.bfloat16 and classes <= 64 and d % 32 == 0 and d <= 256
 
     @staticmethod
-    def combine_fc_bwd(g, w, a, b, dtype):
+    def combine_fc_fwd(x1, a, x2, b, w, bias, row_map=None):
+        xc = (a * x1.float() + b * x2.float()).to(x1.dtype)          # rounded once, as the kernel does
+        out = xc.float() @ w.to(x1.dtype).float().t() + bias
+        if row_map is not None:
+            res = torch.empty_like(out)
+            res[row_map.long()] = out
+            return res
+        return out
+
+    @staticmethod
+    def combine_fc_bwd(g, w, a, b, dtype, row_map=None):
+        if row_map is not None:
+            g = g[row_map.long()]
         dx = g.to(dtype).float() @ w.to(dtype).float()
         return (a * dx).to(dtype), (b * dx).to(dtype)
 

@@ -1441,3 +1441,39 @@ def test_trainer_loss_lines_in_one_pass(cuda, dtype):
     assert float((g_got.float() - g_ref).abs().max()) <= tol * float(g_ref.abs().max())
     ignored = idx[::7]
     assert float(g_got[ignored].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,d,c", [(1000, 256, 47), (33, 128, 7), (5001, 256, 64), (2500, 64, 2)])
+def test_combine_fc_row_mapped(cuda, n, d, c):
+    """sgf_combine_fc_fwd_mapped / _bwd_mapped: the fused head with the module's row permutation folded into its stores
+    (forward: row j of the product lands in row row_map[j]) and loads (backward: row j of dx reads row row_map[j] of the
+    incoming gradient) — bit-identical to the unmapped kernels followed / preceded by the explicit permutation."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n + d + c)
+    x1 = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    x2 = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(c, d, generator=g) / d ** 0.5).to(cuda)
+    b = (torch.randn(c, generator=g) * 0.1).to(cuda)
+    go = torch.randn(n, c, generator=g).to(cuda)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(cuda)
+    assert ops.combine_fc_mapped_supported(x1, c)
+    plain = ops.K.combine_fc_fwd(x1, 0.8, x2, 0.2, w, b)
+    mapped = ops.K.combine_fc_fwd(x1, 0.8, x2, 0.2, w, b, perm)
+    want = torch.empty_like(plain)
+    want[perm.long()] = plain
+    assert torch.equal(mapped, want)
+    d1, d2 = ops.K.combine_fc_bwd(go[perm.long()].contiguous(), w, 0.8, 0.2, torch.bfloat16)
+    m1, m2 = ops.K.combine_fc_bwd(go, w, 0.8, 0.2, torch.bfloat16, perm)
+    assert torch.equal(d1, m1) and torch.equal(d2, m2)
+    # the autograd node: same logits / gradients as the unmapped node between two explicit permutations
+    leaves = [t.clone().requires_grad_(True) for t in (x1, x2, w, b)]
+    out = ops.combine_fc(leaves[1], leaves[0], leaves[2], leaves[3], 0.8, 0.2, perm)
+    (out * go).sum().backward()
+    ref_l = [t.clone().requires_grad_(True) for t in (x1, x2, w, b)]
+    ref = ops.combine_fc(ref_l[1], ref_l[0], ref_l[2], ref_l[3], 0.8, 0.2)
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(n, dtype=torch.int32, device=cuda)
+    (ref[inv.long()] * go).sum().backward()
+    assert torch.equal(out, ref[inv.long()])
+    for a, r in zip(leaves, ref_l):
+        assert _rel(a.grad.float(), r.grad.float()) <= 1e-6

@@ -152,30 +152,31 @@ class NeighborSampler:
         return nodes[:nn].long(), ei, bs
 
     def _hops(self, st, nodes, srcs, dsts, frontier, local0, n_known, batch_id):
+        """The hop-by-hop path (a fan-out of -1 has no a-priori capacity): one sgf_neighbor_sample_hop per hop, its edge and
+        node counts read back to size the next hop's buffers."""
         dev = self.device
-        if True:   # (kept at this depth: the body is the per-hop loop of sample())
-            for hop, k in enumerate(self.fanouts):
-                m = int(frontier.numel())
-                if m == 0:
-                    break
-                cap = m * (k if k >= 0 else max(self.max_deg, 1))
-                e_src = torch.empty(cap, dtype=torch.int32, device=dev)
-                e_dst = torch.empty(cap, dtype=torch.int32, device=dev)
-                s_glob = torch.empty(cap, dtype=torch.int32, device=dev)
-                new = torch.empty(cap, dtype=torch.int32, device=dev)
-                counts = torch.zeros(2, dtype=torch.int64, device=dev)
-                nbytes = _lib.load().sgf_neighbor_sample_workspace_bytes(m, cap)
-                ws = ops._workspace(dev, "nbr_sample", nbytes)
-                _lib.call("sgf_neighbor_sample_hop", _ptr(self.rowptr), _ptr(self.colind), _ptr(frontier), m, local0, k,
-                          ctypes.c_uint64(self.seed), ctypes.c_uint64(batch_id), hop, _ptr(self.local_of), n_known, cap,
-                          _ptr(e_src), _ptr(e_dst), _ptr(s_glob), _ptr(new), _ptr(counts), _ptr(ws), ws.numel(), st)
-                ne, nn = (int(v) for v in counts.tolist())
-                self.host_reads += 2        # this one and the edge count inside sgf_neighbor_sample_hop
-                srcs.append(e_src[:ne])
-                dsts.append(e_dst[:ne])
-                frontier, local0 = new[:nn].contiguous(), n_known
-                n_known += nn
-                nodes.append(frontier)
+        for hop, k in enumerate(self.fanouts):
+            m = int(frontier.numel())
+            if m == 0:
+                break
+            cap = m * (k if k >= 0 else max(self.max_deg, 1))
+            e_src = torch.empty(cap, dtype=torch.int32, device=dev)
+            e_dst = torch.empty(cap, dtype=torch.int32, device=dev)
+            s_glob = torch.empty(cap, dtype=torch.int32, device=dev)
+            new = torch.empty(cap, dtype=torch.int32, device=dev)
+            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            nbytes = _lib.load().sgf_neighbor_sample_workspace_bytes(m, cap)
+            ws = ops._workspace(dev, "nbr_sample", nbytes)
+            _lib.call("sgf_neighbor_sample_hop", _ptr(self.rowptr), _ptr(self.colind), _ptr(frontier), m, local0, k,
+                      ctypes.c_uint64(self.seed), ctypes.c_uint64(batch_id), hop, _ptr(self.local_of), n_known, cap,
+                      _ptr(e_src), _ptr(e_dst), _ptr(s_glob), _ptr(new), _ptr(counts), _ptr(ws), ws.numel(), st)
+            ne, nn = (int(v) for v in counts.tolist())
+            self.host_reads += 2        # this one and the edge count inside sgf_neighbor_sample_hop
+            srcs.append(e_src[:ne])
+            dsts.append(e_dst[:ne])
+            frontier, local0 = new[:nn].contiguous(), n_known
+            n_known += nn
+            nodes.append(frontier)
 
 
 class NeighborLoader:

@@ -624,6 +624,20 @@ int sgf_gcn_epilogue_stats(const void* a, int64_t lda, const void* w, int64_t ld
  * fp32 storage: two sgf_gcn_epilogue_dx launches.  Results are identical either way. */
 int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1, const void* w2, int64_t ldw, int64_t n, int32_t d,
                          int32_t dtype, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2, int32_t pair, void* stream);
+
+/* The same two gradients with the gradient of x0 = layer_[0] ACCUMULATED IN PLACE across the layers (large/ours.py:83-93: x0
+ * feeds every layer's Linear and its residual; the layers' backward nodes run last-to-first):
+ *     dy      = dz W[:, :d]
+ *     acc_out = dz W[:, d:] + gadd + acc_in        gadd (nullable): this layer's residual gradient of x0;
+ *                                                  acc_in (nullable): the running sum the layers before left
+ * One launch, w = [W1 | W2] as the Linear stores it (ldw >= 2 d).  d = 256 runs as PAIRS of workgroups that each produce
+ * half of the columns of BOTH results (balanced: the pair reads dz once through L2 and equal shares of the addends).  bf16
+ * storage, d in {64, 128, 256}; acc_out may alias acc_in (same rows, same columns are read before they are written).
+ * Replaces sgf_gcn_epilogue_dx2 + the final k-operand sgf_sum_n: 14 T instead of 16 T of traffic for three layers. */
+int32_t sgf_gcn_epilogue_dx2_acc_supported(int32_t d, int32_t dtype);
+int sgf_gcn_epilogue_dx2_acc(const void* dz, int64_t lddz, const void* w, int64_t ldw, int64_t n, int32_t d, int32_t dtype,
+                             void* dy, int64_t lddy, const void* gadd, int64_t ldg, const void* acc_in, int64_t ldai,
+                             void* acc_out, int64_t ldao, void* stream);
 int sgf_gcn_epilogue_dx(const void* dy, int64_t lddy, const void* w, int64_t ldw, int64_t n, int32_t d_in,
                         int32_t d_out, int32_t dtype, void* dx, int64_t lddx, void* stream);
 /* GraphConvLayer with use_init (large/ours.py:36-38):  y = [a1 | a2] W^T + bias,  W = [W1 | W2] of width 2 d.

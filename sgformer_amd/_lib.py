@@ -146,6 +146,9 @@ SIGNATURES = {
     "sgf_gcn_epilogue_dx": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     "sgf_gcn_epilogue_dx2": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64,
                                        c_int32, _P]),
+    "sgf_gcn_epilogue_dx2_acc_supported": (c_int32, [c_int32, c_int32]),
+    "sgf_gcn_epilogue_dx2_acc": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P,
+                                           c_int64, _P, c_int64, _P]),
     "sgf_gcn_epilogue_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int32,
                                c_int32, _P, c_int64, _P]),
     "sgf_gcn_bn_bwd_dx_supported": (c_int32, [c_int32, c_int32]),

@@ -297,6 +297,159 @@ __global__ __launch_bounds__(kRgThreads, 2) void k_rowgemm_bf16(RowGemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Both input gradients of the two-operand Linear z = [y | x0] W^T (large/ours.py:36-38 differentiated) in one launch, with the
+// gradient of x0 = layer_[0] ACCUMULATED IN PLACE across the layers (large/ours.py:83-93: x0 feeds every layer and its
+// residual):
+//     dy      = dz W[:, :D]
+//     acc_out = dz W[:, D:] + gadd + acc_in          (gadd: the residual's gradient of this layer; acc_in: the layers before)
+// Balanced roles: a block produces HC = D / ROLES output columns of BOTH results — its B^T in LDS is the virtual matrix
+// [W[:, c0 : c0 + HC] | W[:, D + c0 : D + c0 + HC]] — so at D = 256 the two workgroups b and b + 8 of a pair read the same
+// dz tiles (the second read an L2 hit) and the same number of addend bytes each, and neither falls behind the other.
+// The addends arrive in the read-back layout of the staging patch (16 bytes per lane, requested before the strip's MFMAs).
+struct Dx2AccArgs {
+  const uint16_t* a; int64_t lda;                      // dz
+  const uint16_t* w; int64_t ldw;                      // W [D, 2 D]
+  uint16_t* y; int64_t ldy;                            // dy
+  const uint16_t* g; int64_t ldg;                      // gadd or null
+  const uint16_t* ai; int64_t ldai;                    // acc_in or null
+  uint16_t* ao; int64_t ldao;                          // acc_out
+  int64_t n;
+};
+
+template <int DK, int ROLES>
+__global__ __launch_bounds__(kRgThreads) void k_dx2acc_bf16(Dx2AccArgs p) {
+  constexpr int HC = DK / ROLES;                       // columns of each result per block
+  constexpr int DN = 2 * HC;                           // virtual output width
+  constexpr int KS = DK / 16, NS = DN / 32;
+  constexpr int BT = DK * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[DN * BT + kRgWaves * kStageBytes];
+  unsigned char* const ldsB = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i31 = lane & 31;
+  const int hi = lane >> 5;
+  unsigned char* const stg = lds + DN * BT + wave * kStageBytes;
+  const int role = ROLES == 2 ? (blockIdx.x >> 3) & 1 : 0;
+  const int64_t vblock = ROLES == 2 ? (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3) : blockIdx.x;
+  const int64_t vgrid = ROLES == 2 ? gridDim.x / 2 : gridDim.x;
+  const int c0 = role * HC;
+
+  // ---- B^T -> LDS, once: B^T[j][k] = W[k][col(j)], col(j) = j < HC ? c0 + j : DK + c0 + (j - HC) ----
+  {
+    constexpr int CH = DN / 8;
+    for (int c = tid; c < DK * CH; c += kRgThreads) {
+      const int k = c / CH, q = c % CH;
+      const int jv = 8 * q;
+      const int col = jv < HC ? c0 + jv : DK + c0 + (jv - HC);
+      const uint4 v = *reinterpret_cast<const uint4*>(p.w + k * p.ldw + col);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<uint16_t*>(ldsB + (jv + t) * BT + 2 * k) =
+            static_cast<uint16_t>(t & 1 ? u[t >> 1] >> 16 : u[t >> 1] & 0xffffu);
+    }
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nwaves = vgrid * kRgWaves;
+  auto load_tile = [&](int64_t t, bf16x8 (&dst)[KS]) {
+    int64_t row = t * 32 + i31;
+    if (row >= p.n) row = p.n - 1;
+    const uint16_t* src = p.a + row * p.lda + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+  };
+  const unsigned char* const bfrag0 = ldsB + i31 * BT + 16 * hi;
+  unsigned char* const st_w = stg + 4 * hi * kStageStride + 2 * i31;
+  const unsigned char* const st_r = stg + (lane >> 3) * kStageStride + 16 * (lane & 7);
+
+  bf16x8 cur[KS], nxt[KS];
+  int64_t t = vblock * kRgWaves + wave;
+  if (t < ntiles) load_tile(t, cur);
+  for (; t < ntiles; t += nwaves) {
+    const int64_t tn = t + nwaves;
+    if (tn < ntiles) load_tile(tn, nxt);
+    const int64_t row0 = t * 32;
+    const bool tail = row0 + 32 > p.n;
+    const int64_t rb = row0 + (lane >> 3);               // this lane's row in the read-back, + 8 q + 16 hh
+    const int cl = c0 + 8 * (lane & 7);                  // its first column inside a 64-column strip pair, + 64 u'
+#pragma unroll
+    for (int u = 0; u < NS / 2; ++u) {
+      const bool is_acc = 64 * u >= HC;                  // compile-time after unrolling
+      const int cu = cl + (is_acc ? 64 * u - HC : 64 * u);
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[0][r] = 0.f;
+        acc[1][r] = 0.f;
+      }
+      // the addends of this strip pair, in the read-back layout: rows rb + 16 hh + 8 q
+      uint4 ag[2][2], aa[2][2];
+      if (is_acc) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            int64_t r = rb + 16 * hh + 8 * q;
+            if (r >= p.n) r = p.n - 1;
+            ag[hh][q] = p.g ? *reinterpret_cast<const uint4*>(p.g + r * p.ldg + cu) : make_uint4(0u, 0u, 0u, 0u);
+            aa[hh][q] = p.ai ? *reinterpret_cast<const uint4*>(p.ai + r * p.ldai + cu) : make_uint4(0u, 0u, 0u, 0u);
+          }
+      }
+      const unsigned char* const bu = bfrag0 + 64 * u * BT;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bu + 32 * s);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bu + 32 * BT + 32 * s);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[s], b1, acc[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 8 * hh; r < 8 * hh + 8; r += 2) {
+            const uint32_t v = cvt_pk_bf16(acc[c][r], acc[c][r + 1]);
+            const int rl = (r & 3) + 8 * ((r >> 2) & 1);
+            *reinterpret_cast<uint16_t*>(st_w + rl * kStageStride + 64 * c) = static_cast<uint16_t>(v & 0xffffu);
+            *reinterpret_cast<uint16_t*>(st_w + (rl + 1) * kStageStride + 64 * c) = static_cast<uint16_t>(v >> 16);
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageStride);
+          const int64_t r = rb + 16 * hh + 8 * q;
+          if (is_acc) {
+            const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t pg[4] = {ag[hh][q].x, ag[hh][q].y, ag[hh][q].z, ag[hh][q].w};
+            const uint32_t pa[4] = {aa[hh][q].x, aa[hh][q].y, aa[hh][q].z, aa[hh][q].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(pv[e] << 16) + __uint_as_float(pg[e] << 16) + __uint_as_float(pa[e] << 16);
+              const float hi2 = __uint_as_float(pv[e] & 0xffff0000u) + __uint_as_float(pg[e] & 0xffff0000u) +
+                                __uint_as_float(pa[e] & 0xffff0000u);
+              o[e] = cvt_pk_bf16(lo, hi2);
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+            if (!tail || r < p.n) *reinterpret_cast<uint4*>(p.ao + r * p.ldao + cu) = v;
+          } else {
+            if (!tail || r < p.n) *reinterpret_cast<uint4*>(p.y + r * p.ldy + cu) = v;
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The two-operand Linear  y = [a1 | a2] W^T + bias  (GraphConvLayer with use_init, large/ours.py:36-38) in ONE pass
 // (+ BatchNorm's column sums).  The contraction runs over 2 D indices, so W is [D, 2 D]:
 //   D <= 128: 64 KiB — one block holds all of it, a wave multiplies a1's tile, then a2's tile into the same accumulators;
@@ -1517,6 +1670,42 @@ extern "C" int sgf_gcn_epilogue_dx2(const void* dy, int64_t lddy, const void* w1
                    static_cast<const uint16_t*>(w2), static_cast<uint16_t*>(dx2), lddx2, 1};
   const int pairs = grid_blocks(n) / 16 * 8;          // whole groups of 8 pairs = 16 consecutive blocks
   return launch_rowgemm<false, 0>(args, d, 2 * pairs, st);
+}
+
+// dy = dz W[:, :d], acc_out = dz W[:, d:] + gadd + acc_in (gadd / acc_in nullable): see k_dx2acc_bf16
+extern "C" int32_t sgf_gcn_epilogue_dx2_acc_supported(int32_t d, int32_t dtype) {
+  return dtype == SGF_BF16 && (d == 64 || d == 128 || d == 256) ? 1 : 0;
+}
+
+extern "C" int sgf_gcn_epilogue_dx2_acc(const void* dz, int64_t lddz, const void* w, int64_t ldw, int64_t n, int32_t d,
+                                        int32_t dtype, void* dy, int64_t lddy, const void* gadd, int64_t ldg,
+                                        const void* acc_in, int64_t ldai, void* acc_out, int64_t ldao, void* stream) {
+  const char* fn = "sgf_gcn_epilogue_dx2_acc";
+  SGF_REQUIRE(n >= 0, SGF_E_INVALID, "%s: negative n", fn);
+  SGF_REQUIRE(sgf_gcn_epilogue_dx2_acc_supported(d, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, d in {64, 128, 256} (got d = %d, dtype %d)", fn, d, dtype);
+  if (n == 0) return SGF_OK;
+  SGF_REQUIRE(dz && w && dy && acc_out, SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(lddz >= d && lddy >= d && ldao >= d && ldw >= 2 * d && (!gadd || ldg >= d) && (!acc_in || ldai >= d),
+              SGF_E_INVALID, "%s: leading dimension smaller than the width", fn);
+  SGF_REQUIRE(rows16(dz, lddz) && rows16(w, ldw) && rows16(dy, lddy) && rows16(acc_out, ldao) &&
+                  (!gadd || rows16(gadd, ldg)) && (!acc_in || rows16(acc_in, ldai)),
+              SGF_E_INVALID, "%s: rows must be 16-byte aligned (pointers %% 16, leading dims %% 8 elements)", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Dx2AccArgs a{static_cast<const uint16_t*>(dz), lddz, static_cast<const uint16_t*>(w), ldw, static_cast<uint16_t*>(dy), lddy,
+               static_cast<const uint16_t*>(gadd), ldg, static_cast<const uint16_t*>(acc_in), ldai,
+               static_cast<uint16_t*>(acc_out), ldao, n};
+  if (d == 256) {
+    int pairs = grid_blocks(n) / 16 * 8;                // whole groups of 8 pairs = 16 consecutive blocks
+    if (pairs < 8) pairs = 8;
+    hipLaunchKernelGGL((k_dx2acc_bf16<256, 2>), dim3(2 * pairs), dim3(kRgThreads), 0, st, a);
+  } else if (d == 128) {
+    hipLaunchKernelGGL((k_dx2acc_bf16<128, 1>), dim3(grid_blocks(n)), dim3(kRgThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_dx2acc_bf16<64, 1>), dim3(grid_blocks(n)), dim3(kRgThreads), 0, st, a);
+  }
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
 }
 
 // ---- backward of the GCN layer's dense half: BatchNorm backward + both input gradients, dx0 accumulated ------------------

@@ -834,6 +834,22 @@ class HipKernels:
         return dx
 
     @staticmethod
+    def gcn_epilogue_dx2_acc_supported(d: int, dtype) -> bool:
+        return dtype == _BF16 and bool(_lib.load().sgf_gcn_epilogue_dx2_acc_supported(int(d), _lib.SGF_BF16))
+
+    @staticmethod
+    def gcn_epilogue_dx2_acc(dz, w, gadd, acc_in):
+        """(dz W[:, :d], dz W[:, d:] + gadd + acc_in): both input gradients of the two-operand Linear, the second one added to
+        the running gradient of x0 (sgf_gcn_epilogue_dx2_acc); gadd / acc_in may be None."""
+        n, d = dz.shape
+        dy = torch.empty_like(dz)
+        acc = torch.empty_like(dz)
+        with torch.cuda.device(dz.device):
+            _lib.call("sgf_gcn_epilogue_dx2_acc", _ptr(dz), _ld(dz), _ptr(w), _ld(w), n, d, _code(dz), _ptr(dy), _ld(dy),
+                      _ptr(gadd), _ld(gadd), _ptr(acc_in), _ld(acc_in), _ptr(acc), _ld(acc), _stream(dz.device))
+        return dy, acc
+
+    @staticmethod
     def gcn_bn_bwd_dx_supported(d: int, dtype) -> bool:
         return dtype == _BF16 and bool(_lib.load().sgf_gcn_bn_bwd_dx_supported(int(d), _lib.SGF_BF16))
 
@@ -2334,6 +2350,13 @@ def _fused_bwd() -> bool:
     return os.environ.get("SGF_GCN_BWD_FUSED", "0") == "1"
 
 
+def _acc_in_place(d: int, dtype) -> bool:
+    """sgf_gcn_epilogue_dx2_acc in the layers' backward (default on; SGF_GCN_DX_ACC=0: paired dx2 + one sgf_sum_n)."""
+    import os
+    return (hasattr(K, "gcn_epilogue_dx2_acc_supported") and K.gcn_epilogue_dx2_acc_supported(d, dtype)
+            and os.environ.get("SGF_GCN_DX_ACC", "1") != "0")
+
+
 def gcn_layer_fused_ok(x0: torch.Tensor, w: torch.Tensor) -> bool:
     """bf16 storage, square blocks of 64 / 128 / 256, W = [W1 | W2] — what sgf_gcn_bn_bwd_dx / sgf_gcn_epilogue_cat take."""
     import os
@@ -2395,14 +2418,25 @@ class _LinearBNActRes(torch.autograd.Function):
             # BatchNorm backward, then BOTH input gradients from one HBM read of dz (paired launch); x0's contributions wait
             # in the chain for the one summation pass
             dz = K.bn_bwd_apply(gout, z, mean, rstd, g32, be32, relu, stats, inv_n, training)
-            dy, dxi = K.gcn_epilogue_dx2(dz, wc[:, :d], wc[:, d:], True)
-            chain.parts.append(dxi)
-            if use_res:
-                chain.parts.append(gout)
-            dx0 = None
-            if first:
-                parts, chain.parts = chain.parts, []
-                dx0 = parts[0] if len(parts) == 1 else (K.sum_n(parts) if len(parts) <= 8 else sum(parts[1:], parts[0]))
+            if _acc_in_place(d, dz.dtype) and not chain.parts:
+                # x0's gradient accumulated IN PLACE: this layer's dz W2 and residual gradient join the running sum inside
+                # the launch that produces dy (balanced pair of workgroups at d = 256) — no k-operand summation pass at the end
+                dy, chain.acc = K.gcn_epilogue_dx2_acc(dz, wc, _rows16(gout) if use_res else None, chain.acc)
+                dx0 = None
+                if first:
+                    dx0, chain.acc = chain.acc, None
+            else:
+                dy, dxi = K.gcn_epilogue_dx2(dz, wc[:, :d], wc[:, d:], True)
+                chain.parts.append(dxi)
+                if use_res:
+                    chain.parts.append(gout)
+                dx0 = None
+                if first:
+                    parts, chain.parts = chain.parts, []
+                    if chain.acc is not None:
+                        parts.append(chain.acc)
+                        chain.acc = None
+                    dx0 = parts[0] if len(parts) == 1 else (K.sum_n(parts) if len(parts) <= 8 else sum(parts[1:], parts[0]))
         dw, db = _linear_param_grads(dz, [yr, xr], [d, d], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and bdt is not None,
                                      wdt, bdt)
         dgamma = stats[d:].to(gdt) if g32 is not None else None

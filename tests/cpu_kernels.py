@@ -120,6 +120,21 @@ class CpuKernels:
         return dz, dy, acc.to(z.dtype)
 
     @staticmethod
+    def gcn_epilogue_dx2_acc_supported(d, dtype):
+        return dtype == torch.bfloat16 and d in (64, 128, 256)
+
+    @staticmethod
+    def gcn_epilogue_dx2_acc(dz, w, gadd, acc_in):
+        d = dz.shape[1]
+        dy = (dz.float() @ w[:, :d].float()).to(dz.dtype)
+        acc = (dz.float() @ w[:, d:].float()).to(dz.dtype).float()            # rounded once before the addends, as the kernel
+        if gadd is not None:
+            acc = acc + gadd.float()
+        if acc_in is not None:
+            acc = acc + acc_in.float()
+        return dy, acc.to(dz.dtype)
+
+    @staticmethod
     def gcn_epilogue_dx2(dy, w1, w2, pair=True):
         return CpuKernels.gcn_epilogue_dx(dy, w1), CpuKernels.gcn_epilogue_dx(dy, w2)
 

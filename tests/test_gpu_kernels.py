@@ -1477,3 +1477,42 @@ def test_combine_fc_row_mapped(cuda, n, d, c):
     assert torch.equal(out, ref[inv.long()])
     for a, r in zip(leaves, ref_l):
         assert _rel(a.grad.float(), r.grad.float()) <= 1e-6
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (100, 256), (31, 128), (4096, 256), (9001, 128), (20001, 256), (70003, 256), (5000, 64)])
+@pytest.mark.parametrize("with_g,with_acc", [(True, True), (True, False), (False, True), (False, False)])
+def test_gcn_epilogue_dx2_acc(cuda, n, d, with_g, with_acc):
+    """sgf_gcn_epilogue_dx2_acc: dy = dz W[:, :d] and acc_out = dz W[:, d:] + gadd + acc_in from one launch (balanced pairs of
+    workgroups at d = 256).  dy bit-identical to sgf_gcn_epilogue_dx; acc_out == bf16(fp32(bf16(dz W2)) + gadd + acc_in):
+    the product is rounded once on its way through the staging patch (as the separate kernel stores it), the sum once more —
+    compared with exactly that arithmetic built from sgf_gcn_epilogue_dx's output (equal up to the ties of the last
+    rounding: <= 1 bf16 ulp on <= 1e-3 of the elements), and with fp64 within 2 bf16 roundings."""
+    from sgformer_amd import ops
+    K = ops.K
+    assert K.gcn_epilogue_dx2_acc_supported(d, torch.bfloat16)
+    g = torch.Generator().manual_seed(7 * n + d + 2 * with_g + with_acc)
+    dz = torch.randn(n, d, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5).bfloat16().to(cuda)
+    gadd = torch.randn(n, d, generator=g).bfloat16().to(cuda) if with_g else None
+    acc_in = (torch.randn(n, d, generator=g) * 2).bfloat16().to(cuda) if with_acc else None
+    dy, acc = K.gcn_epilogue_dx2_acc(dz, w, gadd, acc_in)
+    dy_ref = K.gcn_epilogue_dx(dz, w[:, :d])
+    p2 = K.gcn_epilogue_dx(dz, w[:, d:])
+    assert torch.equal(dy, dy_ref)
+    want = p2.float()
+    if with_g:
+        want = want + gadd.float()
+    if with_acc:
+        want = want + acc_in.float()
+    want_b = want.bfloat16()
+    diff = (acc.float() - want_b.float()).abs()
+    ulp = want_b.float().abs().clamp_min(1e-30) * 2.0 ** -7
+    assert bool((diff <= ulp).all()) and int((diff > 0).sum()) <= max(2, int(1e-3 * acc.numel()))
+    ref64 = dz.double() @ w[:, d:].double()
+    if with_g:
+        ref64 = ref64 + gadd.double()
+    if with_acc:
+        ref64 = ref64 + acc_in.double()
+    assert float((acc.double() - ref64).abs().max()) <= 2.0 ** -7 * float(ref64.abs().max()) + 1e-6
+    dy2, acc2 = K.gcn_epilogue_dx2_acc(dz, w, gadd, acc_in)
+    assert torch.equal(dy, dy2) and torch.equal(acc, acc2)

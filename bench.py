@@ -504,7 +504,7 @@ def main():
     if (rank == 0 and world == 1 and args.graph == "uniform" and not args.no_structured
             and not args.workload.endswith("-weak")):
         k = max(3, min(args.steps, 5))
-        q = run_workload(args, "community", rank, world, dev, k, 2)
+        q = run_workload(args, "community", rank, world, dev, k, 3)
         structured = {
             "graph": "same N / degree; communities of 64-256 nodes in super-communities of 64 (80 % / 15 % / 5 % of "
                      "the pairs inside the community / the super-community / anywhere), node ids randomly permuted",

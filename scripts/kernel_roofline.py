@@ -74,6 +74,9 @@ def main(path: str, elem: int):
         ("k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx2, paired)" if r04 else "k_rowgemm_bf16<256,IO 0>  (sgf_gcn_epilogue_dx)",
          ("k_rowgemm_bf16<256, false, 0, 0>",), 3 * T if r04 else 2 * T,
          "dz -> dy AND dx0 from one HBM read of dz (workgroups b, b + 8 share the tile in L2)" if r04 else "dy -> dx", find),
+        ("k_dx2acc_bf16<256,2>  (sgf_gcn_epilogue_dx2_acc, balanced pairs)", ("k_dx2acc_bf16<256, 2>",), 14 * T / 3,
+         "dz -> dy AND acc_out = dz W2 + residual gradient + acc_in: 4T for the first layer of the chain, 5T for the other two",
+         find),
         ("k_rowgemm2_bf16<256,2,stats>  (sgf_gcn_epilogue_cat)", ("k_rowgemm2_bf16<256, 2, true>",), 3 * T,
          "[y | x0] W^T + b + BatchNorm sums in one pass (paired column halves); full-size launches only", find_full),
         ("k_rowgemm_bf16<256,IO 1>  (sgf_gcn_epilogue_partial)", ("k_rowgemm_bf16<256, false, 1, 0>",), 2 * T,

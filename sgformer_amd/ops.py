@@ -920,12 +920,16 @@ _SEGMENT = 1024   # = sgf_spmm_segment_len()
 SMALL_GRAPH_NNZ = 1 << 23
 
 
-def long_row_segments(rowptr: torch.Tensor, nnz: Optional[int] = None) -> int:
+def long_row_segments(rowptr: torch.Tensor, nnz: Optional[int] = None, max_row_len: Optional[int] = None) -> int:
     """sum over rows longer than LONG_ROW of ceil(len / segment): the `long_segments` argument of
     sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built) — or, for
     small graphs whose nnz is known on the host, the bound  sum ceil(len/seg) <= nnz/seg + nnz/(LONG_ROW+1)
-    without any device read (0 when no row can be long at all)."""
+    without any device read (0 when no row can be long at all).  `max_row_len`: a bound on the longest row the caller
+    knows without looking (a sampled batch: its largest fan-out; any graph: its node count) — at most LONG_ROW means no
+    split path at all (no memset, no extra launches) for that CSR."""
     if rowptr.numel() <= 1:
+        return 0
+    if max_row_len is not None and max_row_len <= LONG_ROW:
         return 0
     if nnz is not None and nnz < SMALL_GRAPH_NNZ:
         return 0 if nnz <= LONG_ROW else nnz // _SEGMENT + nnz // (LONG_ROW + 1) + 1
@@ -973,7 +977,10 @@ class CSRGraph:
         self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
         self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
-        self.long_segments = long_row_segments(self.rowptr, self.nnz)
+        # longest possible row: the caller's bound (sampling.NeighborSampler marks its batches with their largest fan-out),
+        # else the node count (a row of a coalesced graph has at most n entries)
+        hint = getattr(edge_index, "_sgf_max_in_degree", None)
+        self.long_segments = long_row_segments(self.rowptr, self.nnz, n if hint is None else min(int(hint), n))
         self.t_long_segments = 0
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None

@@ -39,8 +39,10 @@ class SampledBatch:
         dev = torch.device(device)
         mv = lambda t: t if (t is None or t.device == dev) else t.to(dev)   # noqa: E731
         out = SampledBatch(mv(self.x), mv(self.edge_index), mv(self.y), self.batch_size, mv(self.n_id))
-        if getattr(self.edge_index, "_sgf_trusted", False) and out.edge_index is not self.edge_index:
-            out.edge_index._sgf_trusted = True
+        if out.edge_index is not self.edge_index:
+            for attr in ("_sgf_trusted", "_sgf_max_in_degree"):       # what ops.CSRGraph reads off a sampled edge list
+                if hasattr(self.edge_index, attr):
+                    setattr(out.edge_index, attr, getattr(self.edge_index, attr))
         return out
 
 
@@ -149,6 +151,7 @@ class NeighborSampler:
         self.host_reads += 1
         ei = torch.stack([e_src[:ne], e_dst[:ne]]).long()
         ei._sgf_trusted = True
+        ei._sgf_max_in_degree = max(self.fanouts)       # every node is a frontier node once: at most fan-out in-edges
         return nodes[:nn].long(), ei, bs
 
     def _hops(self, st, nodes, srcs, dsts, frontier, local0, n_known, batch_id):

@@ -764,3 +764,15 @@ def test_packed_attention_algebra_matches_the_term_by_term_form(sum_v, d, d_in):
     assert float(((got[0] + got[0].t()) - (gref[0] + gref[0].t())).abs().max()) <= 1e-11 * max(1.0, float(gref[0].abs().max()))
     for a, b in zip(got[1:], gref[1:]):
         assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max()))
+
+
+def test_long_row_bound_uses_what_the_caller_knows():
+    """ADVICE r02 / VERDICT r03: the host-side bound on long-row segments sent every small graph with more than 1024 entries
+    down the split path.  A caller-supplied bound on the longest row (a sampled batch: its fan-out; any graph: its node count)
+    at most LONG_ROW switches the split path off without a device read."""
+    from sgformer_amd import ops
+    rowptr = torch.arange(0, 5001, 5)                                       # 1000 rows of 5 entries: nnz = 5000 > LONG_ROW
+    assert ops.long_row_segments(rowptr, 5000) > 0                           # nothing known: the bound
+    assert ops.long_row_segments(rowptr, 5000, max_row_len=15) == 0          # a sampled batch with fan-outs <= 15
+    assert ops.long_row_segments(rowptr, 5000, max_row_len=1000) == 0        # a graph of 1000 nodes
+    assert ops.long_row_segments(rowptr, 5000, max_row_len=ops.LONG_ROW + 1) > 0

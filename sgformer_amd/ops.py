@@ -1531,6 +1531,47 @@ def _attn_h_small_packed(Gt, Wqk, Wv, n_total: float, sum_v: bool = False):
     return Mm[:D], Mm[D], wb[:D], wb[D:] + n_total
 
 
+def _attn_h_packed_fwd(Gt, Wqk, Wv, n_total: float):
+    """_attn_h_small_packed(sum_v=False) WITHOUT autograd, keeping what its hand-written backward needs:
+    Out = c Wq~^T (Wk~ Gt) Vx + n_total Vx with Vx = [Wv~^T | e_D]; M, m, w, beta are the blocks of Out."""
+    d = Wv.shape[0]
+    E = Gt.shape[0]
+    D = E - 1
+    PG = Wqk @ Gt
+    ssq = (PG * Wqk).view(2, -1).sum(1)
+    c = torch.rsqrt(ssq[0] * ssq[1])
+    Vx = torch.zeros((E, d + 1), dtype=Gt.dtype, device=Gt.device)
+    Vx[:, :d] = Wv.t()
+    Vx[D, d:].fill_(1.0)                                 # (fill_, not `= 1.0`: a Python scalar assignment is a syncing H2D copy)
+    SZ = PG[d:] @ Vx                                     # [s0 | z0]
+    T = Wqk[:d].t() @ SZ
+    Out = torch.addcmul(Vx * n_total, T, c)
+    return Out, (PG, ssq, c, Vx, SZ, T)
+
+
+def _attn_h_packed_bwd(Gt, Wqk, Wv, n_total: float, saved, gOut):
+    """Gradients of the packed operands from gOut [(D + 1) x (d + 1)] (the gradients of M, m, w, beta in Out's blocks):
+    20 launches, none of autograd's zero-filled slice gradients.  With Gt symmetric:
+        gT = c gOut, gc = <gOut, T>, (g_sq, g_sk) = -gc c / (2 ssq)
+        gWq~ = SZ gT^T + 2 g_sq PQ... (PQ = Wq~ Gt enters twice: through ||Q||^2 directly and through Gt's symmetry)"""
+    PG, ssq, c, Vx, SZ, T = saved
+    d = Wv.shape[0]
+    gc = torch.dot(gOut.reshape(-1), T.reshape(-1))
+    gs = (gc * c * -0.5) / ssq                           # [g_sq, g_sk]
+    gT = gOut * c
+    Wq = Wqk[:d]
+    gSZ = Wq @ gT                                        # [d, d + 1]
+    gs2 = gs.repeat_interleave(d)[:, None]               # [2 d, 1]
+    gPG = gs2 * Wqk                                      # [g_sq Wq~ ; g_sk Wk~]
+    gPG[d:] += gSZ @ Vx.t()                              # + the path through K^T V and K^T 1
+    gWqk = torch.addmm(gs2 * PG, gPG, Gt)                # PG = Wqk Gt: gPG Gt^T (Gt symmetric) + the direct <PG, Wqk> term
+    gWqk[:d] += SZ @ gT.t()
+    gGt = Wqk.t() @ gPG
+    gVx = torch.addmm(gOut * n_total, PG[d:].t(), gSZ)   # Vx enters twice: SZ = PK Vx and the n_total Vx term
+    gWv = gVx[:, :d].t()
+    return gGt, gWqk, gWv
+
+
 def _attn_h_pack(G, s, n_rows: float, wq, bq, wk, bk, wv, bv):
     """The augmented operands of _attn_h_small_packed (no autograd: the caller differentiates w.r.t. the packed leaves
     and slices their gradients)."""
@@ -1572,11 +1613,21 @@ class _AttentionFromInput(torch.autograd.Function):
             n_rows = float(shard.n_global)
         n_total = n_rows if n_override is None else float(n_override)
         # the d x d algebra on packed operands, recorded ONCE: the backward differentiates this graph instead of re-running it
-        with torch.enable_grad(), _SmallGemms():
-            leaves = [t.requires_grad_(True) for t in _attn_h_pack(G, s, n_rows, *f32)]
-            small = _attn_h_small_packed(*leaves, n_total, sum_v=sum_v)
-        M, m, w, beta = (t.detach().contiguous() for t in small)
-        ctx.small = (leaves, small)
+        di = f32[0].shape[1]
+        if sum_v:           # DIFFormer's numerator: the autograd form (no recipe's hot path)
+            with torch.enable_grad(), _SmallGemms():
+                leaves = [t.requires_grad_(True) for t in _attn_h_pack(G, s, n_rows, *f32)]
+                small = _attn_h_small_packed(*leaves, n_total, sum_v=True)
+            M, m, w, beta = (t.detach().contiguous() for t in small)
+            ctx.small = (leaves, small, None)
+        else:               # forward and backward written out: 12 + 20 launches, nothing recorded
+            with _SmallGemms():
+                packed = _attn_h_pack(G, s, n_rows, *f32)
+                Out, saved = _attn_h_packed_fwd(*packed, n_total)
+            do = f32[0].shape[0]
+            M, m = Out[:di, :do].contiguous(), Out[di, :do].contiguous()
+            w, beta = Out[:di, do].contiguous(), Out[di:, do].contiguous()
+            ctx.small = (packed, None, saved)
         out, den = K.attn_h_fwd(h, M, m, w, beta)
         ctx.save_for_backward(h, out, den, G, s, M, w, *f32)
         ctx.meta = (n_rows, n_total, shard, wv is None,
@@ -1601,10 +1652,18 @@ class _AttentionFromInput(torch.autograd.Function):
         dbeta = hstats[d * d + 2 * d:]
         # backward through the d x d algebra: the graph the forward recorded on the packed operands; the gradients of
         # G, s and the six parameters are blocks of the packed ones
-        leaves, small = ctx.small
-        with _SmallGemms():
-            gGt, gWqk, gWv = torch.autograd.grad(small, leaves, grad_outputs=(dM, dm, dw_, dbeta), retain_graph=True)
+        leaves, small, saved = ctx.small
         do, di = f32[0].shape
+        with _SmallGemms():
+            if saved is None:
+                gGt, gWqk, gWv = torch.autograd.grad(small, leaves, grad_outputs=(dM, dm, dw_, dbeta), retain_graph=True)
+            else:
+                gOut = torch.empty((di + 1, do + 1), dtype=_F32, device=h.device)
+                gOut[:di, :do] = dM
+                gOut[di, :do] = dm
+                gOut[:di, do] = dw_
+                gOut[di, do:] = dbeta
+                gGt, gWqk, gWv = _attn_h_packed_bwd(*leaves, n_total, saved, gOut)
         Dm = gGt[:di, :di]
         D = (Dm + Dm.t()).contiguous()
         ds = gGt[:di, di] + gGt[di, :di]

@@ -776,3 +776,36 @@ def test_long_row_bound_uses_what_the_caller_knows():
     assert ops.long_row_segments(rowptr, 5000, max_row_len=15) == 0          # a sampled batch with fan-outs <= 15
     assert ops.long_row_segments(rowptr, 5000, max_row_len=1000) == 0        # a graph of 1000 nodes
     assert ops.long_row_segments(rowptr, 5000, max_row_len=ops.LONG_ROW + 1) > 0
+
+
+@pytest.mark.parametrize("d", [5, 8, 16])
+def test_packed_attention_algebra_hand_written_backward(d):
+    """ops._attn_h_packed_fwd / _bwd (what the training step runs: 12 + 20 launches, no autograd graph) == autograd through
+    ops._attn_h_small_packed, in fp64 to 1e-12: the four outputs and the gradients of the three packed operands (Gt's through
+    the symmetrised form D = dG + dG^T and ds, which is all the caller uses)."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(d)
+    h = torch.randn(40, d, generator=g, dtype=torch.float64)
+    par = [torch.randn(d, d, generator=g, dtype=torch.float64) * 0.3 if i % 2 == 0 else
+           torch.randn(d, generator=g, dtype=torch.float64) * 0.1 for i in range(6)]
+    old = ops._F32
+    ops._F32 = torch.float64
+    try:
+        packed = [t.requires_grad_(True) for t in ops._attn_h_pack(h.t() @ h, h.sum(0), 40.0, *par)]
+        ref = ops._attn_h_small_packed(*packed, 55.0, sum_v=False)
+        cot = [torch.randn(t.shape, generator=g, dtype=torch.float64) for t in ref]
+        gref = torch.autograd.grad(ref, packed, cot)
+        with torch.no_grad():
+            pk = [t.detach() for t in packed]
+            out, saved = ops._attn_h_packed_fwd(*pk, 55.0)
+            gout = torch.zeros(d + 1, d + 1, dtype=torch.float64)
+            gout[:d, :d], gout[d, :d], gout[:d, d], gout[d, d:] = cot[0], cot[1], cot[2], cot[3]
+            got = ops._attn_h_packed_bwd(*pk, 55.0, saved, gout)
+    finally:
+        ops._F32 = old
+    for a, b in zip((out[:d, :d], out[d, :d], out[:d, d], out[d:, d]), ref):
+        assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max()))
+    sym = lambda m: m + m.t()      # noqa: E731
+    assert float((sym(got[0]) - sym(gref[0])).abs().max()) <= 1e-12 * max(1.0, float(gref[0].abs().max()))
+    for a, b in zip(got[1:], gref[1:]):
+        assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max()))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 400 /* 0.4.0: sgf_gcn_epilogue_cat / _dx2, sgf_gram2, sgf_gram_bn_bwd / _ln_bwd, sgf_bn_bwd_stats2, sgf_bn_finalize, sgf_gcn_bn_bwd_dx, sgf_neighbor_sample_batch, sgf_reload_env */
+#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -336,6 +336,12 @@ int sgf_neighbor_sample_batch(const int64_t* rowptr, const int32_t* colind, cons
 int sgf_gather_rows(const void* src, int64_t lds, int32_t src_dtype, int64_t n_src, const void* idx,
                     int32_t idx_is_int64, int64_t n_out, int32_t d, void* dst, int64_t ldd,
                     int32_t dst_dtype, void* stream);
+/* The same copy for feature widths that are not a multiple of 4 (pokec f = 65, Cora f = 1433; large/ours.py:77,:198 read x
+ * as it comes): dst[i, :d] = src[idx ? idx[i] : i, :d], dst[i, d:d_pad] = 0, with the same optional storage change.  idx may
+ * be NULL (identity).  Done once per feature tensor at the module entry; the stems then run on the aligned kernels with
+ * zero-padded weight columns. */
+int sgf_pad_rows(const void* src, int64_t lds, int32_t src_dtype, int64_t n_src, const void* idx, int32_t idx_is_int64,
+                 int64_t n_out, int32_t d, int32_t d_pad, void* dst, int64_t ldd, int32_t dst_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T3 — linear global attention core.   Replaces large/ours.py:130-149,157
@@ -453,6 +459,33 @@ int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const void* g, int6
 int sgf_attn_h_bwd_post(const void* h, int64_t ldh, int64_t n, int32_t d, int32_t dtype, const float* D, const float* ds,
                         const void* workspace, size_t workspace_bytes, const void* addend, int64_t ldadd, void* dh,
                         int64_t lddh, void* stream);
+
+/* The d x d algebra between the two node passes, as ONE entry each way (csrc/attn_small.hip; r05 — r04 issued it from
+ * Python as 12 + 20 ATen / rocBLAS launches).  Replaces the small dense part of large/ours.py:123-149 with the projections
+ * folded in (formulas above), written on augmented operands:
+ *   sgf_attn_h_small_fwd : (G [d_in, d_in], s [d_in], n_rows, n_total, wq / wk / wv [d_out, d_in] with leading dim ldw,
+ *                           bq / bk / bv [d_out]; wv = NULL: V is h itself, use_weight=False, needs d_in == d_out)
+ *                          -> M [d_in, d_out] (ldm), m [d_out], w [d_in], beta [1]   — the operands of sgf_attn_h_fwd;
+ *                          `saved` (sgf_attn_h_small_saved_bytes, caller-owned, opaque) keeps what the backward needs.
+ *                          6 launches: pack, 3 products on the exact-fp32 matrix cores (csrc/gemm.hip), ||Q||^2 / ||K||^2
+ *                          (one block, fixed summation order), scale + unpack.
+ *   sgf_attn_h_small_bwd : (dM [d_in, d_out] (lddm), dw [d_in], dm [d_out], dbeta [1] = the blocks of hstats, after the
+ *                          ranks' all-reduce) -> dG2 = dG + dG^T [d_in, d_in] (lddg) and ds [d_in] — the D / ds operands
+ *                          of sgf_attn_h_bwd_post / _apply — and the six parameter gradients gwq / gwk / gwv [d_out, d_in]
+ *                          (ldgw), gbq / gbk / gbv [d_out] (any of them NULL to skip).  9 launches; workspace:
+ *                          sgf_attn_h_small_workspace_bytes.
+ * n_rows = the number of rows behind G and s (global count when sharded); n_total = the N of large/ours.py:133.
+ * Everything fp32 and on the device: no host synchronisation, no host read of ||Q|| or ||K||. */
+size_t sgf_attn_h_small_saved_bytes(int32_t d_in, int32_t d_out);
+size_t sgf_attn_h_small_workspace_bytes(int32_t d_in, int32_t d_out);
+int sgf_attn_h_small_fwd(const float* G, int64_t ldg, const float* s, float n_rows, float n_total, const float* wq,
+                         const float* bq, const float* wk, const float* bk, const float* wv, const float* bv, int64_t ldw,
+                         int32_t d_in, int32_t d_out, float* M, int64_t ldm, float* m, float* w, float* beta, void* saved,
+                         size_t saved_bytes, void* stream);
+int sgf_attn_h_small_bwd(const float* dM, int64_t lddm, const float* dw, const float* dm, const float* dbeta, float n_total,
+                         int32_t d_in, int32_t d_out, const void* saved, size_t saved_bytes, float* dG2, int64_t lddg,
+                         float* ds, float* gwq, float* gbq, float* gwk, float* gbk, float* gwv, float* gbv, int64_t ldgw,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T4/T6/T7 — weight and bias gradients of the Linear layers.   Replaces what autograd does for
@@ -710,6 +743,24 @@ int sgf_stem_pair(const void* x, int64_t ldx, int64_t n, int32_t d_in, const voi
                   const float* bias0, const void* w1, int64_t ldw1, const float* bias1, int32_t d_out, int32_t dtype,
                   void* y0, int64_t ldy0, void* y1, int64_t ldy1, const float* shift0, float* stats0, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * T4 — the general Linear: every shape the streaming kernels above do not take (csrc/gemm.hip; r05).   Replaces
+ * F.linear / addmm / matmul for large/ours.py:77,:198 with input widths such as f = 1433 (Cora, medium/ours.py:133-145) or
+ * widths that are not multiples of 4, the multi-head projections :123-126, medium/models.py GCNConv's x @ weight, the dX of
+ * any of them — no Linear of the path leaves this library, whatever its shape:
+ *     c[i, j] = alpha * sum_k A(i, k) B(k, j) + bias[j] + beta * addend[i, j]          i < m, j < n
+ *     A(i, k) = a[i * a_rs + k * a_cs],   B(k, j) = b[k * b_rs + j * b_cs]             (element strides: any transposition)
+ * y = x W^T + b : a = x (a_rs = ldx, a_cs = 1), b = W (b_rs = 1, b_cs = ldw);   dx = g W : b = W (b_rs = ldw, b_cs = 1).
+ * Any m, n, k, any alignment.  Both operands bf16: bf16 matrix cores (exact products, fp32 sums); otherwise the exact-fp32
+ * matrix cores (a bf16 operand is widened).  alpha_dev (nullable): a DEVICE scalar multiplied into alpha; bias fp32 [n] or
+ * NULL; addend [m, n] (ldadd, add_dtype) or NULL, may alias c.  64 x 64 output tile per workgroup; not split over k
+ * (node reductions such as dW = g^T x belong on sgf_gram).
+ * ------------------------------------------------------------------------------------------ */
+int sgf_gemm(const void* a, int64_t a_rs, int64_t a_cs, int32_t a_dtype, const void* b, int64_t b_rs, int64_t b_cs,
+             int32_t b_dtype, int64_t m, int32_t n, int64_t k, float alpha, const float* alpha_dev, const float* bias,
+             float beta, const void* addend, int64_t ldadd, int32_t add_dtype, void* c, int64_t ldc, int32_t c_dtype,
+             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T7 — branch combine alone.   large/ours.py:269-270:  y = gw * x2 + (1 - gw) * x1.

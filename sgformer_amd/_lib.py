@@ -68,6 +68,8 @@ SIGNATURES = {
                                           c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_gather_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                   c_int32, _P]),
+    "sgf_pad_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_int64, c_int32, c_int32, _P, c_int64,
+                               c_int32, _P]),
     "sgf_attn_stats_len": (c_int64, [c_int32, c_int32]),
     "sgf_attn_bstats_len": (c_int64, [c_int32, c_int32]),
     "sgf_attn_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
@@ -93,6 +95,12 @@ SIGNATURES = {
                                                _P]),
     "sgf_attn_h_bwd_post": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P, c_int64, _P,
                                       c_int64, _P]),
+    "sgf_attn_h_small_saved_bytes": (c_size_t, [c_int32, c_int32]),
+    "sgf_attn_h_small_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "sgf_attn_h_small_fwd": (c_int32, [_P, c_int64, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32,
+                                       _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_attn_h_small_bwd": (c_int32, [_P, c_int64, _P, _P, _P, c_float, c_int32, c_int32, _P, c_size_t, _P, c_int64, _P,
+                                       _P, _P, _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     "sgf_gram_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sgf_gram": (c_int32, [_P, c_int64, c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P,
                            _P, c_size_t, _P]),
@@ -168,6 +176,8 @@ SIGNATURES = {
     "sgf_stem_pair_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "sgf_stem_pair": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, _P, c_int32, c_int32, _P,
                                 c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "sgf_gemm": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, c_int64, c_int32, c_int64, c_int32, c_int64, c_float,
+                           _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64, c_int32, _P]),
     "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
                             c_int64, _P]),
 }

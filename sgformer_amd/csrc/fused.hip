@@ -1281,6 +1281,58 @@ extern "C" int sgf_gather_rows(const void* src, int64_t lds, int32_t src_dtype, 
   return SGF_OK;
 }
 
+// dst[i, :d] = src[idx ? idx[i] : i, :d] (storage change allowed), dst[i, d:d_pad] = 0 — the module-entry copy of node
+// features whose width is not a multiple of 4 (pokec: f = 65, Cora: f = 1433): one scalar-granular pass ONCE per feature
+// tensor, after which every kernel sees 8- / 16-byte aligned rows.  Lanes walk the destination row, so stores coalesce and
+// the (unaligned) source rows are read contiguously.
+namespace sgf {
+namespace {
+template <typename TS, typename TD, typename TI>
+__global__ __launch_bounds__(kThreads) void k_pad_rows(const TS* __restrict__ src, int64_t lds, const TI* __restrict__ idx,
+                                                       int64_t n_src, int64_t n_out, int d, int d_pad, TD* __restrict__ dst,
+                                                       int64_t ldd) {
+  const int64_t total = n_out * d_pad;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t row = i / d_pad;
+    const int col = static_cast<int>(i % d_pad);
+    float v = 0.f;
+    if (col < d) {
+      const int64_t r = idx ? static_cast<int64_t>(idx[row]) : row;
+      if (r >= 0 && r < n_src) v = load1<TS>(src + r * lds + col);
+    }
+    store1<TD>(dst + row * ldd + col, v);
+  }
+}
+}  // namespace
+}  // namespace sgf
+
+extern "C" int sgf_pad_rows(const void* src, int64_t lds, int32_t src_dtype, int64_t n_src, const void* idx,
+                            int32_t idx_is_int64, int64_t n_out, int32_t d, int32_t d_pad, void* dst, int64_t ldd,
+                            int32_t dst_dtype, void* stream) {
+  using namespace sgf;
+  SGF_REQUIRE(n_out >= 0 && d >= 0 && d_pad >= d && n_src >= 0, SGF_E_INVALID, "sgf_pad_rows: bad sizes");
+  SGF_REQUIRE((src_dtype == SGF_F32 || src_dtype == SGF_BF16) && (dst_dtype == SGF_F32 || dst_dtype == SGF_BF16),
+              SGF_E_INVALID, "sgf_pad_rows: unknown dtype");
+  if (n_out == 0 || d_pad == 0) return SGF_OK;
+  SGF_REQUIRE(src && dst && lds >= d && ldd >= d_pad, SGF_E_INVALID, "sgf_pad_rows: bad pointer / ld");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(ew_grid(n_out * d_pad));
+#define SGF_PAD(TS_, TD_, TI_)                                                                                      \
+  hipLaunchKernelGGL((k_pad_rows<TS_, TD_, TI_>), grid, dim3(kThreads), 0, st, static_cast<const TS_*>(src), lds, \
+                     static_cast<const TI_*>(idx), n_src, n_out, d, d_pad, static_cast<TD_*>(dst), ldd)
+#define SGF_PAD_I(TS_, TD_) \
+  do { if (idx && idx_is_int64) SGF_PAD(TS_, TD_, int64_t); else SGF_PAD(TS_, TD_, int32_t); } while (0)
+  if (src_dtype == SGF_F32 && dst_dtype == SGF_F32) SGF_PAD_I(float, float);
+  else if (src_dtype == SGF_F32) SGF_PAD_I(float, uint16_t);
+  else if (dst_dtype == SGF_F32) SGF_PAD_I(uint16_t, float);
+  else SGF_PAD_I(uint16_t, uint16_t);
+#undef SGF_PAD_I
+#undef SGF_PAD
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
 extern "C" int sgf_sum_n(const void* const* xs, const int64_t* lds, int32_t k, int64_t n, int32_t d,
                          int32_t dtype, void* y, int64_t ldy, void* stream) {
   int rc = check_ew("sgf_sum_n", n, d, dtype);

@@ -337,6 +337,85 @@ class HipKernels:
                       _stream(src.device))
         return out
 
+    @staticmethod
+    def pad_rows(src: torch.Tensor, idx: Optional[torch.Tensor], d_pad: int, out_dtype=None) -> torch.Tensor:
+        """out[i, :d] = src[idx[i] if idx is given else i, :d], out[i, d:d_pad] = 0, optionally cast fp32 <-> bf16 — the
+        aligned copy of features whose width is not a multiple of 4 (sgf_pad_rows)."""
+        if src.stride(-1) != 1:
+            src = src.contiguous()
+        n_out = int(src.shape[0] if idx is None else idx.numel())
+        d = src.shape[1]
+        out = torch.empty((n_out, d_pad), dtype=out_dtype or src.dtype, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.call("sgf_pad_rows", _ptr(src), src.stride(0), _code(src), src.shape[0], _ptr(idx),
+                      int(idx is not None and idx.dtype == torch.int64), n_out, d, d_pad, _ptr(out), out.stride(0),
+                      _code(out), _stream(src.device))
+        return out
+
+    # ---- T4: the general Linear (any shape, any alignment; csrc/gemm.hip) ----
+    @staticmethod
+    def gemm(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, out_dtype=None, alpha: float = 1.0, alpha_dev=None,
+             beta: float = 0.0, addend=None) -> torch.Tensor:
+        """out[m, n] = alpha * a[m, k] @ b[k, n] + bias + beta * addend — a, b any 2-D VIEWS (strides are passed on, so
+        x @ w.t() costs no copy), fp32 or bf16 storage each; out: given, or new in out_dtype (default: a's dtype)."""
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise RuntimeError(f"gemm: inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)}")
+        dev = a.device
+        if out is None:
+            out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=dev)
+        elif out.stride(-1) != 1 and n > 1:
+            raise RuntimeError("gemm: out must have contiguous rows")
+        if addend is not None and (addend.stride(-1) != 1 and n > 1):
+            addend = addend.contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gemm", _ptr(a), a.stride(0), a.stride(1), _code(a), _ptr(b), b.stride(0), b.stride(1), _code(b),
+                      m, n, k, float(alpha), _ptr(alpha_dev), _ptr(bias), float(beta), _ptr(addend),
+                      0 if addend is None else max(addend.stride(0), n), 0 if addend is None else _code(addend),
+                      _ptr(out), max(out.stride(0), n), _code(out), _stream(dev))
+        return out
+
+    # ---- T3: the d x d algebra of the attention as one call each way (csrc/attn_small.hip) ----
+    @staticmethod
+    def attn_h_small_fwd(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv):
+        """(M [D, d], m [d], w [D], beta [1], saved) from the Gram matrix G = h^T h [D, D], s = sum_n h_n and the three
+        projections' fp32 weights [d, D] / biases [d] (wv None: V = h)."""
+        d, D = wq.shape
+        dev = G.device
+        lib = _lib.load()
+        ws = [t if (t is None or (t.dtype == _F32 and t.is_contiguous())) else t.float().contiguous()
+              for t in (wq, bq, wk, bk, wv, bv)]
+        G = G if (G.dtype == _F32 and G.stride(-1) == 1) else G.float().contiguous()
+        s = s if (s.dtype == _F32 and s.is_contiguous()) else s.float().contiguous()
+        M = torch.empty((D, d), dtype=_F32, device=dev)
+        mwb = torch.empty(d + D + 1, dtype=_F32, device=dev)
+        saved = torch.empty(lib.sgf_attn_h_small_saved_bytes(D, d), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_small_fwd", _ptr(G), G.stride(0), _ptr(s), float(n_rows), float(n_total), _ptr(ws[0]),
+                      _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), _ptr(ws[5]), D, D, d, _ptr(M), d,
+                      _ptr(mwb[:d]), _ptr(mwb[d:d + D]), _ptr(mwb[d + D:]), _ptr(saved), saved.numel(), _stream(dev))
+        return M, mwb[:d], mwb[d:d + D], mwb[d + D:], saved
+
+    @staticmethod
+    def attn_h_small_bwd(dM, dw, dm, dbeta, n_total: float, saved, d_in: int, d_out: int, want_v: bool = True):
+        """(D = dG + dG^T [D, D], ds [D], gwq, gbq, gwk, gbk, gwv | None, gbv | None) from the reduced gradients of
+        M, w, m, beta (the blocks of hstats) and what attn_h_small_fwd saved."""
+        D, d = d_in, d_out
+        dev = dM.device
+        lib = _lib.load()
+        ws = _workspace(dev, "attn_small", lib.sgf_attn_h_small_workspace_bytes(D, d))
+        Dm = torch.empty((D, D), dtype=_F32, device=dev)
+        ds = torch.empty(D, dtype=_F32, device=dev)
+        gw = torch.empty((3 if want_v else 2, d, D), dtype=_F32, device=dev)
+        gb = torch.empty((3 if want_v else 2, d), dtype=_F32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sgf_attn_h_small_bwd", _ptr(dM), dM.stride(0), _ptr(dw), _ptr(dm), _ptr(dbeta), float(n_total), D, d,
+                      _ptr(saved), saved.numel(), _ptr(Dm), D, _ptr(ds), _ptr(gw[0]), _ptr(gb[0]), _ptr(gw[1]), _ptr(gb[1]),
+                      _ptr(gw[2]) if want_v else None, _ptr(gb[2]) if want_v else None, D, _ptr(ws), ws.numel(),
+                      _stream(dev))
+        return Dm, ds, gw[0], gb[0], gw[1], gb[1], (gw[2] if want_v else None), (gb[2] if want_v else None)
+
     # ---- T3 ----  q, k: [n, H*d] views (ld = stride(0)); v: [n, Hv*d]
     @staticmethod
     def attn_fwd_reduce(q, k, v, heads: int, v_heads: int, d: int) -> torch.Tensor:
@@ -1465,111 +1544,53 @@ def attention(qkv: torch.Tensor, v_ext: Optional[torch.Tensor], heads: int, d: i
 # ------------------------------------------------------------------------------------------------
 # T3 + T4 fused: attention straight from the un-projected input (H = 1, query == source)
 # ------------------------------------------------------------------------------------------------
-class _SmallGemms:
-    """The d x d algebra is ~20 fp32 GEMMs of 256^3 per step.  hipBLASLt's pick for that shape runs
-    63 us, rocBLAS's 6.8 us (measured on MI355X, ROCm 7.2), while for the [N, 256] x [256, 256] bf16
-    GEMMs hipBLASLt is the faster library — so prefer rocBLAS only inside this block.  The flag is
-    process-wide; forward and backward are each issued by one host thread, so there is no race."""
+class _MM(torch.autograd.Function):
+    """a @ b for small fp32 matrices on sgf_gemm (csrc/gemm.hip), differentiable: the d x d algebra's products stay inside
+    libsgf.so also where autograd differentiates it (DIFFormer's sum_v form, the test references)."""
 
-    def __enter__(self):
-        self.prev = None
-        if K.name == "hip":
-            self.prev = torch.backends.cuda.preferred_blas_library()
-            torch.backends.cuda.preferred_blas_library("cublas")     # = rocBLAS on ROCm
-        return self
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return K.gemm(a, b)
 
-    def __exit__(self, *exc):
-        if self.prev is not None:
-            torch.backends.cuda.preferred_blas_library(self.prev)
-        return False
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = K.gemm(g, b.t()) if ctx.needs_input_grad[0] else None
+        gb = K.gemm(a.t(), g) if ctx.needs_input_grad[1] else None
+        return ga, gb
 
 
-def _attn_h_small(G, s, n_rows: float, n_total: float, wq, bq, wk, bk, wv, bv, sum_v: bool = False):
-    """The d x d algebra of include/sgf.h (sgf_attn_h_*): fp32, tiny, differentiable torch ops.
-    G = h^T h, s = sum_n h_n over ALL rows (n_rows of them); weights [d, d_in], biases [d].
-    sum_v=False: SGFormer's numerator  q S + N V_n   (large/ours.py:137-138);
-    sum_v=True : DIFFormer's numerator q S + sum_l V_l (medium/difformer.py:26-29)."""
-    wk_s, wv_s, wq_s = wk @ s, wv @ s, wq @ s
-    s0 = wk @ G @ wv.t() + torch.outer(wk_s, bv) + torch.outer(bk, wv_s) + n_rows * torch.outer(bk, bv)
-    z0 = wk_s + n_rows * bk
-    ssq_q = ((wq @ G) * wq).sum() + 2.0 * torch.dot(bq, wq_s) + n_rows * torch.dot(bq, bq)
-    ssq_k = ((wk @ G) * wk).sum() + 2.0 * torch.dot(bk, wk_s) + n_rows * torch.dot(bk, bk)
-    c = 1.0 / (torch.sqrt(ssq_q) * torch.sqrt(ssq_k))
-    if sum_v:
-        M = c * (wq.t() @ s0)
-        m = c * (bq @ s0) + wv_s + n_rows * bv
-    else:
-        M = c * (wq.t() @ s0) + n_total * wv.t()
-        m = c * (bq @ s0) + n_total * bv
-    w = c * (wq.t() @ z0)
-    beta = (c * torch.dot(bq, z0) + n_total).reshape(1)
-    return M.contiguous(), m.contiguous(), w.contiguous(), beta.contiguous()
+def mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Matrix product of two 2-D tensors (views welcome: strides are passed through) on sgf_gemm."""
+    return _MM.apply(a, b)
 
 
 def _attn_h_small_packed(Gt, Wqk, Wv, n_total: float, sum_v: bool = False):
-    """_attn_h_small on the AUGMENTED operands — the same algebra in 12 launches instead of ~45 (and ~30 instead of ~110
-    in its autograd backward; at 4.6 us per tiny launch the one-by-one form cost 0.9 ms of every training step):
+    """The d x d algebra of include/sgf.h (sgf_attn_h_*) on AUGMENTED operands, as differentiable torch ops whose products
+    run on sgf_gemm (mm) — the form DIFFormer's sum_v numerator takes (no recipe's hot path); SGFormer's own numerator runs
+    as sgf_attn_h_small_fwd / _bwd (csrc/attn_small.hip), whose formulation this is (tests/attn_algebra.py holds the
+    term-by-term restatement both are checked against):
         Gt  = [[G, s], [s^T, n_rows]]   = ht^T ht for ht = [h | 1]          [(D + 1) x (D + 1)]
         Wqk = [[wq | bq], [wk | bk]]                                        [2 d x (D + 1)]
         Wv  = [wv | bv]                                                     [d x (D + 1)]
     so that  K^T V = (Wk~ Gt) Wv~^T  (all four bias terms included),  K^T 1 = (Wk~ Gt)[:, D],  ||Q||_F^2 = sum((Wq~ Gt) * Wq~)
     and one product  Wq~^T [K^T V | K^T 1]  carries  wq^T s0, bq s0, wq^T z0 and bq . z0  in its blocks.
-    Returns (M [D, d], m [d], w [D], beta [1]) as _attn_h_small does."""
+    Returns (M [D, d], m [d], w [D], beta [1])."""
     d = Wv.shape[0]
     D = Gt.shape[0] - 1
-    PG = Wqk @ Gt                                        # [2 d, D + 1]
+    PG = mm(Wqk, Gt)                                       # [2 d, D + 1]
     ssq = (PG * Wqk).view(2, -1).sum(1)                  # ||Q||^2, ||K||^2
     c = torch.rsqrt(ssq[0] * ssq[1])                     # (not ssq.prod(): its backward looks for zeros on the HOST)
     PK = PG[d:]
-    SZ = torch.cat([PK @ Wv.t(), PK[:, D:]], 1)          # [s0 | z0]   [d, d + 1]
-    U = (Wqk[:d].t() @ SZ) * c                           # rows :D = wq^T [s0 | z0], row D = bq [s0 | z0]
+    SZ = torch.cat([mm(PK, Wv.t()), PK[:, D:]], 1)          # [s0 | z0]   [d, d + 1]
+    U = mm(Wqk[:d].t(), SZ) * c                          # rows :D = wq^T [s0 | z0], row D = bq [s0 | z0]
     if sum_v:
-        Mm = torch.cat([U[:D, :d], (U[D, :d] + Wv @ Gt[:, D])[None]], 0)
+        Mm = torch.cat([U[:D, :d], (U[D, :d] + mm(Wv, Gt[:, D:]).view(-1))[None]], 0)
     else:
         Mm = torch.add(U[:, :d], Wv.t(), alpha=n_total)  # rows :D = M, row D = m
     wb = U[:, d].contiguous()
     return Mm[:D], Mm[D], wb[:D], wb[D:] + n_total
-
-
-def _attn_h_packed_fwd(Gt, Wqk, Wv, n_total: float):
-    """_attn_h_small_packed(sum_v=False) WITHOUT autograd, keeping what its hand-written backward needs:
-    Out = c Wq~^T (Wk~ Gt) Vx + n_total Vx with Vx = [Wv~^T | e_D]; M, m, w, beta are the blocks of Out."""
-    d = Wv.shape[0]
-    E = Gt.shape[0]
-    D = E - 1
-    PG = Wqk @ Gt
-    ssq = (PG * Wqk).view(2, -1).sum(1)
-    c = torch.rsqrt(ssq[0] * ssq[1])
-    Vx = torch.zeros((E, d + 1), dtype=Gt.dtype, device=Gt.device)
-    Vx[:, :d] = Wv.t()
-    Vx[D, d:].fill_(1.0)                                 # (fill_, not `= 1.0`: a Python scalar assignment is a syncing H2D copy)
-    SZ = PG[d:] @ Vx                                     # [s0 | z0]
-    T = Wqk[:d].t() @ SZ
-    Out = torch.addcmul(Vx * n_total, T, c)
-    return Out, (PG, ssq, c, Vx, SZ, T)
-
-
-def _attn_h_packed_bwd(Gt, Wqk, Wv, n_total: float, saved, gOut):
-    """Gradients of the packed operands from gOut [(D + 1) x (d + 1)] (the gradients of M, m, w, beta in Out's blocks):
-    20 launches, none of autograd's zero-filled slice gradients.  With Gt symmetric:
-        gT = c gOut, gc = <gOut, T>, (g_sq, g_sk) = -gc c / (2 ssq)
-        gWq~ = SZ gT^T + 2 g_sq PQ... (PQ = Wq~ Gt enters twice: through ||Q||^2 directly and through Gt's symmetry)"""
-    PG, ssq, c, Vx, SZ, T = saved
-    d = Wv.shape[0]
-    gc = torch.dot(gOut.reshape(-1), T.reshape(-1))
-    gs = (gc * c * -0.5) / ssq                           # [g_sq, g_sk]
-    gT = gOut * c
-    Wq = Wqk[:d]
-    gSZ = Wq @ gT                                        # [d, d + 1]
-    gs2 = gs.repeat_interleave(d)[:, None]               # [2 d, 1]
-    gPG = gs2 * Wqk                                      # [g_sq Wq~ ; g_sk Wk~]
-    gPG[d:] += gSZ @ Vx.t()                              # + the path through K^T V and K^T 1
-    gWqk = torch.addmm(gs2 * PG, gPG, Gt)                # PG = Wqk Gt: gPG Gt^T (Gt symmetric) + the direct <PG, Wqk> term
-    gWqk[:d] += SZ @ gT.t()
-    gGt = Wqk.t() @ gPG
-    gVx = torch.addmm(gOut * n_total, PG[d:].t(), gSZ)   # Vx enters twice: SZ = PK Vx and the n_total Vx term
-    gWv = gVx[:, :d].t()
-    return gGt, gWqk, gWv
 
 
 def _attn_h_pack(G, s, n_rows: float, wq, bq, wk, bk, wv, bv):
@@ -1615,19 +1636,15 @@ class _AttentionFromInput(torch.autograd.Function):
         # the d x d algebra on packed operands, recorded ONCE: the backward differentiates this graph instead of re-running it
         di = f32[0].shape[1]
         if sum_v:           # DIFFormer's numerator: the autograd form (no recipe's hot path)
-            with torch.enable_grad(), _SmallGemms():
+            with torch.enable_grad():
                 leaves = [t.requires_grad_(True) for t in _attn_h_pack(G, s, n_rows, *f32)]
                 small = _attn_h_small_packed(*leaves, n_total, sum_v=True)
             M, m, w, beta = (t.detach().contiguous() for t in small)
             ctx.small = (leaves, small, None)
-        else:               # forward and backward written out: 12 + 20 launches, nothing recorded
-            with _SmallGemms():
-                packed = _attn_h_pack(G, s, n_rows, *f32)
-                Out, saved = _attn_h_packed_fwd(*packed, n_total)
-            do = f32[0].shape[0]
-            M, m = Out[:di, :do].contiguous(), Out[di, :do].contiguous()
-            w, beta = Out[:di, do].contiguous(), Out[di:, do].contiguous()
-            ctx.small = (packed, None, saved)
+        else:               # ONE library call each way (sgf_attn_h_small_fwd / _bwd: 6 + 9 launches, csrc/attn_small.hip)
+            M, m, w, beta, saved = K.attn_h_small_fwd(G, s, n_rows, n_total, f32[0], f32[1], f32[2], f32[3],
+                                                      None if wv is None else f32[4], None if wv is None else f32[5])
+            ctx.small = (None, None, saved)
         out, den = K.attn_h_fwd(h, M, m, w, beta)
         ctx.save_for_backward(h, out, den, G, s, M, w, *f32)
         ctx.meta = (n_rows, n_total, shard, wv is None,
@@ -1654,21 +1671,16 @@ class _AttentionFromInput(torch.autograd.Function):
         # G, s and the six parameters are blocks of the packed ones
         leaves, small, saved = ctx.small
         do, di = f32[0].shape
-        with _SmallGemms():
-            if saved is None:
-                gGt, gWqk, gWv = torch.autograd.grad(small, leaves, grad_outputs=(dM, dm, dw_, dbeta), retain_graph=True)
-            else:
-                gOut = torch.empty((di + 1, do + 1), dtype=_F32, device=h.device)
-                gOut[:di, :do] = dM
-                gOut[di, :do] = dm
-                gOut[:di, do] = dw_
-                gOut[di, do:] = dbeta
-                gGt, gWqk, gWv = _attn_h_packed_bwd(*leaves, n_total, saved, gOut)
-        Dm = gGt[:di, :di]
-        D = (Dm + Dm.t()).contiguous()
-        ds = gGt[:di, di] + gGt[di, :di]
-        grads = (None, None, gWqk[:do, :di].contiguous(), gWqk[:do, di].contiguous(), gWqk[do:, :di].contiguous(),
-                 gWqk[do:, di].contiguous(), gWv[:, :di].contiguous(), gWv[:, di].contiguous())
+        if saved is None:       # DIFFormer's sum_v form: the graph the forward recorded (products on sgf_gemm through mm)
+            gGt, gWqk, gWv = torch.autograd.grad(small, leaves, grad_outputs=(dM, dm, dw_, dbeta), retain_graph=True)
+            Dm = gGt[:di, :di]
+            D = (Dm + Dm.t()).contiguous()
+            ds = gGt[:di, di] + gGt[di, :di]
+            grads = (None, None, gWqk[:do, :di].contiguous(), gWqk[:do, di].contiguous(), gWqk[do:, :di].contiguous(),
+                     gWqk[do:, di].contiguous(), gWv[:, :di].contiguous(), gWv[:, di].contiguous())
+        else:
+            D, ds, *pgr = K.attn_h_small_bwd(dM, dw_, dm, dbeta, n_total, saved, di, do, want_v=not v_is_h)
+            grads = (None, None, *pgr)
         # the other gradient of h (the residual branch's, parked by a GradTap that ran before this node) is added in
         # the last pass instead of by autograd's separate three-tensor add
         extra = None
@@ -2056,8 +2068,9 @@ def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:
 # ------------------------------------------------------------------------------------------------
 # T4: the Linear layers  y = x W^T + b  (large/ours.py:123-126, :36-40, :77, :198, :275).
 # bf16 storage, square layers of width 64 / 128 / 256 (and pairs [x1 | x2] of them): forward, the BatchNorm column sums of
-# the output and dX on the streaming row kernels (sgf_gcn_epilogue_*, csrc/rowgemm.hip); other shapes and fp32 storage:
-# forward and dX on hipBLASLt (plain library GEMMs).  The weight / bias gradients
+# the output and dX on the streaming row kernels (sgf_gcn_epilogue_*, csrc/rowgemm.hip); fp32 storage, widths % 4 up to 256:
+# the exact-fp32 streaming kernel (csrc/linear_f32.hip); EVERY other shape: the general matrix-core kernel sgf_gemm
+# (csrc/gemm.hip) — no Linear of the path is a library GEMM.  The weight / bias gradients
 #     dW = dY^T X   (a d x d <- [N x d]^T [N x d] reduction over all nodes),   db = colsum(dY)
 # always run on sgf_gram: hipBLASLt's kernels for that shape ran at 0.7 TB/s (3.6 ms per call at
 # ogbn-products scale, profiles/r01_products_bf16_kernel_stats.md) and ATen's column reduction for
@@ -2073,7 +2086,6 @@ class _Linear(torch.autograd.Function):
         K.check(*xs)
         dt = xs[0].dtype
         wc = w if w.dtype == dt else w.to(dt)
-        bc = None if b is None else (b if b.dtype == dt else b.to(dt))
         widths = [x.shape[1] for x in xs]
         if sum(widths) != w.shape[1]:
             raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
@@ -2088,15 +2100,15 @@ class _Linear(torch.autograd.Function):
                 y = _linear_with_stats(xr, wc, b32, stats_req)
             else:
                 y, _ = _streaming_linear(xr, wc, b32)
-        elif len(xs) == 1:
-            y = torch.nn.functional.linear(xs[0], wc, bc)
         else:
-            # first operand with the bias, the rest accumulated IN PLACE (torch.addmm(y, ...) out of
-            # place first copies y into the result: a 1.25 GB memcpy per call at products scale)
-            y = torch.addmm(bc, xs[0], wc[:, :widths[0]].t()) if bc is not None else xs[0] @ wc[:, :widths[0]].t()
+            # any other shape (input widths beyond 256 or not multiples of 4, odd hidden widths, multi-head projections):
+            # the general matrix-core kernel (sgf_gemm, csrc/gemm.hip) — first operand with the bias, the rest accumulated
+            # IN PLACE; W's column blocks are passed as strided views (no copy, no transposition)
+            b32 = None if b is None else b.detach().float().contiguous()
+            y = K.gemm(xs[0], wc[:, :widths[0]].t(), bias=b32)
             off = widths[0]
             for x, k in zip(xs[1:], widths[1:]):
-                y.addmm_(x, wc[:, off:off + k].t())
+                K.gemm(x, wc[:, off:off + k].t(), out=y, beta=1.0, addend=y)
                 off += k
         if stats_req is not None and not fused:
             stats_req["out"] = batch_stats(y, stats_req.get("shard"))
@@ -2117,7 +2129,7 @@ class _Linear(torch.autograd.Function):
             elif _streaming_linear_ok(g, wc[:, off:off + k], dx=True):
                 dxs.append(K.gcn_epilogue_dx(_rows16(g), wc[:, off:off + k]))
             else:
-                dxs.append(g @ wc[:, off:off + k])
+                dxs.append(K.gemm(g, wc[:, off:off + k]))
             off += k
         dw, db = _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype)
         return (dw, db, None, *dxs)
@@ -2199,7 +2211,10 @@ class _StemPair(torch.autograd.Function):
                                        ctx.needs_input_grad[2] and bd0 is not None, wd0, bd0)
         dw1, db1 = _linear_param_grads(g1.contiguous(), [x], k, ctx.needs_input_grad[3],
                                        ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
-        dx = (g0 @ w0c + g1 @ w1c) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(g0.contiguous(), w0c)
+            K.gemm(g1.contiguous(), w1c, out=dx, beta=1.0, addend=dx)
         return dx, dw0, db0, dw1, db1, None
 
 
@@ -2306,7 +2321,8 @@ class _StemPairBN(torch.autograd.Function):
                 if gl is None:
                     raise NotImplementedError("features that require a gradient behind the fused LayerNorm stem: set "
                                               "SGF_STEM_LN_FUSED=0")
-            dx = dz @ w0c + gl @ w1c
+            dx = K.gemm(dz, w0c)
+            K.gemm(gl.contiguous(), w1c, out=dx, beta=1.0, addend=dx)
         return dx, dw0, db0, dw1, db1, dgamma, dbeta, None, None, dlg, dlb, None
 
 
@@ -2517,8 +2533,8 @@ def linear_bn_act_res(y, x0, w, b, gamma, beta, bn_hook, relu, use_res, shard, c
 
 
 def linear(x, w, b):
-    """nn.Linear: square bf16 layers on the streaming row-GEMM (sgf_gcn_epilogue_stats / _dx), the rest
-    on hipBLASLt; weight / bias gradients on sgf_gram."""
+    """nn.Linear: square bf16 layers / fp32 layers up to 256 wide on the streaming row kernels (sgf_gcn_epilogue_stats / _dx),
+    every other shape on sgf_gemm; weight / bias gradients on sgf_gram."""
     return _Linear.apply(w, b, None, x)
 
 

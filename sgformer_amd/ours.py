@@ -60,11 +60,20 @@ def _side_stream(device):
     return s
 
 
+def _stem_w(lin: nn.Linear, x):
+    """lin.weight for an input SGFormer.forward zero-padded to a multiple of 4 columns (pokec: f = 65 -> 68; sgf_pad_rows):
+    zero weight columns for the padding, differentiable — autograd slices dW back to the parameter's shape."""
+    pad = x.shape[1] - lin.weight.shape[1]
+    if pad < 0:
+        raise RuntimeError(f"input has {x.shape[1]} features, the layer expects {lin.weight.shape[1]}")
+    return lin.weight if pad == 0 else F.pad(lin.weight, (0, pad))
+
+
 def _lin(x, lin: nn.Linear):
     """nn.Linear in the activation dtype: fp32 master weights are cast per call when the model runs
-    with bf16 activations (`SGFormer.compute_dtype`).  Forward / dX on the streaming row kernels (bf16, square
-    layers) or hipBLASLt, dW / db on sgf_gram (ops.linear)."""
-    return ops.linear(x, lin.weight, lin.bias)
+    with bf16 activations (`SGFormer.compute_dtype`).  Forward / dX on the streaming row kernels (bf16 square
+    layers, fp32 layers up to 256 wide) or the general matrix-core kernel sgf_gemm, dW / db on sgf_gram (ops.linear)."""
+    return ops.linear(x, _stem_w(lin, x), lin.bias)
 
 
 def _drop(x, p, training, res=None):
@@ -580,39 +589,51 @@ class SGFormer(nn.Module):
             repart = shard.repartition_for(edge_index)
             if repart is not None:
                 x, edge_index = repart.to_new(x), repart.edge_index
-        if view is not None and view.perm is not None:
-            if x.requires_grad:
+        # Entry copy of the features: row permutation (re-ordered graph), storage cast, and zero-padding of a width that is
+        # not a multiple of 4 (pokec: 65 -> 68) — ONE pass (sgf_gather_rows / sgf_pad_rows).  Full-graph training hands in
+        # the SAME feature tensor every step: the copy is kept, keyed on the tensor's identity and version (the key tensor is
+        # pinned so that a recycled data_ptr cannot alias it).
+        perm = view.perm if view is not None else None
+        f = x.shape[1]
+        fp = (f + 3) // 4 * 4
+        pad = fp != f and not x.requires_grad and hasattr(ops.K, "pad_rows")
+        if x.requires_grad:
+            if perm is not None:
                 x = ops.permute_rows(x, view.perm, view.inv, cdt)
-            else:
-                # full-graph training hands in the SAME feature tensor every step: its permuted (and cast) copy is kept
-                # with the view, keyed on the tensor's identity and version (the key tensor is pinned so that a recycled
-                # data_ptr cannot alias it)
-                key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, cdt)
-                hit = getattr(view, "_x_cache", None)
-                if hit is None or hit[0] != key:
-                    hit = (key, ops.permute_rows(x, view.perm, view.inv, cdt), x)
-                    view._x_cache = hit
-                x = hit[1]
-        elif x.dtype != cdt:
-            x = x.to(cdt)
+            elif x.dtype != cdt:
+                x = x.to(cdt)
+        elif perm is not None or pad or x.dtype != cdt:
+            holder = view if view is not None else self
+            key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, cdt, bool(pad), perm is not None)
+            hit = getattr(holder, "_x_cache", None)
+            if hit is None or hit[0] != key:
+                if pad:
+                    xe = ops.K.pad_rows(x, perm, fp, cdt)
+                elif perm is not None:
+                    xe = ops.permute_rows(x, view.perm, view.inv, cdt)
+                else:
+                    xe = x.to(cdt)
+                hit = (key, xe, x)
+                object.__setattr__(holder, "_x_cache", hit)
+            x = hit[1]
         # K10: the first Linear of both branches reads the same x — one pass, two outputs, the GCN stem's BatchNorm
         # sums on the way (bf16 storage, <= 128 input features)
         stem_t = stem_g = None
         gc, tc = (self.graph_conv if self.use_graph else None), self.trans_conv
-        if (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns") and gc.fused_stem_ok(x)
-                and ops.stem_pair_bn_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
+        both = gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
+        wg, wt = (_stem_w(gc.fcs[0], x), _stem_w(tc.fcs[0], x)) if both else (None, None)
+        if both and gc.fused_stem_ok(x) and ops.stem_pair_bn_supported(x, wg, wt):
             bn0 = gc.bns[0]
             ln = None
-            if getattr(tc, "use_bn", False) and hasattr(tc, "bns") and ops.stem_ln_supported(x, tc.fcs[0].weight):
+            if getattr(tc, "use_bn", False) and hasattr(tc, "bns") and ops.stem_ln_supported(x, wt):
                 # TransConv's stem too: Linear -> LayerNorm -> relu in the same node (its dW comes from sgf_gram_ln_bwd)
                 ln = (tc.bns[0].weight, tc.bns[0].bias, tc.bns[0].eps, True)
-            x0a, x0b, yt = ops.stem_pair_bn(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,
+            x0a, x0b, yt = ops.stem_pair_bn(x, wg, gc.fcs[0].bias, wt, tc.fcs[0].bias,
                                             bn0.weight, bn0.bias, gc._bn_hook(bn0), gc._shard, ln)
             stem_t, stem_g = (("ln", yt) if ln is not None else yt), ("bn", x0a, x0b)
-        elif (gc is not None and hasattr(tc, "fcs") and hasattr(gc, "fcs") and hasattr(gc, "bns")
-                and ops.stem_pair_supported(x, gc.fcs[0].weight, tc.fcs[0].weight)):
+        elif both and ops.stem_pair_supported(x, wg, wt):
             want = gc.use_bn and _uses_batch_stats(gc, gc.bns[0])
-            (yg, yt), st = ops.stem_pair(x, gc.fcs[0].weight, gc.fcs[0].bias, tc.fcs[0].weight, tc.fcs[0].bias,
+            (yg, yt), st = ops.stem_pair(x, wg, gc.fcs[0].bias, wt, tc.fcs[0].bias,
                                          want_stats0=want, shard=gc._shard)
             stem_t, stem_g = yt, (yg, st)
         if self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None:

@@ -177,6 +177,55 @@ class CpuKernels:
         return src[idx.long()].to(out_dtype or src.dtype)
 
     @staticmethod
+    def pad_rows(src, idx, d_pad, out_dtype=None):
+        rows = src if idx is None else src[idx.long()]
+        out = torch.zeros((rows.shape[0], d_pad), dtype=out_dtype or src.dtype)
+        out[:, :src.shape[1]] = rows.to(out.dtype)
+        return out
+
+    # ---- the general Linear (csrc/gemm.hip): fp32 accumulation of exact products, one rounding on the way out ----
+    @staticmethod
+    def gemm(a, b, bias=None, out=None, out_dtype=None, alpha=1.0, alpha_dev=None, beta=0.0, addend=None):
+        al = float(alpha) * (float(alpha_dev) if alpha_dev is not None else 1.0)
+        acc = torch.float64 if a.dtype == torch.float64 else torch.float32     # (fp64: the formulation tests)
+        v = al * (a.to(acc) @ b.to(acc))
+        if bias is not None:
+            v = v + bias.to(acc)
+        if addend is not None:
+            v = v + beta * addend.to(acc)
+        if out is None:
+            return v.to(out_dtype or a.dtype)
+        out.copy_(v.to(out.dtype))
+        return out
+
+    # ---- the d x d algebra of the attention (csrc/attn_small.hip): the packed formulation itself ----
+    @staticmethod
+    def attn_h_small_fwd(G, s, n_rows, n_total, wq, bq, wk, bk, wv, bv):
+        from sgformer_amd import ops
+        from tests import attn_algebra as A
+        d, D = wq.shape
+        if wv is None:
+            wv, bv = torch.eye(D, dtype=torch.float32), torch.zeros(D, dtype=torch.float32)
+        packed = ops._attn_h_pack(G.float(), s.float(), float(n_rows), wq.float(), bq.float(), wk.float(), bk.float(),
+                                  wv.float(), bv.float())
+        Out, saved = A.attn_h_packed_fwd(*packed, float(n_total))
+        return (Out[:D, :d].contiguous(), Out[D, :d].contiguous(), Out[:D, d].contiguous(), Out[D:, d].contiguous(),
+                (packed, saved))
+
+    @staticmethod
+    def attn_h_small_bwd(dM, dw, dm, dbeta, n_total, saved, d_in, d_out, want_v=True):
+        from tests import attn_algebra as A
+        packed, sv = saved
+        D, d = d_in, d_out
+        gOut = torch.empty((D + 1, d + 1), dtype=torch.float32)
+        gOut[:D, :d], gOut[D, :d], gOut[:D, d], gOut[D, d:] = dM, dm, dw, dbeta
+        gGt, gWqk, gWv = A.attn_h_packed_bwd(*packed, float(n_total), sv, gOut)
+        Dm = gGt[:D, :D]
+        return ((Dm + Dm.t()).contiguous(), (gGt[:D, D] + gGt[D, :D]).contiguous(), gWqk[:d, :D].contiguous(),
+                gWqk[:d, D].contiguous(), gWqk[d:, :D].contiguous(), gWqk[d:, D].contiguous(),
+                gWv[:, :D].contiguous() if want_v else None, gWv[:, D].contiguous() if want_v else None)
+
+    @staticmethod
     def lds_rows_max(dtype):
         return 288 if dtype == torch.bfloat16 else 144
 

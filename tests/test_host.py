@@ -731,7 +731,7 @@ def test_launcher_runs_the_trainers_three_loss_lines_in_one_pass():
 
 @pytest.mark.parametrize("sum_v", [False, True])
 @pytest.mark.parametrize("d,d_in", [(8, 8), (16, 12)])
-def test_packed_attention_algebra_matches_the_term_by_term_form(sum_v, d, d_in):
+def test_packed_attention_algebra_matches_the_term_by_term_form(cpu_table, sum_v, d, d_in):
     """ops._attn_h_small_packed (augmented operands, 12 launches) == ops._attn_h_small (include/sgf.h's formulas term by term),
     values and all eight gradients, in fp64 to 1e-12."""
     import torch
@@ -745,7 +745,8 @@ def test_packed_attention_algebra_matches_the_term_by_term_form(sum_v, d, d_in):
     if d != d_in:
         pytest.skip("M = c wq^T s0 + N wv^T needs d == d_in") if not sum_v else None
     leaves = [t.clone().requires_grad_(True) for t in (G, s, *par)]
-    ref = ops._attn_h_small(leaves[0], leaves[1], 50.0, 70.0, *leaves[2:], sum_v=sum_v)
+    from tests import attn_algebra as A
+    ref = A.attn_h_small(leaves[0], leaves[1], 50.0, 70.0, *leaves[2:], sum_v=sum_v)
     cot = [torch.randn(t.shape, generator=g, dtype=torch.float64) for t in ref]
     gref = torch.autograd.grad(ref, leaves, cot)
     old = ops._F32
@@ -779,11 +780,12 @@ def test_long_row_bound_uses_what_the_caller_knows():
 
 
 @pytest.mark.parametrize("d", [5, 8, 16])
-def test_packed_attention_algebra_hand_written_backward(d):
+def test_packed_attention_algebra_hand_written_backward(cpu_table, d):
     """ops._attn_h_packed_fwd / _bwd (what the training step runs: 12 + 20 launches, no autograd graph) == autograd through
     ops._attn_h_small_packed, in fp64 to 1e-12: the four outputs and the gradients of the three packed operands (Gt's through
     the symmetrised form D = dG + dG^T and ds, which is all the caller uses)."""
     from sgformer_amd import ops
+    from tests import attn_algebra as A
     g = torch.Generator().manual_seed(d)
     h = torch.randn(40, d, generator=g, dtype=torch.float64)
     par = [torch.randn(d, d, generator=g, dtype=torch.float64) * 0.3 if i % 2 == 0 else
@@ -797,10 +799,10 @@ def test_packed_attention_algebra_hand_written_backward(d):
         gref = torch.autograd.grad(ref, packed, cot)
         with torch.no_grad():
             pk = [t.detach() for t in packed]
-            out, saved = ops._attn_h_packed_fwd(*pk, 55.0)
+            out, saved = A.attn_h_packed_fwd(*pk, 55.0)
             gout = torch.zeros(d + 1, d + 1, dtype=torch.float64)
             gout[:d, :d], gout[d, :d], gout[:d, d], gout[d, d:] = cot[0], cot[1], cot[2], cot[3]
-            got = ops._attn_h_packed_bwd(*pk, 55.0, saved, gout)
+            got = A.attn_h_packed_bwd(*pk, 55.0, saved, gout)
     finally:
         ops._F32 = old
     for a, b in zip((out[:d, :d], out[d, :d], out[:d, d], out[d:, d]), ref):

@@ -220,6 +220,13 @@ def patch_adam():
 
     def __init__(self, params, *args, **kwargs):
         params = list(params)
+        # a group's 'params' may be a GENERATOR (Adam([{'params': model.parameters()}])): materialise it on a shallow copy of
+        # the group before looking at it, or the optimizer proper would find it exhausted and train nothing
+        for i, grp in enumerate(params):
+            if isinstance(grp, dict) and "params" in grp:
+                grp = dict(grp)
+                grp["params"] = [grp["params"]] if torch.is_tensor(grp["params"]) else list(grp["params"])
+                params[i] = grp
         if "fused" not in kwargs and "foreach" not in kwargs and len(args) < 6:
             flat = [p for grp in params for p in (grp["params"] if isinstance(grp, dict) else [grp])]
             if flat and all(torch.is_tensor(p) and p.is_cuda and p.is_floating_point() for p in flat):

@@ -67,6 +67,25 @@ def _meta_funcs():
 _META = _meta_funcs()
 
 
+_UNIQUE_IDX = {}
+
+
+def _idx_is_unique(idx) -> bool:
+    """Does the 1-D row index hold every row at most once (and no negative, wrapping entries)?  The one-pass kernels STORE a
+    row's gradient (sgf_nll_bwd) and keep one label per node, so `out[idx]` with a repeated row must take ATen's path, which
+    accumulates (idx = [1, 3, 3, 7] gave the right loss and a wrong gradient).  One device reduction + host read
+    per index TENSOR, cached on its identity and version — a full-graph trainer indexes with the same train_idx every step."""
+    key = (idx.data_ptr(), idx._version, idx.numel(), str(idx.device))
+    hit = _UNIQUE_IDX.get(key)
+    if hit is None:
+        n = idx.numel()
+        ok = n == 0 or (int(idx.min()) >= 0 and int(_torch.unique(idx).numel()) == n)
+        if len(_UNIQUE_IDX) >= 16:
+            _UNIQUE_IDX.pop(next(iter(_UNIQUE_IDX)))
+        _UNIQUE_IDX[key] = hit = (bool(ok), idx)          # (the tensor is pinned: a recycled data_ptr cannot alias the key)
+    return hit[0]
+
+
 class LazyLogSoftmax(_torch.Tensor):
     """log_softmax(logits, dim=1) that has not been computed yet (or the rows `idx` of it)."""
 
@@ -74,7 +93,7 @@ class LazyLogSoftmax(_torch.Tensor):
     def __new__(cls, logits, idx=None, orig=None):
         shape = logits.shape if idx is None else (idx.shape[0], logits.shape[1])
         r = _torch.Tensor._make_wrapper_subclass(cls, shape, dtype=logits.dtype, device=logits.device,
-                                                 requires_grad=False)
+                                                 requires_grad=bool(logits.requires_grad))
         r._sgf_logits, r._sgf_idx, r._sgf_orig, r._sgf_cache = logits, idx, orig, None
         return r
 
@@ -90,7 +109,7 @@ class LazyLogSoftmax(_torch.Tensor):
         if (func is _torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], LazyLogSoftmax)
                 and args[0]._sgf_idx is None and args[0]._sgf_cache is None and _torch.is_tensor(args[1])
                 and not isinstance(args[1], LazyLogSoftmax) and args[1].dim() == 1 and args[1].dtype == _torch.long
-                and args[1].device == args[0]._sgf_logits.device):
+                and args[1].device == args[0]._sgf_logits.device and _idx_is_unique(args[1])):
             return LazyLogSoftmax(args[0]._sgf_logits, args[1], args[0]._sgf_orig)
         with _torch._C.DisableTorchFunctionSubclass():
             if func in _META:                  # shape / dtype / device ... live on the wrapper: nothing is computed for them

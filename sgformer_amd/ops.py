@@ -792,6 +792,7 @@ class HipKernels:
         """row_map (int32 permutation): row j of the product is stored as row row_map[j]"""
         n, d = x1.shape
         c = w.shape[0]
+        HipKernels._check_row_map(row_map, n, x1.device)
         logits = torch.empty((n, c), dtype=_F32, device=x1.device)
         with torch.cuda.device(x1.device):
             if row_map is None:
@@ -807,6 +808,7 @@ class HipKernels:
         """row_map: row j of dx1 / dx2 comes from row row_map[j] of g"""
         n, c = g.shape
         d = w.shape[1]
+        HipKernels._check_row_map(row_map, n, g.device)
         dx1 = torch.empty((n, d), dtype=dtype, device=g.device)
         dx2 = torch.empty((n, d), dtype=dtype, device=g.device)
         with torch.cuda.device(g.device):
@@ -819,6 +821,14 @@ class HipKernels:
                           _lib.SGF_BF16, _ptr(dx1), dx1.stride(0), _ptr(dx2), dx2.stride(0), _ptr(row_map),
                           _stream(g.device))
         return dx1, dx2
+
+    @staticmethod
+    def _check_row_map(row_map, n: int, device):
+        """The *_mapped kernels read `const int32_t*`: anything else would scatter rows out of bounds."""
+        if row_map is not None and not (row_map.dtype == torch.int32 and row_map.is_contiguous() and row_map.numel() == n
+                                        and row_map.device == device):
+            raise RuntimeError(f"combine_fc: row_map must be a contiguous int32 permutation of {n} rows on {device}, got "
+                               f"{row_map.dtype} x {tuple(row_map.shape)} on {row_map.device}")
 
     # ---- T6 / K8: Linear (+ BatchNorm statistics) as one streaming pass ----
     @staticmethod
@@ -1004,7 +1014,7 @@ def long_row_segments(rowptr: torch.Tensor, nnz: Optional[int] = None, max_row_l
     sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built) — or, for
     small graphs whose nnz is known on the host, the bound  sum ceil(len/seg) <= nnz/seg + nnz/(LONG_ROW+1)
     without any device read (0 when no row can be long at all).  `max_row_len`: a bound on the longest row the caller
-    knows without looking (a sampled batch: its largest fan-out; any graph: its node count) — at most LONG_ROW means no
+    GUARANTEES without looking (a sampled batch: its largest fan-out; NOT the node count — duplicate edges are kept) — at most LONG_ROW means no
     split path at all (no memset, no extra launches) for that CSR."""
     if rowptr.numel() <= 1:
         return 0
@@ -1056,10 +1066,12 @@ class CSRGraph:
         self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
         self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
-        # longest possible row: the caller's bound (sampling.NeighborSampler marks its batches with their largest fan-out),
-        # else the node count (a row of a coalesced graph has at most n entries)
+        # longest possible row: only a bound the caller GUARANTEES (sampling.NeighborSampler marks its batches with their
+        # largest fan-out).  The node count is no bound: sgf_csr_build keeps duplicate edges (large/ours.py:33 does not
+        # coalesce), so a row of a small multigraph can exceed LONG_ROW entries — without a hint the nnz-based
+        # bound (small graphs) or the exact count from rowptr applies.
         hint = getattr(edge_index, "_sgf_max_in_degree", None)
-        self.long_segments = long_row_segments(self.rowptr, self.nnz, n if hint is None else min(int(hint), n))
+        self.long_segments = long_row_segments(self.rowptr, self.nnz, None if hint is None else int(hint))
         self.t_long_segments = 0
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None

@@ -77,8 +77,15 @@ def _shared_get(kind: str, key_tensors, extra, build):
     return hit[0]
 
 
+# above this worst-case entry count a batch is sampled hop by hop (buffers sized from the real frontier) instead of in one call
+_ONE_CALL_MAX_ENTRIES = 64 << 20
+
+
 class NeighborSampler:
-    """sample(seeds) -> (n_id int64 [nodes], edge_index int64 [2, edges] in local ids, batch_size)."""
+    """sample(seeds) -> (n_id int64 [nodes], edge_index int64 [2, edges] in local ids, batch_size).
+
+    Samplers over the same graph share ONE node -> local-id table and one workspace (`_shared_get`): they must be drawn from
+    one batch at a time on one stream — which is how 100M/nb-sample.py uses its train / valid / test loaders."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, num_neighbors: Sequence[int], seed: int = 0,
                  device: Optional[torch.device] = None):
@@ -105,8 +112,11 @@ class NeighborSampler:
         batch_id = self.batches if batch_id is None else int(batch_id)
         self.batches += 1
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if self._fan_dev is not None:
+        if self._fan_dev is not None and self._batch_capacity(bs) <= _ONE_CALL_MAX_ENTRIES:
             return self._sample_batch(seeds32, bs, batch_id, st)
+        # deep / wide fan-outs: the one-call form sizes every buffer to the worst case bs * (k1 + k1 k2 + ...) BEFORE any
+        # de-duplication (GBs per batch for e.g. [25, 20, 15, 10] at 1024 seeds); hop by hop the buffers follow the
+        # actual frontier
         nodes = [seeds32]
         srcs, dsts = [], []
         with torch.cuda.device(dev):
@@ -125,6 +135,14 @@ class NeighborSampler:
         ei = torch.stack([torch.cat(srcs), torch.cat(dsts)]).long() if srcs else torch.zeros(2, 0, dtype=torch.int64, device=dev)
         ei._sgf_trusted = True          # local ids are in range by construction: ops.CSRGraph skips its host check
         return n_id32.long(), ei, bs
+
+    def _batch_capacity(self, bs: int) -> int:
+        """Worst-case number of sampled entries of one batch: bs * (k1 + k1 k2 + ...)."""
+        total, width = 0, bs
+        for k in self.fanouts:
+            width *= max(k, 0)
+            total += width
+        return total
 
     def _sample_batch(self, seeds32, bs, batch_id, st):
         dev = self.device

@@ -721,6 +721,20 @@ def test_launcher_runs_the_trainers_three_loss_lines_in_one_pass():
         lr, = torch.autograd.grad(full.sum(), logits)
         assert torch.allclose(lg, lr)
         assert not isinstance(F.log_softmax(logits, dim=0), LazyLogSoftmax)                  # other dims: ATen
+        # a row index with REPEATED rows must accumulate per occurrence — ATen's path, not the storing kernels
+        dup = torch.tensor([1, 3, 3, 7, 3, 1])
+        td = label.squeeze(1)[dup]
+        ncall = len(calls)
+        rows = F.log_softmax(logits, dim=1)[dup]
+        got_d = criterion(rows, td)
+        gd, = torch.autograd.grad(got_d, logits)
+        ref_d = nll0(ls0(logits, dim=1)[dup], td)
+        grd, = torch.autograd.grad(ref_d, logits)
+        assert len(calls) == ncall and abs(float(got_d) - float(ref_d)) <= 1e-6 and float((gd - grd).abs().max()) <= 1e-7
+        neg = torch.tensor([-1, 2, 5])                                                       # wrapping (negative) entries too
+        assert torch.allclose(criterion(F.log_softmax(logits, dim=1)[neg], label.squeeze(1)[neg]),
+                              nll0(ls0(logits, dim=1)[neg], label.squeeze(1)[neg])) and len(calls) == ncall
+        assert F.log_softmax(logits, dim=1).requires_grad and not F.log_softmax(logits.detach(), dim=1).requires_grad
         assert not isinstance(F.log_softmax(torch.randn(4, 100), dim=1), LazyLogSoftmax)     # more than 64 classes: ATen
     finally:
         ops.K.nll_fwd = real
@@ -811,3 +825,29 @@ def test_packed_attention_algebra_hand_written_backward(cpu_table, d):
     assert float((sym(got[0]) - sym(gref[0])).abs().max()) <= 1e-12 * max(1.0, float(gref[0].abs().max()))
     for a, b in zip(got[1:], gref[1:]):
         assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max()))
+
+
+def test_patch_adam_keeps_generator_valued_param_groups(monkeypatch):
+    """Adam([{'params': model.parameters()}]) — a GENERATOR inside a group dict — under launch.patch_adam must
+    train every parameter (the patch used to exhaust the generator while looking at it: a group of size 0, silently)."""
+    import torch.nn as nn
+    from sgformer_amd import launch
+    monkeypatch.delenv("SGF_FUSED_ADAM", raising=False)
+    orig = torch.optim.Adam.__init__
+    was = getattr(torch.optim.Adam, "_sgf_patched", False)
+    if was:
+        pytest.skip("Adam already patched in this process")
+    try:
+        launch.patch_adam()
+        m = nn.Linear(3, 2)
+        opt = torch.optim.Adam([{"params": m.parameters(), "weight_decay": 1e-5}], lr=0.1)
+        assert len(opt.param_groups) == 1 and len(opt.param_groups[0]["params"]) == 2
+        opt2 = torch.optim.Adam([{"params": m.weight}, {"params": (p for p in [m.bias])}], lr=0.1)
+        assert [len(g["params"]) for g in opt2.param_groups] == [1, 1]
+        w0 = m.weight.detach().clone()
+        m(torch.ones(1, 3)).sum().backward()
+        opt.step()
+        assert not torch.equal(w0, m.weight.detach())
+    finally:
+        torch.optim.Adam.__init__ = orig
+        torch.optim.Adam._sgf_patched = False

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows */
+#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -400,6 +400,16 @@ int sgf_attn_bwd_apply(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int32_t v_heads, int32_t d, int32_t dtype, const float* stats,
                        float* bstats, void* dq, int64_t lddq, void* dk, int64_t lddk,
                        void* dv, int64_t lddv, void* stream);
+/* The same two calls for PER-HEAD output gradients: full_attention_conv returns [N, H, D] (medium/ours.py:14-46,
+ * 100M/ours.py:12-53) and a caller may differentiate through the heads before any mean.  g: [n, H, d] (ldg >= H * d); head h's
+ * gradient enters as it is (no 1/H).  H = 1 coincides with sgf_attn_bwd_reduce / _apply. */
+int sgf_attn_bwd_reduce_heads(const void* q, int64_t ldq, const void* g, int64_t ldg, const void* o, int64_t ldo,
+                              const float* den, int64_t n, int32_t heads, int32_t d, int32_t dtype, float* bstats,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int sgf_attn_bwd_apply_heads(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* g,
+                             int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n, double n_total,
+                             int32_t heads, int32_t v_heads, int32_t d, int32_t dtype, const float* stats, float* bstats,
+                             void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T3 + T4 fused — attention straight from the un-projected layer input (H = 1, query == source:

@@ -82,6 +82,11 @@ SIGNATURES = {
     "sgf_attn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                                      _P, c_int64, c_double, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                      _P, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "sgf_attn_bwd_reduce_heads": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32,
+                                            c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "sgf_attn_bwd_apply_heads": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
+                                           _P, c_int64, c_double, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                           _P, c_int64, _P, c_int64, _P, c_int64, _P]),
     "sgf_attn_h_bstats_len": (c_int64, [c_int32]),
     "sgf_attn_h_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "sgf_attn_h_bwd_reduce": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32,

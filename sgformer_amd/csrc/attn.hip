@@ -1827,7 +1827,7 @@ int fwd_apply_t(const void* q, int64_t ldq, const void* v, int64_t ldv, int64_t 
 template <typename T>
 int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const void* o, int64_t ldo,
                  const float* den, int64_t n, int heads, int d, float* bstats, void* ws,
-                 hipStream_t st) {
+                 hipStream_t st, bool g_per_head = false) {
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(g, ldg) && aligned4<T>(o, ldo), SGF_E_INVALID,
               "sgf_attn_bwd_reduce: q/g/o must be 4-element aligned with ld %% 4 == 0");
   const int DP = padded_dim(d);
@@ -1841,10 +1841,11 @@ int bwd_reduce_t(const void* q, int64_t ldq, const void* g, int64_t ldg, const v
   }
   ReduceArgs a{};
   a.a = q; a.lda = ldq;
-  a.b = g; a.ldb = ldg;     // g is [n, d]: shared by all heads
+  a.b = g; a.ldb = ldg;     // g is [n, d]: the gradient of the head MEAN, shared by all heads — or [n, H, d] (g_per_head)
   a.q = o; a.ldq = ldo;     // o is [n, H, d] (or out when H == 1)
   a.den = den;
-  a.n = n; a.d = d; a.db = d; a.heads = heads; a.b_heads = 1; a.gscale = 1.f / heads;
+  a.n = n; a.d = d; a.db = d; a.heads = heads;
+  a.b_heads = g_per_head ? heads : 1; a.gscale = g_per_head ? 1.f : 1.f / heads;
   a.partial = static_cast<float*>(ws);
   int rc = launch_reduce<T, kModeBwd>(a, DP, nblk, st);
   if (rc != SGF_OK) return rc;
@@ -1861,7 +1862,7 @@ int bwd_apply_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
                 const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n,
                 double n_total, int heads, int v_heads, int d, const float* stats, float* bstats,
                 void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                hipStream_t st) {
+                hipStream_t st, bool g_per_head = false) {
   SGF_REQUIRE(aligned4<T>(q, ldq) && aligned4<T>(k, ldk) && aligned4<T>(v, ldv) &&
                   aligned4<T>(g, ldg) && aligned4<T>(o, ldo),
               SGF_E_INVALID, "sgf_attn_bwd_apply: operands must be 4-element aligned");
@@ -1878,10 +1879,11 @@ int bwd_apply_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
     ApplyArgs a{};
     a.stats = stats; a.stats_len = slen; a.sdot = bstats + (blen - 1);
     a.n = n; a.d = d; a.heads = heads;
-    a.ntot = static_cast<float>(n_total); a.gscale = 1.f / heads;
+    a.ntot = static_cast<float>(n_total); a.gscale = g_per_head ? 1.f : 1.f / heads;
     a.den = const_cast<float*>(den) + h;
+    const T* gh = static_cast<const T*>(g) + (g_per_head ? ho : 0);     // this head's gradient (or the shared mean gradient)
     // dQ_h = c (dnum S0^T + dden z0) - s Q / ||Q||^2
-    a.a = g; a.lda = ldg;
+    a.a = gh; a.lda = ldg;
     a.a2 = static_cast<const T*>(o) + ho; a.lda2 = ldo;
     a.e = static_cast<const T*>(q) + ho; a.lde = ldq;
     a.out = static_cast<T*>(dq) + ho; a.ldo = lddq;
@@ -1900,7 +1902,7 @@ int bwd_apply_t(const void* q, int64_t ldq, const void* k, int64_t ldk, const vo
     if (rc != SGF_OK) return rc;
     // dV_h = N dnum + c K dS0       (accumulated over heads when V is shared)
     a.a = static_cast<const T*>(k) + ho; a.lda = ldk;
-    a.e = g; a.lde = ldg;
+    a.e = gh; a.lde = ldg;
     a.out = static_cast<T*>(dv) + (v_heads == 1 ? 0 : ho); a.ldo = lddv;
     a.bmat = bstats + static_cast<int64_t>(h) * d * d; a.trans_b = 0;
     a.cvec = nullptr;
@@ -1984,4 +1986,40 @@ extern "C" int sgf_attn_bwd_apply(const void* q, int64_t ldq, const void* k, int
                               v_heads, d, stats, bstats, dq, lddq, dk, lddk, dv, lddv, st);
   return bwd_apply_t<uint16_t>(q, ldq, k, ldk, v, ldv, g, ldg, o, ldo, den, n, n_total, heads,
                                v_heads, d, stats, bstats, dq, lddq, dk, lddk, dv, lddv, st);
+}
+
+// The same backward for PER-HEAD output gradients (full_attention_conv returns [N, H, D], medium/ours.py:14-46, 100M/ours.py:12-53):
+// g is [n, H, d] (ldg >= H * d), head h's gradient enters without the 1/H of the head mean.  H = 1: identical to the above.
+extern "C" int sgf_attn_bwd_reduce_heads(const void* q, int64_t ldq, const void* g, int64_t ldg, const void* o, int64_t ldo,
+                                         const float* den, int64_t n, int32_t heads, int32_t d, int32_t dtype, float* bstats,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_common("sgf_attn_bwd_reduce_heads", n, heads, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(bstats && (n == 0 || (q && g && o && den)), SGF_E_INVALID, "sgf_attn_bwd_reduce_heads: null pointer");
+  SGF_REQUIRE(n == 0 || ldg >= static_cast<int64_t>(heads) * d, SGF_E_INVALID, "sgf_attn_bwd_reduce_heads: ldg < H * d");
+  SGF_REQUIRE(workspace_bytes >= sgf_attn_workspace_bytes(n, heads, d) && workspace, SGF_E_WORKSPACE,
+              "sgf_attn_bwd_reduce_heads: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32)
+    return bwd_reduce_t<float>(q, ldq, g, ldg, o, ldo, den, n, heads, d, bstats, workspace, st, true);
+  return bwd_reduce_t<uint16_t>(q, ldq, g, ldg, o, ldo, den, n, heads, d, bstats, workspace, st, true);
+}
+
+extern "C" int sgf_attn_bwd_apply_heads(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                        const void* g, int64_t ldg, const void* o, int64_t ldo, const float* den, int64_t n,
+                                        double n_total, int32_t heads, int32_t v_heads, int32_t d, int32_t dtype,
+                                        const float* stats, float* bstats, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                                        void* dv, int64_t lddv, void* stream) {
+  int rc = check_common("sgf_attn_bwd_apply_heads", n, heads, d, dtype);
+  if (rc != SGF_OK) return rc;
+  SGF_REQUIRE(v_heads == heads || v_heads == 1, SGF_E_INVALID, "sgf_attn_bwd_apply_heads: v_heads must be H or 1");
+  SGF_REQUIRE(stats && bstats && (n == 0 || (q && k && v && g && o && den && dq && dk && dv)), SGF_E_INVALID,
+              "sgf_attn_bwd_apply_heads: null pointer");
+  SGF_REQUIRE(n == 0 || ldg >= static_cast<int64_t>(heads) * d, SGF_E_INVALID, "sgf_attn_bwd_apply_heads: ldg < H * d");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == SGF_F32)
+    return bwd_apply_t<float>(q, ldq, k, ldk, v, ldv, g, ldg, o, ldo, den, n, n_total, heads, v_heads, d, stats, bstats, dq,
+                              lddq, dk, lddk, dv, lddv, st, true);
+  return bwd_apply_t<uint16_t>(q, ldq, k, ldk, v, ldv, g, ldg, o, ldo, den, n, n_total, heads, v_heads, d, stats, bstats, dq,
+                               lddq, dk, lddk, dv, lddv, st, true);
 }

@@ -441,24 +441,25 @@ class HipKernels:
         return out, den, o_heads
 
     @staticmethod
-    def attn_bwd_reduce(q, g, o, den, heads: int, d: int) -> torch.Tensor:
+    def attn_bwd_reduce(q, g, o, den, heads: int, d: int, per_head: bool = False) -> torch.Tensor:
+        """per_head: g is [n, H * d], the gradients of the per-head outputs (no 1/H), instead of the head mean's [n, d]"""
         n, dev = q.shape[0], q.device
         lib = _lib.load()
         bstats = torch.empty(lib.sgf_attn_bstats_len(heads, d), dtype=_F32, device=dev)
         ws = _workspace(dev, "attn", lib.sgf_attn_workspace_bytes(n, heads, d))
         with torch.cuda.device(dev):
-            _lib.call("sgf_attn_bwd_reduce", _ptr(q), _ld(q), _ptr(g), _ld(g), _ptr(o), _ld(o),
+            _lib.call("sgf_attn_bwd_reduce_heads" if per_head else "sgf_attn_bwd_reduce", _ptr(q), _ld(q), _ptr(g), _ld(g), _ptr(o), _ld(o),
                       _ptr(den), n, heads, d, _code(q), _ptr(bstats), _ptr(ws), ws.numel(),
                       _stream(dev))
         return bstats
 
     @staticmethod
     def attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total: float, heads: int, v_heads: int,
-                       d: int, dq, dk, dv):
+                       d: int, dq, dk, dv, per_head: bool = False):
         """Writes dq, dk, dv (views with row stride = stride(0)) in place."""
         n, dev = q.shape[0], q.device
         with torch.cuda.device(dev):
-            _lib.call("sgf_attn_bwd_apply", _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(g),
+            _lib.call("sgf_attn_bwd_apply_heads" if per_head else "sgf_attn_bwd_apply", _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(v), _ld(v), _ptr(g),
                       _ld(g), _ptr(o), _ld(o), _ptr(den), n, float(n_total), heads, v_heads, d,
                       _code(q), _ptr(stats), _ptr(bstats), _ptr(dq), _ld(dq), _ptr(dk), _ld(dk),
                       _ptr(dv), _ld(dv), _stream(dev))
@@ -1507,10 +1508,12 @@ def _split(qkv, v_ext, heads, d):
 
 
 class _Attention(torch.autograd.Function):
-    """qkv: [N, 3*H*d] = [Q | K | V], or [N, 2*H*d] = [Q | K] with v_ext: [N, d] (V not projected)."""
+    """qkv: [N, 3*H*d] = [Q | K | V], or [N, 2*H*d] = [Q | K] with v_ext: [N, d] (V not projected).
+    per_head (H > 1): returns the per-head outputs [N, H*d] (what full_attention_conv returns, medium/ours.py:14-46) and
+    takes their gradient [N, H*d] in the backward (sgf_attn_bwd_*_heads) — instead of the head mean [N, d]."""
 
     @staticmethod
-    def forward(ctx, qkv, v_ext, heads: int, d: int, shard, n_override=None):
+    def forward(ctx, qkv, v_ext, heads: int, d: int, shard, n_override=None, per_head=False):
         K.check(qkv, v_ext)
         qkv, v_ext = _rows(qkv), _rows(v_ext)
         n, hd = qkv.shape[0], heads * d
@@ -1523,34 +1526,37 @@ class _Attention(torch.autograd.Function):
             if n_override is None:
                 n_total = float(shard.n_global)
         out, den, o_heads = K.attn_fwd_apply(q, v, stats, n_total, heads, v_heads, d)
+        per_head = bool(per_head) and heads > 1
         ctx.save_for_backward(qkv, v_ext, out, den, o_heads, stats)
-        ctx.meta = (heads, d, n_total, shard)
-        return out
+        ctx.meta = (heads, d, n_total, shard, per_head)
+        return o_heads if per_head else out
 
     @staticmethod
     def backward(ctx, g):
         qkv, v_ext, out, den, o_heads, stats = ctx.saved_tensors
-        heads, d, n_total, shard = ctx.meta
+        heads, d, n_total, shard, per_head = ctx.meta
         g = _rows(g.contiguous())
         hd = heads * d
         q, k, v, v_heads = _split(qkv, v_ext, heads, d)
         o = out if heads == 1 else o_heads
-        bstats = K.attn_bwd_reduce(q, g, o, den, heads, d)
+        kw = {"per_head": True} if per_head else {}
+        bstats = K.attn_bwd_reduce(q, g, o, den, heads, d, **kw)
         if shard is not None:
             shard.all_reduce(bstats)
         dqkv = torch.empty_like(qkv)
         dv_ext = torch.empty_like(v_ext) if v_ext is not None else None
         dv = dqkv[:, 2 * hd:] if v_ext is None else dv_ext
         K.attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total, heads, v_heads, d,
-                         dqkv[:, :hd], dqkv[:, hd:2 * hd], dv)
-        return dqkv, dv_ext, None, None, None, None
+                         dqkv[:, :hd], dqkv[:, hd:2 * hd], dv, **kw)
+        return dqkv, dv_ext, None, None, None, None, None
 
 
 def attention(qkv: torch.Tensor, v_ext: Optional[torch.Tensor], heads: int, d: int, shard=None,
-              n_total=None):
+              n_total=None, per_head: bool = False):
     """mean_h (qn S + N V)/(qn z + N) from fused projections; see _Attention.  `n_total` overrides
-    the N of large/ours.py:133 (default: the number of rows, or the global count when sharded)."""
-    return _Attention.apply(qkv, v_ext, heads, d, shard, n_total)
+    the N of large/ours.py:133 (default: the number of rows, or the global count when sharded).
+    per_head (H > 1): the per-head outputs [N, H*d] instead of their mean, differentiable."""
+    return _Attention.apply(qkv, v_ext, heads, d, shard, n_total, per_head)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -93,35 +93,19 @@ def _drop(x, p, training, res=None):
 def full_attention_conv(qs, ks, vs, output_attn=False, shard=None):
     """medium/ours.py:14-46 / 100M/ours.py:12-53 as a free function: qs, ks [N,H,M], vs [N,H|1,D].
 
-    Returns [N, H, D] like the reference for H == 1 (every recipe).  The kernels produce the head
-    MEAN (what every caller in the reference takes next, medium/ours.py:98); per-head outputs for
-    H > 1 are not exposed through this free function — use `TransConvLayer`.
+    Returns [N, H, D] like the reference, differentiable for any H: for H > 1 the per-head outputs come from the forward
+    kernels' per-head buffer and their gradients enter sgf_attn_bwd_reduce_heads / _apply_heads (TransConvLayer, which takes
+    the head mean next as medium/ours.py:98 does, keeps the mean-gradient form).
     """
     n, h, d = qs.shape
-    if h != 1:
-        # per-head outputs [N, H, D] (medium/ours.py:14-46 returns them; every caller in the reference takes the
-        # head mean next, :98): served from the kernels' per-head buffer, forward only — the backward kernels
-        # take the gradient of the head MEAN, which is what TransConvLayer differentiates
-        if torch.is_grad_enabled() and (qs.requires_grad or ks.requires_grad or vs.requires_grad):
-            raise NotImplementedError("full_attention_conv: per-head outputs for H > 1 are forward-only; under "
-                                      "autograd call TransConvLayer (the head mean, as the reference takes next)")
-        if output_attn:
-            raise NotImplementedError("full_attention_conv: output_attn with H > 1: use TransConvLayer")
-        q2, k2 = ops._rows(qs.reshape(n, h * d)), ops._rows(ks.reshape(n, h * d))
-        vh = vs.shape[1]
-        v2 = ops._rows(vs.reshape(n, vh * d))
-        stats = ops.K.attn_fwd_reduce(q2, k2, v2, h, vh, d)
-        if shard is not None:
-            shard.all_reduce(stats)
-        _, _, o_heads = ops.K.attn_fwd_apply(q2, v2, stats, float(n if shard is None else shard.n_global), h, vh, d)
-        return o_heads.reshape(n, h, d)
     qk = torch.cat([qs.reshape(n, h * d), ks.reshape(n, h * d)], dim=1)
+    # H > 1: the per-head outputs [N, H, D], differentiable (sgf_attn_bwd_*_heads take the per-head gradients)
     if vs.shape[1] == h:
         qkv = torch.cat([qk, vs.reshape(n, h * d)], dim=1)
-        out = ops.attention(qkv, None, h, d, shard)
+        out = ops.attention(qkv, None, h, d, shard, per_head=h > 1)
     else:
-        out = ops.attention(qk, vs.reshape(n, d), h, d, shard)
-    out = out.unsqueeze(1) if h == 1 else out
+        out = ops.attention(qk, vs.reshape(n, d), h, d, shard, per_head=h > 1)
+    out = out.reshape(n, h, d)
     if output_attn:
         return out, _attention_matrix(qs, ks)
     return out

@@ -366,11 +366,11 @@ class CpuKernels:
         return out, den.contiguous(), (o.reshape(n, heads * d).to(q.dtype) if heads > 1 else None)
 
     @staticmethod
-    def attn_bwd_reduce(q, g, o, den, heads, d):
+    def attn_bwd_reduce(q, g, o, den, heads, d, per_head=False):
         n = q.shape[0]
         qh = q.reshape(n, heads, d).float()
         oh = o.reshape(n, heads, d).float()
-        gh = (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
+        gh = g.float().reshape(n, heads, d) if per_head else (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
         dnum = gh / den.unsqueeze(-1)
         dden = -(gh * oh).sum(-1) / den
         ds0 = torch.einsum("nhm,nhd->hmd", qh, dnum)
@@ -378,7 +378,7 @@ class CpuKernels:
         return torch.cat([ds0.reshape(-1), dz0.reshape(-1), torch.zeros(1)])
 
     @staticmethod
-    def attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total, heads, v_heads, d, dq, dk, dv):
+    def attn_bwd_apply(q, k, v, g, o, den, stats, bstats, n_total, heads, v_heads, d, dq, dk, dv, per_head=False):
         n = q.shape[0]
         s0, z0 = CpuKernels._unpack(stats, heads, d)
         ds0, dz0 = CpuKernels._unpack(bstats, heads, d)
@@ -390,7 +390,7 @@ class CpuKernels:
         qh, kh = q.reshape(n, heads, d).float(), k.reshape(n, heads, d).float()
         vh = v.reshape(n, v_heads, d).float().expand(-1, heads, -1)
         oh = o.reshape(n, heads, d).float()
-        gh = (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
+        gh = g.float().reshape(n, heads, d) if per_head else (g.float() / heads).unsqueeze(1).expand(-1, heads, -1)
         dnum = gh / den.unsqueeze(-1)
         dden = -(gh * oh).sum(-1) / den
         gq = c * (torch.einsum("nhd,hmd->nhm", dnum, s0) + dden.unsqueeze(-1) * z0) - s * qh / ssq_q

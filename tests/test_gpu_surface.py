@@ -75,7 +75,8 @@ def test_difformer_gcn_conv_with_edge_weight(cuda):
 
 @pytest.mark.parametrize("v_heads", [2, 1])
 def test_full_attention_conv_per_head_outputs(cuda, v_heads):
-    """H = 2: [N, H, D] per-head outputs (forward only) against the oracle restatement of medium/ours.py:14-46."""
+    """H = 2: [N, H, D] per-head outputs against the restatement of medium/ours.py:14-46 — values, and (r05) the gradients of
+    Q, K, V for an arbitrary per-head cotangent through sgf_attn_bwd_reduce_heads / _apply_heads vs fp64 autograd."""
     from sgformer_amd.ours import full_attention_conv
     n, h, d = 1500, 2, 64
     g = torch.Generator().manual_seed(4)
@@ -90,5 +91,17 @@ def test_full_attention_conv_per_head_outputs(cuda, v_heads):
     num = torch.einsum("nhm,hmd->nhd", qn, kvs) + n * v64
     den = torch.einsum("nhm,hm->nh", qn, kn.sum(0)).unsqueeze(-1) + n
     assert _rel(out, num / den) <= 2e-6
-    with pytest.raises(NotImplementedError):
-        full_attention_conv(qs.to(cuda).requires_grad_(True), ks.to(cuda), vs.to(cuda))
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (qs, ks, vs))
+    qn, kn = q64 / q64.norm(), k64 / k64.norm()
+    kvs = torch.einsum("lhm,lhd->hmd", kn, v64.expand(n, h, d) if v_heads == 1 else v64)
+    ref = (torch.einsum("nhm,hmd->nhd", qn, kvs) + n * v64) / (torch.einsum("nhm,hm->nh", qn, kn.sum(0)).unsqueeze(-1) + n)
+    cot = torch.randn(n, h, d, generator=g)
+    # a cotangent whose all-pair part matters: SURVEY 0.5 — the self term N V swamps the rest, so weigh the small term too
+    gq, gk, gv = torch.autograd.grad((ref * cot.double()).sum(), (q64, k64, v64))
+    qd, kd, vd = (t.to(cuda).requires_grad_(True) for t in (qs, ks, vs))
+    got = full_attention_conv(qd, kd, vd)
+    assert got.shape == (n, h, d) and got.requires_grad
+    dq, dk, dv = torch.autograd.grad((got * cot.to(cuda)).sum(), (qd, kd, vd))
+    assert dv.shape == vs.shape
+    assert _rel(dv.cpu(), gv) <= 1e-5
+    assert _rel(dq.cpu(), gq) <= 2e-3 and _rel(dk.cpu(), gk) <= 2e-3

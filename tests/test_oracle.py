@@ -61,17 +61,22 @@ def test_oracle_matches_golden(path):
     if meta["variant"] == "medium":
         return _medium_golden(z, meta)
     cfg = meta["cfg"]
-    x = torch.from_numpy(z["x"])
+    # production-width fixtures (r05) store parameters / features / logits / gradients as fp32 (the reference ran in fp64 on
+    # exactly those fp32-representable inputs): run the restatement in fp64 on them, compare to the stored precision
+    prod = bool(meta.get("production"))
+    stored = 2e-7 if prod else 0.0
+    x = torch.from_numpy(z["x"]).double()
     ei = torch.from_numpy(z["edge_index"])
     y = torch.from_numpy(z["y"])
     idx = torch.from_numpy(z["train_idx"])
     p = {k[6:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("param/")}
+    p = {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}
     for k, v in p.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
     parts, stats = {}, {}
     logits = O.sgformer_forward(p, x, ei, cfg, training=True, parts=parts, bn_stats=stats)
-    assert np.abs(logits.detach().numpy() - z["logits_train"]).max() <= 1e-12
+    assert np.abs(logits.detach().numpy() - z["logits_train"]).max() <= 1e-12 + stored * np.abs(z["logits_train"]).max()
     loss = O.nll_loss(logits, y, idx)
     assert abs(float(loss) - float(z["loss"])) <= 1e-12
     loss.backward()
@@ -79,16 +84,17 @@ def test_oracle_matches_golden(path):
         if k.startswith("grad/"):
             g = p[k[5:]].grad
             assert g is not None, k
-            assert np.abs(g.numpy() - z[k]).max() <= 1e-12 + 1e-9 * np.abs(z[k]).max(), k
+            assert np.abs(g.numpy() - z[k]).max() <= 1e-12 + (1e-9 + stored) * np.abs(z[k]).max(), k
     # attention intermediates of the reference's einsum calls (large/ours.py:136-143)
     for i in range(cfg.get("trans_num_layers", 1)):
         pr = parts[f"attn{i}"]
         assert np.abs(pr["kvs"].detach().numpy() - z[f"attn{i}/kvs"]).max() <= 1e-14
         assert np.abs(pr["ks_sum"].detach().numpy() - z[f"attn{i}/ks_sum"]).max() <= 1e-14
         n = x.shape[0]
-        q_kvs = (pr["num"] - n * pr["vs"]).detach().numpy()
-        assert np.abs(q_kvs - z[f"attn{i}/q_kvs"]).max() <= 1e-10
-        assert np.abs((pr["den"].squeeze(-1) - n).detach().numpy() - z[f"attn{i}/q_ks_sum"]).max() <= 1e-10
+        if f"attn{i}/q_kvs" in z.files:              # (per-node intermediates are not stored at production size)
+            q_kvs = (pr["num"] - n * pr["vs"]).detach().numpy()
+            assert np.abs(q_kvs - z[f"attn{i}/q_kvs"]).max() <= 1e-10
+            assert np.abs((pr["den"].squeeze(-1) - n).detach().numpy() - z[f"attn{i}/q_ks_sum"]).max() <= 1e-10
         # the un-normalised partials libsgf reduces, rescaled, are the reference's kvs / ks_sum
         raw = O.attention_raw_stats(pr["qs"], pr["ks"], pr["vs"]).detach()
         h, d = pr["qs"].shape[1], pr["qs"].shape[2]
@@ -106,7 +112,7 @@ def test_oracle_matches_golden(path):
         if k.startswith("after/"):
             pe[k[6:]] = torch.from_numpy(z[k])
     le = O.sgformer_forward(pe, x, ei, cfg, training=False)
-    assert np.abs(le.numpy() - z["logits_eval"]).max() <= 1e-12
+    assert np.abs(le.numpy() - z["logits_eval"]).max() <= 1e-12 + stored * np.abs(z["logits_eval"]).max()
     # CSR arrays: the reference's sorted COO (target, source, fp32 value) bit for bit
     if "coo/row" in z.files:
         rowptr, colind, val, deg = O.csr_build(z["edge_index"], x.shape[0])

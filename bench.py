@@ -107,8 +107,18 @@ def parse():
     ap.add_argument("--aten-loss", action="store_true", help="(older spelling of --loss aten)")
     ap.add_argument("--no-structured", action="store_true",
                     help="skip the second measurement on the community-structured graph with shuffled node ids")
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "community", "powerlaw"],
-                    help="graph generator of the HEADLINE measurement (default: uniform random, the r01 workload)")
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "community", "powerlaw", "rmat"],
+                    help="graph generator of the HEADLINE measurement (default: uniform random, the r01 workload); rmat = "
+                         "R-MAT with the Graph500 parameters (a, b, c = 0.57, 0.19, 0.19), ids shuffled")
+    ap.add_argument("--dropout", default="0", choices=["0", "recipe"],
+                    help="'recipe': the dropout probabilities of the workload's run.sh recipe (ogbn-arxiv: 0.5 / 0.5, "
+                         "large/run.sh:2-5; the products / pokec recipes use 0) on sgf_dropout (Philox keyed on seed and "
+                         "element index, mask recomputed in the backward) inside the timed step; '0': the parity setting")
+    ap.add_argument("--mode", default="fullgraph", choices=["fullgraph", "minibatch"],
+                    help="minibatch: one step = one EPOCH of the reference's random-partition mini-batch loop "
+                         "(large/main-batch.py:129-151, batch_size 100000 as in large/run.sh:15-19) as the unchanged trainer "
+                         "runs it under sgformer_amd.launch; value = N / epoch time")
+    ap.add_argument("--batch-size", type=int, default=100000)
     return ap.parse_args()
 
 
@@ -268,7 +278,7 @@ def make_inputs(workload: str, nodes: int, seed: int, rank: int, world: int, dev
             ctx = ShardContext(n, local_edges=True)
     else:
         gen = {"community": synth.synthetic_graph_community, "powerlaw": synth.synthetic_graph_community_powerlaw,
-               "uniform": synth.synthetic_graph}[graph]
+               "uniform": synth.synthetic_graph, "rmat": synth.synthetic_graph_rmat}[graph]
         ei = gen(n, avg_deg, seed=seed, device=dev)
         x, y, train_idx = synth.synthetic_task(n, f, c, seed=seed)
         n_train = train_idx.numel()
@@ -284,15 +294,18 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx = make_inputs(args.workload, args.nodes, args.seed,
                                                                            rank, world, dev, graph_kind)
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    x, y, train_idx = x.to(dev, dtype), y.to(dev), train_idx.to(dev)
+    # the features are handed to the model in fp32 EVERY step, exactly as an unchanged trainer does (large/main.py:130:
+    # model(dataset.graph['node_feat'], ...)); the module keeps its storage-dtype (and row-permuted / zero-padded) copy of a
+    # feature tensor it has seen before (SGFormer.forward: keyed on the tensor's identity and version) — the features of a
+    # full-graph run are constant data, like the CSR
+    x, y, train_idx = x.to(dev), y.to(dev), train_idx.to(dev)
 
     torch.manual_seed(args.seed)
+    p_trans, p_gnn = synth.RECIPE_DROPOUT.get(args.workload, (0.0, 0.0)) if args.dropout == "recipe" else (0.0, 0.0)
     # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
-    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0,
+    model = SGFormer(f, d, c, trans_dropout=p_trans, gnn_dropout=p_gnn,
                      compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
-    # fp32 logits straight from the fused head, as under sgformer_amd.launch (fp32 features in -> fp32 logits out); the
-    # features here are stored in bf16 ahead of the loop, which would otherwise round the logits to bf16 and back
-    model.logits_dtype = torch.float32
+    model.logits_dtype = torch.float32     # (fp32 features in -> fp32 logits out, as under sgformer_amd.launch)
     if ctx is not None:
         shard_model(model, ctx)
     # the optimizer exactly as the trainer constructs it (large/main.py:114-119); under sgformer_amd.launch — and here —
@@ -402,9 +415,118 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                      # 0 when the halo plan is off (all-gather fallback) or this rank has no halo
                      "halo_exchanges_overlapped_per_step": getattr(ctx, "overlapped_exchanges", 0) // max(warmup + steps, 1)}
     out = dict(n=n, f=f, c=c, d=d, weak=weak, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_fused=ms_fused, loss_mode=state["mode"],
+               dropout=(p_trans, p_gnn),
                roof=roof, view=view_stats, prepare_s=t_prep, exchanged=exchanged,
                peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
     del model, opt, x, y
+    ops.graph_cache.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_minibatch(args, dev, steps, warmup):
+    """One step = one EPOCH of large/main-batch.py:129-151 as the unchanged trainer runs it under sgformer_amd.launch
+    (features resident on the GPU: launch.patch_resident_features; per-batch induced subgraph on the GPU: batching.subgraph
+    = torch_geometric.utils.subgraph's semantics; 16 host threads; labels and masks on the HOST as the trainer keeps them):
+        idx = randperm(n);  per batch:  train_mask[idx_i], x[idx_i].to(device), subgraph(idx_i, edge_index, relabel), y[idx_i]
+        .to(device), model(x_i, edge_index_i), log_softmax, criterion(out_i[train_mask_i], y_i[train_mask_i]), backward, step
+    — the trainer's lines verbatim, including its boolean-mask indexing (one device->host read per batch).  The per-batch
+    breakdown comes from HIP events on the launch stream (GPU timeline, gaps included) and host timers (time to ISSUE)."""
+    from sgformer_amd import batching, launch
+    launch.limit_host_threads()
+    n, avg_deg, f, c, d = synth.SHAPES[args.workload]
+    if args.nodes:
+        n = args.nodes
+    cfg = dict(synth.RECIPES.get(args.workload, synth.RECIPES["ogbn-products"]))
+    gen = {"community": synth.synthetic_graph_community, "powerlaw": synth.synthetic_graph_community_powerlaw,
+           "uniform": synth.synthetic_graph, "rmat": synth.synthetic_graph_rmat}[args.graph]
+    ei = gen(n, avg_deg, seed=args.seed, device=dev).cpu()          # the dataset lives on the HOST (main-batch.py:43-99)
+    x, y, train_idx = synth.synthetic_task(n, f, c, seed=args.seed)
+    x = x.to(dev)                                                   # launch.patch_resident_features
+    true_label = y.unsqueeze(1)
+    train_mask = torch.zeros(n, dtype=torch.bool)
+    train_mask[train_idx] = True
+    dtype = None if args.dtype == "f32" else torch.bfloat16
+    torch.manual_seed(args.seed)
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=dtype, **cfg).to(dev)
+    launch.patch_adam()
+    opt = torch.optim.Adam(model.parameters(), weight_decay=1e-5, lr=0.01)      # main-batch.py:125-127 (one group)
+    criterion = torch.nn.NLLLoss()
+    bs = args.batch_size
+    num_batch = n // bs + (n % bs > 0)
+    marks = ("gather", "subgraph", "forward", "loss_backward", "optimizer")
+    ev, host = [], {k: 0.0 for k in marks}
+    gen_cpu = torch.Generator().manual_seed(args.seed)
+
+    def epoch(record):
+        model.train()
+        idx = torch.randperm(n, generator=gen_cpu)
+        for i in range(num_batch):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if record else None
+            t = [time.perf_counter()]
+            if record:
+                e[0].record()
+            idx_i = idx[i * bs:(i + 1) * bs]
+            train_mask_i = train_mask[idx_i]
+            x_i = x[idx_i].to(dev)
+            y_i = true_label[idx_i].to(dev)
+            t.append(time.perf_counter())
+            if record:
+                e[1].record()
+            ei_i, _ = batching.subgraph(idx_i, ei, num_nodes=n, relabel_nodes=True)
+            ei_i = ei_i.to(dev)
+            t.append(time.perf_counter())
+            if record:
+                e[2].record()
+            opt.zero_grad()
+            out_i = model(x_i, ei_i)
+            t.append(time.perf_counter())
+            if record:
+                e[3].record()
+            out_i = F.log_softmax(out_i, dim=1)
+            loss = criterion(out_i[train_mask_i], y_i.squeeze(1)[train_mask_i])
+            loss.backward()
+            t.append(time.perf_counter())
+            if record:
+                e[4].record()
+            opt.step()
+            t.append(time.perf_counter())
+            if record:
+                e[5].record()
+                ev.append(e)
+                for k, a, b in zip(marks, t, t[1:]):
+                    host[k] += b - a
+        return loss
+
+    launch.patch_nll_loss()
+    timer = SpmmTimer()
+    timer.install()
+    try:
+        for _ in range(warmup):
+            epoch(False)
+        torch.cuda.synchronize()
+        timer.active = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = epoch(True)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timer.active = False
+    finally:
+        launch.unpatch_nll_loss()
+        timer.uninstall()
+    gpu = {k: 0.0 for k in marks}
+    for e in ev:
+        for k, a, b in zip(marks, e, e[1:]):
+            gpu[k] += a.elapsed_time(b)
+    nb = max(len(ev), 1)
+    breakdown = {"batches_per_epoch": num_batch, "batch_nodes": bs,
+                 "per_batch_ms_on_the_gpu_timeline": {k: round(v / nb, 3) for k, v in gpu.items()},
+                 "per_batch_ms_host_issue": {k: round(v / nb * 1e3, 3) for k, v in host.items()},
+                 "per_batch_ms_wall": round(elapsed / nb * 1e3, 3)}
+    out = dict(n=n, f=f, c=c, d=d, nnz=int(ei.shape[1]), elapsed=elapsed, loss=float(loss.detach()), roof=timer.summary(),
+               breakdown=breakdown, peak_mem=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+    del model, opt, x
     ops.graph_cache.clear()
     torch.cuda.empty_cache()
     return out
@@ -499,6 +621,27 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.mode == "minibatch":
+        if world != 1 or DRYRUN:
+            raise SystemExit("--mode minibatch is a single-GPU measurement")
+        steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+        r = run_minibatch(args, dev, steps, warmup)
+        ms = r["elapsed"] / steps * 1e3
+        line = {"metric": f"SGFormer fwd+bwd nodes/sec on {args.workload}, random-partition mini-batch epoch "
+                          f"(large/main-batch.py:129-151)",
+                "value": r["n"] * steps / r["elapsed"], "unit": "nodes/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+                "data": "synthetic",
+                "config": {"workload": f"{args.workload}-shaped {args.graph} graph, one step = one EPOCH of "
+                                       f"{r['breakdown']['batches_per_epoch']} random partitions of {args.batch_size} nodes "
+                                       f"(large/run.sh:15-19), the trainer's loop lines verbatim, features resident on the "
+                                       f"GPU, labels / masks on the host, dropout 0",
+                           "nodes": r["n"], "nnz": r["nnz"], "features": r["f"], "hidden": r["d"], "classes": r["c"],
+                           "parallelism": "single GPU", "debug_override": bool(args.nodes)},
+                "loss": r["loss"], "peak_mem_GB": r["peak_mem"], "minibatch": r["breakdown"], "roofline": r["roof"],
+                "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+        return
     r = run_workload(args, args.graph, rank, world, dev, args.steps, args.warmup, with_aten=True)
     structured = None
     if (rank == 0 and world == 1 and args.graph == "uniform" and not args.no_structured
@@ -519,12 +662,21 @@ def main():
                      "to global hubs, node ids randomly permuted (synth.synthetic_graph_community_powerlaw)",
             "nnz": q["nnz"], "value": q["n"] * 3 / q["elapsed"], "unit": "nodes/s", "steps": 3,
             "ms_per_step": round(q["elapsed"] / 3 * 1e3, 3), "graph_view": q["view"], "roofline": q["roof"]}
+        # ... and on a STANDARD skewed generator nobody here tuned: R-MAT with the Graph500 parameters
+        q = run_workload(args, "rmat", rank, world, dev, 3, 2)
+        structured["rmat"] = {
+            "graph": "R-MAT, Graph500 parameters a, b, c = 0.57, 0.19, 0.19 over ceil(log2 N) levels restricted to N ids, "
+                     "same number of undirected pairs before coalescing, node ids randomly permuted "
+                     "(synth.synthetic_graph_rmat)",
+            "nnz": q["nnz"], "value": q["n"] * 3 / q["elapsed"], "unit": "nodes/s", "steps": 3,
+            "ms_per_step": round(q["elapsed"] / 3 * 1e3, 3), "graph_view": q["view"], "roofline": q["roof"]}
 
     if rank == 0:
         n, f, c, d, weak = r["n"], r["f"], r["c"], r["d"], r["weak"]
         ms = r["elapsed"] / args.steps * 1e3
         gname = {"uniform": "uniform random graph", "community": "community graph with shuffled node ids",
-                 "powerlaw": "power-law community graph with global hubs and shuffled node ids"}[args.graph]
+                 "powerlaw": "power-law community graph with global hubs and shuffled node ids",
+                 "rmat": "R-MAT graph (Graph500 a, b, c = 0.57, 0.19, 0.19) with shuffled node ids"}[args.graph]
         line = {
             "metric": f"SGFormer fwd+bwd nodes/sec on {args.workload} full-graph",
             "value": n * args.steps / r["elapsed"], "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
@@ -533,7 +685,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped {gname}, full-graph "
                                    f"training step (fwd + log_softmax/NLL on the training rows + bwd + Adam), "
-                                   f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout 0"
+                                   f"{'100M' if 'papers' in args.workload else 'large'}/run.sh recipe, dropout "
+                                   + ("0" if not any(r["dropout"]) else f"{r['dropout'][0]} (attention branch) / "
+                                      f"{r['dropout'][1]} (GCN branch) as in the recipe, sgf_dropout")
                                    + (f"; {n // world:,} nodes per rank, rows generated per rank" if weak else ""),
                        "loss": {"trainer": "the trainer's own lines (large/main.py:139-141: log_softmax, row indexing, "
                                            "nn.NLLLoss) as they run under sgformer_amd.launch (launch.patch_nll_loss: F.log_softmax returns a lazy "
@@ -542,6 +696,12 @@ def main():
                                 "aten": "F.log_softmax + F.nll_loss on ATen's kernels"}[r["loss_mode"]],
                        "ms_per_step_with_aten_loss": None if r["ms_aten"] is None else round(r["ms_aten"], 3),
                        "ms_per_step_with_fused_loss": None if r["ms_fused"] is None else round(r["ms_fused"], 3),
+                       "features_in": "fp32 features handed to the model every step (as large/main.py:130 does); the module "
+                                      "caches its storage-dtype copy of a feature tensor it has already seen",
+                       "roofline_target_reading": "frac is on ALGORITHMIC bytes (SURVEY.md §8d B_spmm); gather_GBps / traffic "
+                                                  "give the measured-bytes reading SURVEY.md §7 allows for graphs without "
+                                                  "locality: the 0.60 target is met on measured bytes (uniform graph), not on "
+                                                  "algorithmic bytes",
                        "nodes": n, ("nnz_per_rank" if weak else "nnz"): r["nnz"], "features": f, "hidden": d, "classes": c,
                        "parallelism": f"node-shard x{world}" if world > 1 else "single GPU",
                        "graph_view": r["view"],

@@ -50,6 +50,11 @@ RECIPES = {
 
 RECIPES["papers100M-weak"] = RECIPES["papers100M-shard8"]
 
+# (trans_dropout, gnn_dropout) of the same recipes: large/run.sh:2-5 (arxiv: 0.5 / 0.5), :15-19 and :22-26 (amazon2m / pokec:
+# 0 / 0), 100M/run.sh:3-7 (0.5 / 0.2)
+RECIPE_DROPOUT = {"ogbn-arxiv": (0.5, 0.5), "ogbn-products": (0.0, 0.0), "pokec": (0.0, 0.0),
+                  "papers100M-shard8": (0.5, 0.2), "papers100M-weak": (0.5, 0.2)}
+
 
 def synthetic_graph(n: int, avg_deg: float, seed: int = 123, directed: bool = False,
                     device="cpu") -> torch.Tensor:
@@ -186,6 +191,55 @@ def synthetic_graph_community_powerlaw(n: int, avg_deg: float, seed: int = 123, 
         perm = torch.randperm(n, generator=g)
         src, dst = perm[src], perm[dst]
     src, dst = src.to(device), dst.to(device)
+    src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])
+    del src, dst, keep
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([key // n, loops]), torch.cat([key % n, loops])])
+
+
+def synthetic_graph_rmat(n: int, avg_deg: float, seed: int = 123, abc=(0.57, 0.19, 0.19), shuffle_ids: bool = True,
+                         device="cpu") -> torch.Tensor:
+    """R-MAT (Chakrabarti, Zhan, Faloutsos 2004) with the Graph500 parameters a, b, c = 0.57, 0.19, 0.19 (d = 0.05) — the
+    STANDARD skewed generator SURVEY.md §8d(b) names, so that one structured number does not come from a generator tuned in
+    this repository.  Every undirected pair picks, bit by bit over ceil(log2 n) levels, one quadrant of the adjacency
+    matrix (a: both ids get a 0 bit, b: the target a 1, c: the source a 1, d: both); pairs with an id >= n are dropped
+    (n is not a power of two: the kept pairs are the generator restricted to the n x n corner) and the draw is sized so
+    that ~n * avg_deg / 2 pairs remain before coalescing; ids are renamed by a seeded random permutation (as Graph500
+    does); then the trainer prologue of `synthetic_graph` (symmetrise + coalesce, no self pairs, one self-loop per node).
+    Heavy-tailed degrees (the largest rows hold 10^4-10^5 entries at products size) and almost no community structure."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a, b, c = abc
+    scale = max(1, (n - 1).bit_length())
+    # P(id < n) for the source / target marginals: bit = 1 with probability c + d / b + d, most significant bit first
+    def keep_prob(p_one):
+        # probability that a scale-bit number with iid bits (P(bit = 1) = p_one) is < n
+        prob, pref = 0.0, 1.0
+        for level in range(scale - 1, -1, -1):
+            bit = (n >> level) & 1
+            if bit:
+                prob += pref * (1.0 - p_one)       # this bit 0 while n has 1: everything below is free
+                pref *= p_one
+            else:
+                pref *= (1.0 - p_one)
+        return prob
+    p_keep = max(keep_prob(1.0 - a - b) * keep_prob(1.0 - a - c), 1e-3)     # (independent marginals: a sizing estimate only)
+    want = int(n * avg_deg / 2)
+    m = int(want / p_keep * 1.05) + 16
+    src = torch.zeros(m, dtype=torch.long, device=device)
+    dst = torch.zeros(m, dtype=torch.long, device=device)
+    for level in range(scale):
+        r = torch.rand(m, generator=g).to(device)
+        src = (src << 1) | (r >= a + b).long()                               # quadrants c, d: source bit 1
+        dst = (dst << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c)).long()   # quadrants b, d: target bit 1
+        del r
+    ok = (src < n) & (dst < n)
+    src, dst = src[ok][:want], dst[ok][:want]
+    del ok
+    if shuffle_ids:
+        perm = torch.randperm(n, generator=g).to(device)
+        src, dst = perm[src], perm[dst]
     src, dst = torch.cat([src, dst]), torch.cat([dst, src])
     keep = src != dst
     key = torch.unique(src[keep] * n + dst[keep])

@@ -157,11 +157,14 @@ def test_bf16_module_matches_reference_fixture_at_production_width(cuda, path):
     err = float(np.abs(logits.detach().double().cpu().numpy() - ref).max())
     report = {"logits_max_abs_err": err, "logits_scale": scale, "loss_err": abs(float(loss) - float(z["loss"]))}
     worst = 0.0
+    gmax = max(float(np.linalg.norm(z[k])) for k in z.files if k.startswith("grad/"))
     for k, prm in m.named_parameters():
         if "grad/" + k not in z.files:
             continue
         g_ref = z["grad/" + k].astype(np.float64)
-        rel = float(np.linalg.norm(prm.grad.double().cpu().numpy() - g_ref) / max(np.linalg.norm(g_ref), 1e-300))
+        # (a Linear bias in front of a BatchNorm has an exactly zero gradient — the reference's 1e-17 is rounding noise —
+        # so the distance is taken relative to the tensor's norm OR a floor of 1e-3 of the largest gradient)
+        rel = float(np.linalg.norm(prm.grad.double().cpu().numpy() - g_ref) / max(np.linalg.norm(g_ref), 1e-3 * gmax))
         report["grad/" + k] = rel
         worst = max(worst, rel)
     print("bf16 production fixture:", meta["name"], json.dumps(report))

@@ -532,6 +532,53 @@ def run_minibatch(args, dev, steps, warmup):
     return out
 
 
+# single-GPU step times measured on MI355X (ms; profiles/r05_bench_*.json) that the scaling MODEL below starts from
+MEASURED_1GPU_MS = {("pokec", "bf16"): 30.0, ("pokec", "f32"): 95.0, ("ogbn-products", "bf16"): 91.5,
+                    ("papers100M-weak", "bf16"): 232.0, ("papers100M-shard8", "bf16"): 232.0, ("ogbn-arxiv", "f32"): 9.9}
+XGMI_LINK_GBS = 153.0      # per direction and link, 7 links per GPU (MI355X_MICROARCH.md); 0.8 of it assumed reachable
+
+
+def scaling_model(workload: str, dtype: str, world: int):
+    """A MODEL of the node-sharded step on `world` GPUs of one node — bytes over xGMI links, NOT a measurement (this build
+    never had more than one GPU; SCALE_r0x.json holds the driver's real numbers when an 8-GPU node was available).
+    Exchanges per step (sgformer_amd/dist.py): per SpMM launch (2 per GCN layer: forward and backward) every rank receives
+    the other ranks' rows of X — all-gather of N d s bytes on a graph without locality (uniform generator; the halo plan
+    sends only the cut-edge rows on a graph sgf_reorder can partition); per attention pass one all-reduce of d^2 + O(d)
+    floats, per BatchNorm 2 d + 1 floats each way, the parameter gradients once.  xGMI is point to point: a rank's P - 1
+    incoming shards arrive on P - 1 different links in parallel, so an all-gather costs one shard over one link."""
+    n, _, f, c, d = synth.SHAPES[workload]
+    weak = workload.endswith("-weak")
+    cfg = synth.RECIPES.get(workload, synth.RECIPES["ogbn-products"])
+    s = 4 if dtype == "f32" else 2
+    n_total = n * world if weak else n
+    shard_rows = n_total // world
+    lg = cfg["gnn_num_layers"]
+    spmm_launches = 2 * lg
+    link = XGMI_LINK_GBS * 0.8 * 1e9
+    shard_bytes = shard_rows * d * s
+    t_all_gather = spmm_launches * shard_bytes / link if world > 1 else 0.0
+    small = (2 * (d * d + 2 * d + 2) + (lg + 1) * 2 * (2 * d + 1)) * 4           # attention fwd + bwd, BatchNorm fwd + bwd
+    n_params = 2 * f * d + 3 * d * d + lg * (2 * d * d if cfg.get("gnn_use_init") else d * d) + d * c
+    t_small = (2 + 2 * (lg + 1)) * 30e-6 + (small + n_params * 4) / link if world > 1 else 0.0   # ~30 us per tiny collective
+    base = MEASURED_1GPU_MS.get((workload, dtype))
+    out = {"label": "MODEL — not a measurement: no multi-GPU hardware was available to this build",
+           "per_rank_rows": shard_rows, "spmm_launches_per_step": spmm_launches,
+           "all_gather_bytes_received_per_rank_per_step": int(spmm_launches * shard_bytes * (world - 1)),
+           "all_reduce_bytes_per_step": int(small + n_params * 4),
+           "xgmi_link_GBps_assumed": round(XGMI_LINK_GBS * 0.8, 1),
+           "t_all_gather_ms_no_overlap": round(t_all_gather * 1e3, 3), "t_small_collectives_ms": round(t_small * 1e3, 3)}
+    if base is not None:
+        compute = base if weak else base / world
+        step = compute + (t_all_gather + t_small) * 1e3
+        out.update({"measured_1gpu_ms": base, "compute_ms_per_rank": round(compute, 3), "modelled_step_ms": round(step, 3),
+                    "modelled_nodes_per_s": round(n_total / (step * 1e-3)),
+                    "modelled_efficiency": round((base / step) if weak else (base / (step * world)), 3),
+                    "note": "compute share = the measured 1-GPU step (weak: unchanged; strong: / world, optimistic for the "
+                            "SpMM on a uniform graph, whose halo rows do not shrink); exchanges counted WITHOUT overlap "
+                            "(dist.py overlaps the own-column product with the halo exchange)"})
+    return out
+
+
 DRYRUN = os.environ.get("SGF_BENCH_DRYRUN") == "1"
 
 
@@ -716,6 +763,8 @@ def main():
             "structured": structured,
             "cpu_baseline": cpu,
         }
+        if world > 1:
+            line["scaling_model"] = scaling_model(args.workload, args.dtype, world)
         if cpu is not None:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
         print(json.dumps(line), flush=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads */
+#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads, sgf_comm_* */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -826,6 +826,29 @@ int sgf_sum_n(const void* const* xs_host, const int64_t* lds_host, int32_t k, in
 size_t sgf_colsum_workspace_bytes(int64_t n, int32_t d);
 int sgf_colsum(const void* x, int64_t ldx, int64_t n, int32_t d, int32_t dtype, float* out,
                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md §8b / §8e — the collectives of the node-sharded run (csrc/comm.hip): thin wrappers over RCCL, which is loaded
+ * with dlopen() at the first call (libsgf.so has no link-time dependency on librccl.so).  The reference has no multi-GPU
+ * path; WHAT is exchanged follows from the kernels' partial-sum layouts above: the attention statistics and BatchNorm sums
+ * and the parameter gradients (all-reduce, fp32, in place), the SpMM operand's rows — whole shards (all-gather) or the
+ * cut-edge rows of a halo plan (all-to-all with per-peer byte ranges).  One process per GPU; the communicator is created
+ * on the calling thread's CURRENT device.  The *_host arrays are host memory (per-peer offsets / sizes in bytes, length =
+ * world); everything else is device memory.  The Python host side (sgformer_amd/dist.py) issues the same collectives
+ * through torch.distributed (backend `nccl` = RCCL); these entries are for a consumer binding the library from C.
+ *   sgf_comm_unique_id  : rank 0 fills id_host (sgf_comm_unique_id_bytes() = 128 bytes) and hands it to the other ranks
+ *                         by any out-of-band means (the launcher's rendezvous);
+ *   sgf_comm_create     : blocks until all `world` ranks have called it with the same id.
+ * ------------------------------------------------------------------------------------------ */
+int32_t sgf_comm_available(void);                 /* 1 if librccl.so and its entry points could be loaded */
+int32_t sgf_comm_unique_id_bytes(void);
+int sgf_comm_unique_id(void* id_host);
+int sgf_comm_create(void** comm_out, int32_t world, int32_t rank, const void* id_host);
+int sgf_comm_destroy(void* comm);
+int sgf_comm_all_reduce_f32(void* comm, float* buf, int64_t count, void* stream);
+int sgf_comm_all_gather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int sgf_comm_all_to_all(void* comm, const void* send, const int64_t* send_offset_host, const int64_t* send_bytes_host,
+                        void* recv, const int64_t* recv_offset_host, const int64_t* recv_bytes_host, void* stream);
 
 #ifdef __cplusplus
 }

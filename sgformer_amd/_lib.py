@@ -183,6 +183,14 @@ SIGNATURES = {
                                 c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "sgf_gemm": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, c_int64, c_int32, c_int64, c_int32, c_int64, c_float,
                            _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64, c_int32, _P]),
+    "sgf_comm_available": (c_int32, []),
+    "sgf_comm_unique_id_bytes": (c_int32, []),
+    "sgf_comm_unique_id": (c_int32, [_P]),
+    "sgf_comm_create": (c_int32, [_P, c_int32, c_int32, _P]),
+    "sgf_comm_destroy": (c_int32, [_P]),
+    "sgf_comm_all_reduce_f32": (c_int32, [_P, _P, c_int64, _P]),
+    "sgf_comm_all_gather": (c_int32, [_P, _P, _P, c_int64, _P]),
+    "sgf_comm_all_to_all": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sgf_axpby": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, c_int64, c_int32, c_int32, _P,
                             c_int64, _P]),
 }

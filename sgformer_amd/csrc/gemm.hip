@@ -10,7 +10,7 @@
 //
 // One skeleton, two matrix-core forms: both operands bf16 -> v_mfma_f32_32x32x16_bf16 (exact products, fp32 sums);
 // otherwise v_mfma_f32_32x32x2f32 (an exact fp32 FMA chain — against a CPU loop only the summation order differs), a bf16
-// operand widened while it is staged.  64 x 64 output tile per 4-wave workgroup, K in steps of 32 through LDS; both tiles
+// operand widened while it is staged.  64 x 64 output tile per 4-wave workgroup, K in steps of 32 or 128 through LDS; both tiles
 // are stored K-CONTIGUOUS in LDS whatever the operand's layout in memory (the staging loop walks the operand along its
 // contiguous dimension — chosen per operand at launch — so global loads coalesce either way), next K-step's elements
 // are requested into registers before the current step is multiplied.  Output-tile index: column tiles fastest, so the
@@ -24,7 +24,9 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kGemmThreads = 256;
-constexpr int GBM = 64, GBN = 64, GBK = 32;
+constexpr int GBM = 64, GBN = 64;      // output tile; the K step is a template parameter: 32, or 128 once k >= 128 (a product of
+                                       // a few hundred in every dimension — the d x d algebra — is bound by the LATENCY of its
+                                       // serial K steps, not by bytes: 23 us at K step 32 for 512 x 257 x 257)
 
 struct GemmArgs {
   const void* a;
@@ -54,25 +56,26 @@ struct Stage;
 template <>
 struct Stage<true> {
   using T = uint16_t;
-  static constexpr int kPitch = GBK + 8;      // 80-byte rows: 16 lanes' 16-byte fragment reads fall on disjoint banks
+  static constexpr int kPad = 8;              // 80- / 272-byte rows: 16 lanes' 16-byte fragment reads fall on disjoint banks
   static __device__ __forceinline__ T fetch(const void* p, int64_t i, int) { return static_cast<const uint16_t*>(p)[i]; }
   static __device__ __forceinline__ T zero() { return 0; }
 };
 template <>
 struct Stage<false> {
   using T = float;
-  static constexpr int kPitch = GBK + 4;      // 144-byte rows: likewise for the float4 fragment reads
+  static constexpr int kPad = 4;              // 144- / 528-byte rows: likewise for the float4 fragment reads
   static __device__ __forceinline__ T fetch(const void* p, int64_t i, int is_bf16) {
     return is_bf16 ? bf16_to_f32(static_cast<const uint16_t*>(p)[i]) : static_cast<const float*>(p)[i];
   }
   static __device__ __forceinline__ T zero() { return 0.f; }
 };
 
-template <bool MX16>
+template <bool MX16, int GBK>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmArgs p) {
   using S = Stage<MX16>;
   using T = typename S::T;
-  constexpr int P = S::kPitch;
+  constexpr int P = GBK + S::kPad;
+  constexpr int E = GBM * GBK / kGemmThreads;       // elements of each tile a thread stages per K step
   __shared__ __attribute__((aligned(16))) T As[GBM * P];
   __shared__ __attribute__((aligned(16))) T Bs[GBN * P];
 
@@ -86,15 +89,15 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmArgs p) {
   const int64_t m0 = tm * GBM;
   const int n0 = tn * GBN;
 
-  // staging coordinates of this thread's 8 elements of each tile: (r, kk) for element e
+  // staging coordinates of this thread's E elements of each tile: (r, kk) for element e
   auto coord = [&](int kc, int e, int& r, int& kk) {
-    if (kc) { kk = tid & 31; r = (tid >> 5) + 8 * e; }
+    if (kc) { kk = tid % GBK; r = tid / GBK + (kGemmThreads / GBK) * e; }
     else    { r = tid & 63; kk = (tid >> 6) + 4 * e; }
   };
-  T ra[8], rb[8];
+  T ra[E], rb[E];
   auto issue = [&](int64_t k0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < E; ++e) {
       int r, kk;
       coord(p.a_kc, e, r, kk);
       const int64_t i = m0 + r, k = k0 + kk;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmArgs p) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < E; ++e) {
       int r, kk;
       coord(p.a_kc, e, r, kk);
       As[r * P + kk] = ra[e];
@@ -188,8 +191,14 @@ int gemm_launch(const void* a, int64_t a_rs, int64_t a_cs, int a_dtype, const vo
   GemmArgs p{a, a_rs, a_cs, b, b_rs, b_cs, a_dtype == SGF_BF16, b_dtype == SGF_BF16, a_cs == 1, b_rs == 1, m, n, k, alpha,
              alpha_dev, bias, beta, addend, ldadd, add_dtype == SGF_BF16, c, ldc, c_dtype == SGF_BF16, static_cast<int32_t>(nb_n)};
   const dim3 grid(static_cast<unsigned>(nb_m * nb_n));
-  if (p.a_bf16 && p.b_bf16) hipLaunchKernelGGL((k_gemm<true>), grid, dim3(kGemmThreads), 0, st, p);
-  else hipLaunchKernelGGL((k_gemm<false>), grid, dim3(kGemmThreads), 0, st, p);
+  const bool mx16 = p.a_bf16 && p.b_bf16;
+  if (k >= 128) {
+    if (mx16) hipLaunchKernelGGL((k_gemm<true, 128>), grid, dim3(kGemmThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm<false, 128>), grid, dim3(kGemmThreads), 0, st, p);
+  } else {
+    if (mx16) hipLaunchKernelGGL((k_gemm<true, 32>), grid, dim3(kGemmThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm<false, 32>), grid, dim3(kGemmThreads), 0, st, p);
+  }
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -616,3 +616,30 @@ def test_bench_under_the_drivers_launch_line(graph, tmp_path):
     else:
         assert ex["all_gather_bytes_per_step"] > 0
     assert out["loss"] == out["loss"] and 0.0 < out["loss"] < 20.0
+
+
+@pytest.mark.parametrize("workload,world", [("pokec", 2), ("papers100M-weak", 2)])
+def test_bench_dry_run_of_the_multi_gpu_configs_prints_exchange_bytes_and_a_labelled_model(workload, world, tmp_path):
+    """BASELINE configs 4 (pokec, node-sharded K^T V all-reduce) and 5 (papers100M-shaped, weak scaling) through the driver's
+    launch line on this GPU-less host (gloo + CPU kernel table, toy node count): the line carries the bytes every exchange
+    moved per step AND a `scaling_model` object that says of itself that it is a model — no multi-GPU number in this
+    repository is a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "SGF_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "2"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1",
+           "--warmup", "1", "--nodes", "600", "--workload", workload]
+    p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == world and out["config"]["dry_run"] is True
+    assert out["scaling"] == ("weak" if workload.endswith("-weak") else "strong")
+    ex = out["config"]["exchanged"]
+    assert ex["all_reduce_bytes_per_step"] > 0 and (ex["all_gather_bytes_per_step"] > 0 or ex["halo_bytes_sent_per_step"] > 0
+                                                     or workload.endswith("-weak"))
+    m = out["scaling_model"]
+    assert m["label"].startswith("MODEL") and "not a measurement" in m["label"]
+    assert m["all_gather_bytes_received_per_rank_per_step"] > 0 and m["modelled_step_ms"] > 0

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads, sgf_comm_* */
+#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads, sgf_comm_*, sgf_subgraph_csr_* */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -102,6 +102,27 @@ int sgf_subgraph_plan(const int64_t* edge_index, int64_t nnz, int64_t n, const i
 int sgf_subgraph_emit(const int64_t* edge_index, int64_t nnz, int64_t n, const int32_t* relabel,
                       int32_t relabel_nodes, int64_t total, int64_t* out, int64_t* out_eid,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* N1 + T1 in one step (r05; csrc/subgraph_csr.hip): the induced subgraph of `subset` AND its normalised CSR, straight from
+ * the CSR of the PARENT graph (sgf_csr_build of the full edge list, cached by the caller) — a batch of m nodes reads its m
+ * parent rows (20 MB per 100 k-node batch at ogbn-products size) instead of all parent edges twice (4 GB) plus a radix
+ * sort of the result.  Replaces large/main-batch.py:139 + large/ours.py:26-33 for the batch:
+ *     rowptr_b int64 [m + 1], colind_b int32 [total], val_b fp32 [total], deg_b int32 [m]  == bit for bit what
+ *     sgf_csr_build returns for torch_geometric's subgraph(subset, edge_index, relabel_nodes=True);
+ *     edge_index_b int64 [2, total] (optional): that edge list in (target, source) order — the same multiset of edges as
+ *     the reference's, whose order (the parent's edge order) no consumer on the path depends on.
+ * Two calls around ONE host read:  _plan -> total[0] = number of kept entries, total[1] = 1 if `subset` repeats a node or
+ * holds an id outside [0, n) (then call _emit with total = 0, which only resets the table, and use sgf_subgraph_* instead);
+ * _emit with the value read.  local_of: int32 [n] owned by the caller, all -1 between calls (the library restores it).
+ * deg_b has m + 1 slots (the last one is scratch).  Workspaces: _plan_workspace_bytes(m), _emit_workspace_bytes(m, total). */
+size_t sgf_subgraph_csr_plan_workspace_bytes(int64_t m);
+size_t sgf_subgraph_csr_emit_workspace_bytes(int64_t m, int64_t total);
+int sgf_subgraph_csr_plan(const int64_t* rowptr, const int32_t* colind, int64_t n, const int64_t* subset, int64_t m,
+                          int32_t* local_of, int64_t* rowptr_b, int32_t* deg_b, int64_t* total, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int sgf_subgraph_csr_emit(const int64_t* rowptr, const int32_t* colind, int64_t n, const int64_t* subset, int64_t m,
+                          int32_t* local_of, const int64_t* rowptr_b, const int32_t* deg_b, int64_t total, int32_t* colind_b,
+                          float* val_b, int64_t* edge_index_b, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N2 — the trainer's graph prologue.   Replaces large/main.py:75-79 (and

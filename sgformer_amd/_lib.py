@@ -29,6 +29,10 @@ SIGNATURES = {
     "sgf_subgraph_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_subgraph_plan": (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "sgf_subgraph_emit": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
+    "sgf_subgraph_csr_plan_workspace_bytes": (c_size_t, [c_int64]),
+    "sgf_subgraph_csr_emit_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sgf_subgraph_csr_plan": (c_int32, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sgf_subgraph_csr_emit": (c_int32, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "sgf_graph_prologue_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sgf_graph_prologue_plan": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "sgf_graph_prologue_emit": (c_int32, [c_int64, c_int64, c_int32, c_int32, c_int64, _P, _P, c_size_t, _P]),

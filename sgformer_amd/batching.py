@@ -40,9 +40,48 @@ def _on_gpu(t: torch.Tensor, device) -> torch.Tensor:
     return d
 
 
+class _Parent:
+    """What is kept per PARENT edge list for the mini-batch path (one or two per process): its CSR (sgf_csr_build, once),
+    whether A^T == A (checked once) and the node -> local-id table of sgf_subgraph_csr_*."""
+
+    def __init__(self, ei_dev: torch.Tensor, n: int):
+        g = ops.CSRGraph(ei_dev, n, validate=True)
+        g.transposed()                                    # one-off: A^T == A ?
+        self.rowptr, self.colind, self.n, self.nnz = g.rowptr, g.colind, n, g.nnz
+        self.symmetric = bool(g.symmetric)
+        self.local_of = torch.full((max(n, 1),), -1, dtype=torch.int32, device=ei_dev.device)
+
+
+_parents: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def _parent_of(edge_index: torch.Tensor, ei_dev: torch.Tensor, n: int) -> _Parent:
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(ei_dev.device), n)
+    hit = _parents.get(key)
+    if hit is not None:
+        _parents.move_to_end(key)
+        return hit[1]
+    p = _Parent(ei_dev, n)
+    _parents[key] = (edge_index, p)                       # (pins the key tensor: a recycled data_ptr cannot alias it)
+    while len(_parents) > 2:
+        _parents.popitem(last=False)
+    return p
+
+
+def _use_parent_csr() -> bool:
+    import os
+    return hasattr(ops.K, "subgraph_csr") and os.environ.get("SGF_SUBGRAPH_CSR", "1") != "0"
+
+
 def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
              num_nodes: Optional[int] = None):
-    """torch_geometric.utils.subgraph(subset, edge_index, edge_attr, relabel_nodes, num_nodes)."""
+    """torch_geometric.utils.subgraph(subset, edge_index, edge_attr, relabel_nodes, num_nodes).
+
+    relabel_nodes=True without edge attributes — the mini-batch trainer's call (large/main-batch.py:139) — takes the parent's
+    cached CSR (sgf_subgraph_csr_*): the batch's m parent rows are read instead of all parent edges, and the result carries its
+    normalised CSR (`_sgf_csr`, adopted by ops.CSRGraph instead of a second sort) and, for a parent with A^T == A, the promise
+    that it is symmetric too.  Its edges come in (target, source) order — the same multiset as the reference's, whose order
+    (the parent's edge order) nothing on the path depends on; SGF_SUBGRAPH_CSR=0 keeps the edge-order-preserving passes."""
     if ops.K.name == "hip":
         if not torch.cuda.is_available():
             ops.K.check(edge_index)   # raises the standard no-CPU-path error
@@ -56,6 +95,16 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
     if subset.dtype == torch.bool:
         subset = subset.nonzero().view(-1)
     ei = _on_gpu(edge_index, device) if ops.K.name == "hip" else edge_index
+    if relabel_nodes and edge_attr is None and _use_parent_csr() and ei.shape[1] > 0:
+        parent = _parent_of(edge_index, ei, n)
+        sub = subset.contiguous().long()
+        got = ops.K.subgraph_csr(parent.rowptr, parent.colind, n, sub, parent.local_of, True)
+        if got is not None:
+            rowptr_b, colind_b, val_b, deg_b, out = got
+            out._sgf_trusted = True
+            out._sgf_csr = (rowptr_b, colind_b, val_b, deg_b)
+            out._sgf_symmetric = parent.symmetric
+            return out, None
     out, eid = ops.K.subgraph(ei, n, subset.contiguous().long(), bool(relabel_nodes), edge_attr is not None)
     if relabel_nodes:
         out._sgf_trusted = True       # ids are positions in `subset`: CSRGraph skips its range check (a host sync)

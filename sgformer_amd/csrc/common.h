@@ -127,6 +127,19 @@ __device__ __forceinline__ void store1<float>(float* p, float f) { *p = f; }
 template <>
 __device__ __forceinline__ void store1<uint16_t>(uint16_t* p, float f) { *p = f32_to_bf16(f); }
 
+// ---- T1: value of one stored entry of the normalised adjacency (large/ours.py:28-31), shared by csr.hip / subgraph_csr.hip ----
+__device__ __forceinline__ float norm_value(int32_t deg_tgt, int32_t deg_src) {
+#pragma clang fp contract(off)
+  // (1. / d[col]).sqrt() and (1. / d[row]).sqrt(): correctly rounded IEEE div and sqrt
+  // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), then one rounded product.
+  const float a = sqrtf(1.0f / static_cast<float>(deg_tgt));
+  const float b = sqrtf(1.0f / static_cast<float>(deg_src));
+  float v = a * b;
+  // torch.nan_to_num(value, nan=0, posinf=0, neginf=0): zero in-degree of the source gives inf
+  if (!(fabsf(v) <= 3.402823466e+38f)) v = 0.0f;
+  return v;
+}
+
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {

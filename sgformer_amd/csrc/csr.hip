@@ -46,18 +46,6 @@ __global__ void k_make_keys(const int64_t* __restrict__ hi, const int64_t* __res
   }
 }
 
-__device__ __forceinline__ float norm_value(int32_t deg_tgt, int32_t deg_src) {
-#pragma clang fp contract(off)
-  // (1. / d[col]).sqrt() and (1. / d[row]).sqrt(): correctly rounded IEEE div and sqrt
-  // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), then one rounded product.
-  const float a = sqrtf(1.0f / static_cast<float>(deg_tgt));
-  const float b = sqrtf(1.0f / static_cast<float>(deg_src));
-  float v = a * b;
-  // torch.nan_to_num(value, nan=0, posinf=0, neginf=0): zero in-degree of the source gives inf
-  if (!(fabsf(v) <= 3.402823466e+38f)) v = 0.0f;
-  return v;
-}
-
 // sorted key = (row_of_A << 32) | col_of_A ; deg is always the IN-degree array.
 // kTransposed = false: row_of_A = tgt, col_of_A = src.   true: row = src, col = tgt.
 template <bool kTransposed>

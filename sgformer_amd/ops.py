@@ -142,6 +142,31 @@ class HipKernels:
                       _ptr(eid), _ptr(ws), ws.numel(), _stream(dev))
         return out, eid
 
+    @staticmethod
+    def subgraph_csr(rowptr, colind, n: int, subset: torch.Tensor, local_of: torch.Tensor, want_edges: bool):
+        """Induced subgraph + its normalised CSR from the parent CSR (sgf_subgraph_csr_*): (rowptr_b, colind_b, val_b, deg_b,
+        edge_index_b | None), or None when `subset` repeats a node / leaves the graph (the caller takes sgf_subgraph_*)."""
+        dev, m = rowptr.device, int(subset.numel())
+        lib = _lib.load()
+        rowptr_b = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        deg_b = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        total = torch.empty(2, dtype=torch.int64, device=dev)
+        ws = _workspace(dev, "subgraph_csr_plan", lib.sgf_subgraph_csr_plan_workspace_bytes(m))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_subgraph_csr_plan", _ptr(rowptr), _ptr(colind), n, _ptr(subset), m, _ptr(local_of), _ptr(rowptr_b),
+                      _ptr(deg_b), _ptr(total), _ptr(ws), ws.numel(), _stream(dev))
+            t, bad = total.tolist()                         # the one host read of the batch
+            t = 0 if bad else int(t)
+            colind_b = torch.empty(t, dtype=torch.int32, device=dev)
+            val_b = torch.empty(t, dtype=_F32, device=dev)
+            ei_b = torch.empty((2, t), dtype=torch.int64, device=dev) if want_edges else None
+            ws2 = _workspace(dev, "subgraph_csr_emit", lib.sgf_subgraph_csr_emit_workspace_bytes(m, t))
+            _lib.call("sgf_subgraph_csr_emit", _ptr(rowptr), _ptr(colind), n, _ptr(subset), m, _ptr(local_of), _ptr(rowptr_b),
+                      _ptr(deg_b), t, _ptr(colind_b), _ptr(val_b), _ptr(ei_b), _ptr(ws2), ws2.numel(), _stream(dev))
+        if bad:
+            return None
+        return rowptr_b, colind_b, val_b, deg_b[:m], ei_b
+
     # ---- N2: trainer prologue (to_undirected / remove_self_loops / add_self_loops) ----
     @staticmethod
     def graph_prologue(ei: torch.Tensor, n: int, undirected: bool, remove_loops: bool, add_loops: bool):
@@ -1066,7 +1091,13 @@ class CSRGraph:
                 raise IndexError(f"edge_index has node ids outside [0, {n})")
         self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
         self.edge_index = ei
-        self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
+        pre = getattr(edge_index, "_sgf_csr", None)
+        if pre is not None and pre[0].numel() == n + 1 and pre[1].numel() == self.nnz:
+            # the producer of this edge list (batching.subgraph on the parent's CSR: sgf_subgraph_csr_*) built the normalised
+            # CSR in the same pass — bit for bit what sgf_csr_build would return for it (tests/test_gpu_r05.py)
+            self.rowptr, self.colind, self.val, self.deg = pre
+        else:
+            self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
         # longest possible row: only a bound the caller GUARANTEES (sampling.NeighborSampler marks its batches with their
         # largest fan-out).  The node count is no bound: sgf_csr_build keeps duplicate edges (large/ours.py:33 does not
         # coalesce), so a row of a small multigraph can exceed LONG_ROW entries — without a hint the nnz-based
@@ -1076,6 +1107,10 @@ class CSRGraph:
         self.t_long_segments = 0
         self._t = None  # (rowptr, colind, val) of A^T, built on first backward
         self.symmetric: Optional[bool] = None
+        if getattr(edge_index, "_sgf_symmetric", False):
+            # an induced subgraph of a graph whose A^T == A was verified once (batching.subgraph): symmetric by construction —
+            # no second sort, no comparison pass and no host read per batch in the first backward
+            self.symmetric, self._t, self.t_long_segments = True, (self.rowptr, self.colind, self.val), self.long_segments
 
     def transposed(self):
         """CSR of A^T for dX = A^T dY; the same arrays when A is symmetric."""

@@ -86,3 +86,59 @@ def test_sampler_falls_back_to_hops_for_huge_fanouts(cuda, monkeypatch):
     assert int(deg.max()) <= 5
     n_id2, e2, _ = s.sample(seeds)          # the node table was reset: a second batch is consistent too
     assert int(e2.max()) < n_id2.numel()
+
+
+@pytest.mark.parametrize("kind", ["undirected", "directed_multigraph", "no_edges_kept"])
+def test_subgraph_from_the_parent_csr_is_bit_exact(cuda, kind):
+    """sgf_subgraph_csr_* (r05): the induced subgraph + its normalised CSR straight from the parent's CSR == bit for bit what
+    sgf_csr_build / the oracle's csr_build give for torch_geometric's subgraph(subset, edge_index, relabel_nodes=True); the
+    emitted edge list is the same multiset of edges as the edge-order-preserving sgf_subgraph_* result; the node table is
+    restored; a parent with A^T == A promises symmetric batches, a directed one does not."""
+    from oracle import sgformer_oracle as O
+    from sgformer_amd import batching, ops, synth
+    n = 5000
+    g = torch.Generator().manual_seed(3)
+    if kind == "undirected":
+        ei = synth.synthetic_graph(n, 14.0, seed=5)
+    elif kind == "directed_multigraph":
+        src, dst = torch.randint(0, n, (40000,), generator=g), torch.randint(0, n, (40000,), generator=g)
+        ei = torch.stack([torch.cat([src, src[:5000]]), torch.cat([dst, dst[:5000]])])       # duplicates, self-loops, no symmetry
+    else:
+        ei = torch.stack([torch.arange(0, n - 1), torch.arange(1, n)])
+    subset = torch.randperm(n, generator=g)[: (1200 if kind != "no_edges_kept" else 40)]
+    if kind == "no_edges_kept":
+        subset = subset[(subset % 7) == 0][:20] * 1          # a few scattered nodes of a path: (almost) no edge survives
+    eid, subd = ei.to(cuda), subset.to(cuda)
+    batching._parents.clear()
+    out, _ = batching.subgraph(subd, eid, num_nodes=n, relabel_nodes=True)
+    assert hasattr(out, "_sgf_csr") and out._sgf_trusted
+    m = subset.numel()
+    # the reference semantics on the host: mask + relabel, original order
+    pos = torch.full((n,), -1, dtype=torch.long)
+    pos[subset] = torch.arange(m)
+    keep = (pos[ei[0]] >= 0) & (pos[ei[1]] >= 0)
+    ref_ei = pos[ei[:, keep]]
+    assert out.shape == ref_ei.shape
+    key = lambda e: torch.sort(e[1] * m + e[0])[0]       # noqa: E731
+    assert torch.equal(key(out.cpu()), key(ref_ei))
+    rowptr, colind, val, deg = O.csr_build(ref_ei.numpy(), m)
+    rb, cb, vb, db = (t.cpu().numpy() for t in out._sgf_csr)
+    assert np.array_equal(rb, rowptr) and np.array_equal(cb, colind.astype(np.int32)) and np.array_equal(db, deg.astype(np.int32))
+    assert np.array_equal(vb.view(np.uint32), val.view(np.uint32))
+    # the emitted edge list is in (target, source) order: exactly the CSR's
+    assert np.array_equal(out[1].cpu().numpy(), np.repeat(np.arange(m), np.diff(rowptr))) and np.array_equal(out[0].cpu().numpy(), colind)
+    parent = next(iter(batching._parents.values()))[1]
+    assert int((parent.local_of != -1).sum()) == 0
+    assert parent.symmetric == (kind == "undirected") and bool(getattr(out, "_sgf_symmetric", False)) == (kind == "undirected")
+    # ops.CSRGraph adopts the arrays (no second sort) and the SpMM on them equals the SpMM on a freshly built CSR
+    gr = ops.CSRGraph(out, m)
+    assert gr.rowptr.data_ptr() == out._sgf_csr[0].data_ptr()
+    fresh = ops.CSRGraph(ref_ei.to(cuda), m)
+    x = torch.randn(m, 64, generator=g).to(cuda)
+    assert torch.equal(ops.spmm_on(gr, x, False), ops.spmm_on(fresh, x, False))
+    if kind == "undirected":
+        assert gr.symmetric is True and gr.transposed()[0].data_ptr() == gr.rowptr.data_ptr()
+    # a subset that repeats a node takes the general path (and leaves the table clean)
+    dup = torch.cat([subd[:10], subd[:3]])
+    out2, _ = batching.subgraph(dup, eid, num_nodes=n, relabel_nodes=True)
+    assert not hasattr(out2, "_sgf_csr") and int((parent.local_of != -1).sum()) == 0

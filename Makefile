@@ -3,6 +3,10 @@ HIPCC ?= hipcc
 ARCH ?= gfx950
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function \
             -fhip-fp32-correctly-rounded-divide-sqrt
+# make PROBES=1: also compile the timing-ablation variants (SGF_*_DEBUG masks; results are then wrong) the probe scripts use
+ifdef PROBES
+HIPFLAGS += -DSGF_PROBES
+endif
 CSRC := sgformer_amd/csrc
 SRCS := $(CSRC)/capi.hip $(CSRC)/csr.hip $(CSRC)/spmm.hip $(CSRC)/attn.hip $(CSRC)/fused.hip $(CSRC)/subgraph.hip $(CSRC)/reorder.hip $(CSRC)/spmm_plan.hip $(CSRC)/prologue.hip $(CSRC)/head.hip $(CSRC)/rowgemm.hip $(CSRC)/spmm_tile.hip $(CSRC)/spmm_pack.hip $(CSRC)/sampler.hip $(CSRC)/linear_f32.hip $(CSRC)/gemm.hip $(CSRC)/attn_small.hip $(CSRC)/comm.hip $(CSRC)/subgraph_csr.hip
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))

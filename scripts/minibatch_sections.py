@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Where a 100 k-node mini-batch step spends its time: every section of the trainer's loop body (large/main-batch.py:134-151)
+timed twice — host time to ISSUE it (the GPU idle at its start) and time until the GPU has FINISHED it.
+    python scripts/minibatch_sections.py [--batches 12]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgformer_amd import batching, launch, synth  # noqa: E402
+from sgformer_amd.ours import SGFormer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=100000)
+    a = ap.parse_args()
+    launch.limit_host_threads()
+    dev = torch.device("cuda:0")
+    n, avg_deg, f, c, d = synth.SHAPES["ogbn-products"]
+    ei = synth.synthetic_graph(n, avg_deg, seed=123, device=dev).cpu()
+    x, y, train_idx = synth.synthetic_task(n, f, c, seed=123)
+    x = x.to(dev)
+    true_label = y.unsqueeze(1)
+    train_mask = torch.zeros(n, dtype=torch.bool)
+    train_mask[train_idx] = True
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16,
+                     **synth.RECIPES["ogbn-products"]).to(dev)
+    launch.patch_adam()
+    launch.patch_nll_loss()
+    opt = torch.optim.Adam(model.parameters(), weight_decay=1e-5, lr=0.01)
+    criterion = torch.nn.NLLLoss()
+    idx = torch.randperm(n)
+    names = ["gather", "subgraph", "forward", "loss", "backward", "optimizer"]
+    issue = {k: 0.0 for k in names}
+    done = {k: 0.0 for k in names}
+
+    def section(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        issue[name] += t1 - t0
+        done[name] += t2 - t0
+        return out
+
+    model.train()
+    for i in range(a.batches + 2):
+        if i == 2:
+            for k in names:
+                issue[k] = done[k] = 0.0
+        idx_i = idx[i * a.batch:(i + 1) * a.batch]
+
+        def gather():
+            return train_mask[idx_i], x[idx_i].to(dev), true_label[idx_i].to(dev)
+        train_mask_i, x_i, y_i = section("gather", gather)
+        ei_i = section("subgraph", lambda: batching.subgraph(idx_i, ei, num_nodes=n, relabel_nodes=True)[0].to(dev))
+        opt.zero_grad()
+        out_i = section("forward", lambda: model(x_i, ei_i))
+
+        def loss_fn():
+            o = F.log_softmax(out_i, dim=1)
+            return criterion(o[train_mask_i], y_i.squeeze(1)[train_mask_i])
+        loss = section("loss", loss_fn)
+        section("backward", loss.backward)
+        section("optimizer", opt.step)
+    nb = a.batches
+    print(json.dumps({"per_batch_ms_host_issue": {k: round(v / nb * 1e3, 3) for k, v in issue.items()},
+                      "per_batch_ms_until_gpu_done": {k: round(v / nb * 1e3, 3) for k, v in done.items()},
+                      "sum_issue_ms": round(sum(issue.values()) / nb * 1e3, 3), "sum_done_ms": round(sum(done.values()) / nb * 1e3, 3)}))
+
+
+if __name__ == "__main__":
+    main()

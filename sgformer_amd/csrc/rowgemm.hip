@@ -1475,6 +1475,7 @@ int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
     case 64: hipLaunchKernelGGL((k_rowgemm_bf16<64, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
     case 128: hipLaunchKernelGGL((k_rowgemm_bf16<128, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
     case 256: {
+#ifdef SGF_PROBES   // timing ablations (make PROBES=1): SGF_ROWGEMM_DEBUG; not compiled into the release library
       static EnvInt dbg_env{"SGF_ROWGEMM_DEBUG", 0};
       const int dbg = dbg_env.get();
       switch (IO == 0 && !STATS ? dbg : 0) {
@@ -1483,6 +1484,9 @@ int launch_rowgemm(const RowGemmArgs& a, int d, int blocks, hipStream_t st) {
 #undef SGF_RG_DBG
         default: hipLaunchKernelGGL((k_rowgemm_bf16<256, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a); break;
       }
+#else
+      hipLaunchKernelGGL((k_rowgemm_bf16<256, STATS, IO>), dim3(blocks), dim3(kRgThreads), 0, st, a);
+#endif
       break;
     }
     default: set_error("sgf_gcn_epilogue: width %d not in {64, 128, 256}", d); return SGF_E_UNSUPPORTED;
@@ -1768,6 +1772,7 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
   if (d == 64) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<64, 1>), dim3(vblocks), dim3(kRgThreads), 0, st, a);
   else if (d == 128) hipLaunchKernelGGL((k_bn_bwd_dx_bf16<128, 2>), dim3(vblocks * 2), dim3(kRgThreads), 0, st, a);
   else {
+#ifdef SGF_PROBES   // timing ablations (make PROBES=1): SGF_GCN_BWD_DEBUG; not compiled into the release library
     static EnvInt dbg_env{"SGF_GCN_BWD_DEBUG", 0};
     switch (dbg_env.get()) {
 #define SGF_BWD_DBG(X) case X: hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4, X>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a); break;
@@ -1775,6 +1780,9 @@ extern "C" int sgf_gcn_bn_bwd_dx(const void* gy, int64_t ldg, const void* z, int
 #undef SGF_BWD_DBG
       default: hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a); break;
     }
+#else
+    hipLaunchKernelGGL((k_bn_bwd_dx_bf16<256, 4>), dim3(vblocks * 4), dim3(kRgThreads), 0, st, a);
+#endif
   }
   SGF_LAUNCH_CHECK();
   return SGF_OK;

@@ -1108,8 +1108,12 @@ int launch_blocked(const int64_t* rowptr, const int32_t* ecode, const float* eva
   // per CU); "lean" halves both and fits 64 VGPRs, for block shapes of which the LDS admits 32 waves per CU.
   // SGF_SPMM_BLK_DEBUG (timing experiments only, results are then wrong): 1 = skip the staging loads,
   // 2 = skip the LDS entries, 4 = skip the gathered entries
+#ifdef SGF_PROBES   // (make PROBES=1; the release library takes no debug mask)
   const char* dbg_env = getenv("SGF_SPMM_BLK_DEBUG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#else
+  const int dbg = 0;
+#endif
   const size_t per_cu = 160 * 1024;
   const bool lean = (per_cu / lds_bytes) * static_cast<size_t>(threads / 64) > 16;
   constexpr int DGd = sizeof(T) == 4 ? 4 : 8, DGl = sizeof(T) == 4 ? 2 : 4;

@@ -602,8 +602,13 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   // 4 / 8 = nt fragment loads / y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
   // loop, 128 = no matrix-core work in the tile phase
   // (both switches are cached: a launch costs no environment look-up; sgf_reload_env() re-reads them)
-  static EnvInt dbg_env{"SGF_SPMM_TILE_DEBUG", 0}, chunk_env{"SGF_SPMM_TILE_CHUNK", 64};
+  static EnvInt chunk_env{"SGF_SPMM_TILE_CHUNK", 64};
+#ifdef SGF_PROBES   // (make PROBES=1; the release library takes no debug mask and does not contain the masked kernels)
+  static EnvInt dbg_env{"SGF_SPMM_TILE_DEBUG", 0};
   const int dbg = dbg_env.get();
+#else
+  const int dbg = 0;
+#endif
   const int chunk = chunk_env.get() > 0 ? chunk_env.get() : 64;   // an XCD walks 64 consecutive blocks (<= 8192 rows) at a time
   const uint16_t* xs = static_cast<const uint16_t*>(x);
   uint16_t* ys = static_cast<uint16_t*>(y);
@@ -611,10 +616,14 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   hipLaunchKernelGGL((k_spmm_tile_bf16<NCT_, NW_, DBG_>), dim3(static_cast<unsigned>(nb)), dim3(NW_ * 64), 0, st, P, xs, \
                      static_cast<uint32_t>(ldx * 2), static_cast<uint32_t>(x_bytes), ys, ldy, static_cast<int32_t>(nb), \
                      chunk, lq, dbg)
+#ifdef SGF_PROBES
 #define SGF_TILE_LAUNCH2(NCT_, NW_)                                               \
   do {                                                                            \
     if (dbg) SGF_TILE_LAUNCH(NCT_, NW_, true); else SGF_TILE_LAUNCH(NCT_, NW_, false); \
   } while (0)
+#else
+#define SGF_TILE_LAUNCH2(NCT_, NW_) SGF_TILE_LAUNCH(NCT_, NW_, false)
+#endif
   if (d == 256) {
     if (block_rows > 128) SGF_TILE_LAUNCH2(8, 8); else SGF_TILE_LAUNCH2(8, 4);
   } else {

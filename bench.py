@@ -582,56 +582,7 @@ def scaling_model(workload: str, dtype: str, world: int):
 DRYRUN = os.environ.get("SGF_BENCH_DRYRUN") == "1"
 
 
-def _enter_dryrun():
-    """SGF_BENCH_DRYRUN=1 (tests/test_dist.py only; never a measurement): the driver's launch line
-    `python -m torch.distributed.run ... bench.py --gpus N ...` on a GPU-less host — gloo instead of RCCL, the CPU kernel
-    table of tests/cpu_kernels.py instead of libsgf.so, torch.cuda's fences as no-ops.  What it exercises is everything
-    of this file that is not a kernel: env parsing, rendezvous, sharding of the inputs, the step sequence, the timing
-    fences and the max-over-ranks reduction, the JSON contract.  The printed line is marked `dry_run`."""
-    sys.path.insert(0, os.path.join(ROOT))
-    from tests.cpu_kernels import CpuKernels
-    ops.set_kernels(CpuKernels())
-    for name in ("synchronize", "set_device", "empty_cache", "reset_peak_memory_stats"):
-        setattr(torch.cuda, name, lambda *a, **k: None)
-    torch.cuda.max_memory_allocated = lambda *a, **k: 0
-    SpmmTimer.install = lambda self: None
-    SpmmTimer.uninstall = lambda self: None
-
-
 SHARE_GPU = os.environ.get("SGF_BENCH_SHARE_GPU") == "1"
-
-
-def _enter_shared_gpu():
-    """SGF_BENCH_SHARE_GPU=1 (validation on a 1-GPU box; never a measurement): the N ranks of the driver's launch line all
-    run on cuda:0 — the node-sharded step with the REAL kernels of libsgf.so (own-column tile / stream SpMM, halo placement,
-    sgf_gather_rows packing, SyncBN statistics, fused Adam) and the real step sequence — while the transport is gloo with the
-    collective's tensors staged through the host (RCCL refuses two ranks on one device).  The printed line is marked
-    `shared_gpu`; its loss must equal the one-rank run's."""
-    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "all_to_all_single", "all_gather_into_tensor")}
-
-    class _Done:
-        def wait(self, *a, **k):
-            return True
-
-        def is_completed(self):
-            return True
-
-    def staged(name, outs, ins):
-        def call(*args, async_op=False, **kw):
-            args = list(args)
-            dev_t = {i: args[i] for i in set(outs) | set(ins) if i < len(args) and torch.is_tensor(args[i]) and args[i].is_cuda}
-            for i, t in dev_t.items():
-                args[i] = t.cpu() if i in ins else torch.empty(t.shape, dtype=t.dtype)
-            real[name](*args, **kw)
-            for i, t in dev_t.items():
-                if i in outs:
-                    t.copy_(args[i])
-            return _Done() if async_op else None
-        return call
-    dist.all_reduce = staged("all_reduce", outs=(0,), ins=(0,))
-    dist.broadcast = staged("broadcast", outs=(0,), ins=(0,))
-    dist.all_to_all_single = staged("all_to_all_single", outs=(0,), ins=(1,))
-    dist.all_gather_into_tensor = staged("all_gather_into_tensor", outs=(0,), ins=(1,))
 
 
 def main():
@@ -643,17 +594,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (see docstring)")
         args.gpus = world
-    if DRYRUN:
-        _enter_dryrun()
+    if DRYRUN:      # test-only mode (tests/test_dist.py): implemented under tests/, not here
+        from tests.bench_modes import enter_dryrun
+        enter_dryrun(sys.modules[__name__])
         if not args.nodes:
             raise SystemExit("SGF_BENCH_DRYRUN=1 needs --nodes (a few thousand)")
         dev = torch.device("cpu")
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback by design)")
-        if SHARE_GPU:
+        if SHARE_GPU:   # validation-only mode on a 1-GPU box: implemented under tests/, not here
             local_rank = 0
-            _enter_shared_gpu()
+            from tests.bench_modes import enter_shared_gpu
+            enter_shared_gpu()
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
 

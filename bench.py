@@ -153,6 +153,8 @@ def cpu_baseline(workload: str, n_sample: int, seed: int, budget_s: float = 20.0
     every core of a 256-core host (a first run with 256 threads was 8x SLOWER than 8 threads), so a
     short probe picks the fastest thread count, and the sample size is cut so that the timed part
     stays within ~`budget_s` seconds (cost is linear in N and nnz)."""
+    if workload == "cora":
+        return _cpu_baseline_cora(seed)
     n_full = synth.SHAPES[workload][0]
     cores = os.cpu_count() or 1
     probe_n = min(20000, n_full)
@@ -168,6 +170,42 @@ def cpu_baseline(workload: str, n_sample: int, seed: int, budget_s: float = 20.0
             "sample": f"{workload}-shaped uniform random graph cut to N={n} (nnz={nnz}), same recipe, "
                       f"fp32, dropout 0, fwd+loss+bwd, median of 3 after 1 warm-up, {dt * 1e3:.0f} ms/step, "
                       f"{best_t} of {cores} host threads (fastest of {cands} in a {probe_n}-node probe)"}
+
+
+def _cpu_baseline_cora(seed: int):
+    """BASELINE config 1 on the host: the oracle's restatement of medium/ours.py + medium/models.py GCN (oracle.medium_forward),
+    Cora shape at its full size (2 708 nodes), medium/run.sh:2-7 recipe, fp32, dropout 0, fwd + loss + bwd."""
+    from oracle import sgformer_oracle as O
+    from sgformer_amd import ours_medium as M
+    n, avg_deg, f, c, d = synth.SHAPES["cora"]
+    cfg = dict(num_layers=1, alpha=0.5, use_bn=False, use_residual=False, use_weight=False, graph_weight=0.8)
+    torch.manual_seed(seed)
+    gnn = M.GCN(f, d, d, num_layers=4, dropout=0.0, use_bn=False)
+    m = M.SGFormer(f, d, c, dropout=0.0, gnn=gnn, **cfg)
+    p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in m.state_dict().items()}
+    ei = synth.synthetic_graph(n, avg_deg, seed=seed)[:, :-n]
+    x = (torch.rand(n, f, generator=torch.Generator().manual_seed(seed)) < 0.0127).float()
+    _, y, idx = synth.synthetic_task(n, 4, c, seed=seed)
+    best = None
+    for threads in (1, 4, 8, 16):
+        if threads > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(threads)
+        times = []
+        for _ in range(6):
+            for v in p.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            O.nll_loss(O.medium_forward(p, x, ei, cfg, training=True), y, idx).backward()
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times[1:])[len(times[1:]) // 2]
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    dt, threads = best
+    return {"value": n / dt, "unit": "nodes/s", "cores": threads, "kind": "port",
+            "sample": f"Cora-shaped graph at its full size (N = {n}, nnz = {int(ei.shape[1])}), medium/run.sh:2-7 recipe, fp32, "
+                      f"dropout 0, fwd+loss+bwd, median of 5 after 1 warm-up, {dt * 1e3:.1f} ms/step, {threads} host threads "
+                      f"(fastest of 1 / 4 / 8 / 16)"}
 
 
 class SpmmTimer:
@@ -293,6 +331,9 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     steps (barrier + synchronize on both sides), return the measurements."""
     n, f, c, d, cfg, weak, ei, x, y, train_idx, n_train, ctx = make_inputs(args.workload, args.nodes, args.seed,
                                                                            rank, world, dev, graph_kind)
+    medium = args.workload == "cora"
+    if medium and (args.dtype != "f32" or ctx is not None):
+        raise SystemExit("--workload cora is BASELINE config 1 (medium/ours.py): fp32, one GPU")
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     # the features are handed to the model in fp32 EVERY step, exactly as an unchanged trainer does (large/main.py:130:
     # model(dataset.graph['node_feat'], ...)); the module keeps its storage-dtype (and row-permuted / zero-padded) copy of a
@@ -303,9 +344,35 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     torch.manual_seed(args.seed)
     p_trans, p_gnn = synth.RECIPE_DROPOUT.get(args.workload, (0.0, 0.0)) if args.dropout == "recipe" else (0.0, 0.0)
     # bf16 = bf16 activation storage with fp32 master weights and fp32 accumulation everywhere
-    model = SGFormer(f, d, c, trans_dropout=p_trans, gnn_dropout=p_gnn,
-                     compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
-    model.logits_dtype = torch.float32     # (fp32 features in -> fp32 logits out, as under sgformer_amd.launch)
+    if medium:
+        # BASELINE config 1: medium/ours.py SGFormer with the GCN backbone, medium/run.sh:2-7 (1 attention layer without
+        # LayerNorm / residual / Wv, GCN num_layers 4 hidden 64 without BatchNorm, graph_weight 0.8, alpha 0.5); the trainer
+        # symmetrises the edge list and adds no self-loops (medium/main.py:94) — GCNConv adds them itself; bag-of-words
+        # features (--no_feat_norm).  model(data) reads data.graph[...] (medium/ours.py:134-136).
+        from sgformer_amd import ours_medium as M
+        ei = ei[:, :-n].contiguous()
+        gx = torch.Generator().manual_seed(args.seed)
+        x = (torch.rand(n, f, generator=gx) < 0.0127).float().to(dev)
+        gnn = M.GCN(f, d, d, num_layers=4, dropout=p_gnn, use_bn=False)
+        core = M.SGFormer(f, d, c, num_layers=1, alpha=0.5, dropout=p_trans, use_bn=False, use_residual=False, use_weight=False,
+                          use_graph=True, graph_weight=0.8, gnn=gnn).to(dev)
+
+        class _Data:
+            def __init__(self, feat, edges):
+                self.graph = {"node_feat": feat, "edge_index": edges, "num_nodes": feat.shape[0]}
+
+        class _Wrap(torch.nn.Module):       # bench's step calls model(x, edge_index); the medium module takes the Data object
+            def __init__(self, core_):
+                super().__init__()
+                self.core, self.params1, self.params2 = core_, core_.params1, core_.params2
+
+            def forward(self, feat, edges):
+                return self.core(_Data(feat, edges))
+        model = _Wrap(core)
+    else:
+        model = SGFormer(f, d, c, trans_dropout=p_trans, gnn_dropout=p_gnn,
+                         compute_dtype=None if args.dtype == "f32" else dtype, **cfg).to(dev)
+        model.logits_dtype = torch.float32     # (fp32 features in -> fp32 logits out, as under sgformer_amd.launch)
     if ctx is not None:
         shard_model(model, ctx)
     # the optimizer exactly as the trainer constructs it (large/main.py:114-119); under sgformer_amd.launch — and here —
@@ -318,7 +385,7 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
     # per-graph, not per-step: CSR, node order, row-block plan (the trainers get the same lazily in their
     # first two epochs) — outside the timed region like every other one-off
     view_stats, t_prep = None, None
-    if ctx is None:
+    if ctx is None and not medium:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         view_stats = dict(ops.prepare_graph(ei, n).stats)
@@ -645,7 +712,7 @@ def main():
     r = run_workload(args, args.graph, rank, world, dev, args.steps, args.warmup, with_aten=True)
     structured = None
     if (rank == 0 and world == 1 and args.graph == "uniform" and not args.no_structured
-            and not args.workload.endswith("-weak")):
+            and not args.workload.endswith("-weak") and args.workload != "cora"):
         k = max(3, min(args.steps, 5))
         q = run_workload(args, "community", rank, world, dev, k, 3)
         structured = {

@@ -52,7 +52,7 @@ RECIPES["papers100M-weak"] = RECIPES["papers100M-shard8"]
 
 # (trans_dropout, gnn_dropout) of the same recipes: large/run.sh:2-5 (arxiv: 0.5 / 0.5), :15-19 and :22-26 (amazon2m / pokec:
 # 0 / 0), 100M/run.sh:3-7 (0.5 / 0.2)
-RECIPE_DROPOUT = {"ogbn-arxiv": (0.5, 0.5), "ogbn-products": (0.0, 0.0), "pokec": (0.0, 0.0),
+RECIPE_DROPOUT = {"cora": (0.2, 0.5), "ogbn-arxiv": (0.5, 0.5), "ogbn-products": (0.0, 0.0), "pokec": (0.0, 0.0),
                   "papers100M-shard8": (0.5, 0.2), "papers100M-weak": (0.5, 0.2)}
 
 

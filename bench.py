@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                   the launch stream inside the timed region, against 8 TB/s; `gather_bytes` is the no-reuse
                   traffic of the same launch (each stored entry fetching a d-wide row), the bound for a
                   uniform random graph (profiles/r02_gather_probe.md).  `traffic` = HBM bytes per launch
-                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r04_spmm_pmc.json,
+                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r05_spmm_pmc.json,
                   written by scripts/pmc_passes.sh; null when no pass has been recorded).
   structured    — the same training step and the same SpMM roofline on a graph of the same size WITH
                   community structure and RANDOMLY PERMUTED node ids (synth.synthetic_graph_community): the
@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 # scripts/spmm_pmc_target.py; FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM).  PMC
 # counters cannot be collected from inside this process, so the figures live in a tracked file written
 # from those passes, keyed on graph kind / dtype / kernel.
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_spmm_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_spmm_pmc.json")
 SPMM_SOURCES = ("spmm.hip", "spmm_tile.hip", "spmm_pack.hip", "spmm_plan.hip", "spmm_shared.h")
 
 
@@ -80,9 +80,9 @@ def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
     except (OSError, ValueError):
         return None, None
     if table.get("_source_sha16") != spmm_source_sha16():
-        return None, "profiles/r04_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
+        return None, "profiles/r05_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
     e = table.get(f"{graph_kind}/{dtype}/{kernel}/{'reordered' if reordered else 'given'}")
-    return (e["hbm_bytes_per_launch"], "profiles/r04_spmm_pmc.json") if e else (None, None)
+    return (e["hbm_bytes_per_launch"], "profiles/r05_spmm_pmc.json") if e else (None, None)
 
 
 def parse():

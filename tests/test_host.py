@@ -875,3 +875,49 @@ def test_patch_adam_keeps_generator_valued_param_groups(monkeypatch):
     finally:
         torch.optim.Adam.__init__ = orig
         torch.optim.Adam._sgf_patched = False
+
+
+@pytest.mark.parametrize("name,dtype", [("arxiv", None), ("products", torch.bfloat16)])
+def test_feature_width_that_is_not_a_multiple_of_4_is_padded_once_at_the_entry(cpu_table, name, dtype):
+    """r05 (pokec: f = 65, large/run.sh:22-26): SGFormer.forward zero-pads x to the next multiple of 4 columns in its entry copy
+    (K.pad_rows) and the stems run with zero-padded weight columns — same logits as the oracle, gradients in the PARAMETERS'
+    own shapes, and a feature tensor seen before is not copied again (the copy is keyed on identity + version)."""
+    from sgformer_amd import ops
+    from sgformer_amd.ours import SGFormer
+    cfg = CONFIGS[name]
+    n, f, d, c = 150, 13, 16, 3
+    torch.manual_seed(3)
+    x = torch.randn(n, f)
+    ei = O.synthetic_graph(n, 5.0, seed=4)
+    y = torch.randint(0, c, (n,))
+    idx = torch.arange(0, n, 2)
+    p = O.init_params(cfg, f, d, c, seed=5)
+    m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=dtype, **cfg)
+    m.load_state_dict({**m.state_dict(), **p})
+    m.train()
+    calls = []
+    real = ops.K.pad_rows
+    ops.K.pad_rows = staticmethod(lambda *a: (calls.append(a[2]), real(*a))[1])
+    try:
+        logits = m(x, ei)
+        O.nll_loss(logits.float(), y, idx).backward()
+        with torch.no_grad():
+            m(x, ei)
+        assert calls == [16], calls                      # 13 -> 16 columns, ONE copy for both forwards
+        x.add_(0.0)                                       # an in-place write bumps the version: the copy is redone
+        with torch.no_grad():
+            m(x, ei)
+        assert calls == [16, 16]
+    finally:
+        ops.K.pad_rows = real
+    p64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in p.items()}
+    ref = O.sgformer_forward(p64, x.double(), ei, cfg, training=True)
+    O.nll_loss(ref, y, idx).backward()
+    tol = 2e-5 if dtype is None else 6e-2
+    assert float((logits.detach().double() - ref.detach()).abs().max()) < tol * max(1.0, float(ref.detach().abs().max()))
+    for k, prm in m.named_parameters():
+        if p64[k].grad is not None:
+            assert prm.grad is not None and prm.grad.shape == prm.shape, k
+    if dtype is None:
+        for k in ("graph_conv.fcs.0.weight", "trans_conv.fcs.0.weight"):
+            assert _rel(dict(m.named_parameters())[k].grad, p64[k].grad) < 2e-3, k

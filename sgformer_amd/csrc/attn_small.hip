@@ -34,8 +34,11 @@ struct SmallWork {          // offsets in floats into the backward workspace
   int64_t gout, gsz, gpg, gwqk, ggt, gvx, gs, total;
 };
 
+// leading dimensions: rows padded to a multiple of 4 floats, so that sgf_gemm stages these operands with 16-byte loads
+__host__ __device__ inline int64_t ld4(int64_t n) { return (n + 3) / 4 * 4; }
+
 SmallLayout small_layout(int D, int d) {
-  const int64_t E = D + 1, d1 = d + 1;
+  const int64_t E = ld4(D + 1), d1 = ld4(d + 1);      // (sizes in the PADDED leading dimensions; the pad columns stay zero)
   SmallLayout L;
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += (n + 3) / 4 * 4; return at; };
@@ -50,7 +53,7 @@ SmallLayout small_layout(int D, int d) {
   return L;
 }
 SmallWork small_work(int D, int d) {
-  const int64_t E = D + 1, d1 = d + 1;
+  const int64_t E = ld4(D + 1), d1 = ld4(d + 1);
   SmallWork W;
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += (n + 3) / 4 * 4; return at; };
@@ -77,33 +80,40 @@ struct PackArgs {
 
 __global__ __launch_bounds__(kSmThreads) void k_small_pack(PackArgs p) {
   const int E = p.D + 1, d1 = p.d + 1;
-  const int64_t nG = static_cast<int64_t>(E) * E, nW = static_cast<int64_t>(2 * p.d) * E, nV = static_cast<int64_t>(E) * d1;
+  const int LE = static_cast<int>(ld4(E)), L1 = static_cast<int>(ld4(d1));
+  const int64_t nG = static_cast<int64_t>(LE) * LE, nW = static_cast<int64_t>(2 * p.d) * LE, nV = static_cast<int64_t>(LE) * L1;
   for (int64_t x = static_cast<int64_t>(blockIdx.x) * kSmThreads + threadIdx.x; x < nG + nW + nV;
        x += static_cast<int64_t>(gridDim.x) * kSmThreads) {
     if (x < nG) {
-      const int i = static_cast<int>(x / E), j = static_cast<int>(x % E);
-      float v;
-      if (i < p.D && j < p.D) v = p.G[i * p.ldg + j];
-      else if (i < p.D) v = p.s[i];
-      else if (j < p.D) v = p.s[j];
-      else v = p.n_rows;
+      const int i = static_cast<int>(x / LE), j = static_cast<int>(x % LE);
+      float v = 0.f;                                   // (pad rows / columns: zero)
+      if (i < E && j < E) {
+        if (i < p.D && j < p.D) v = p.G[i * p.ldg + j];
+        else if (i < p.D) v = p.s[i];
+        else if (j < p.D) v = p.s[j];
+        else v = p.n_rows;
+      }
       p.Gt[x] = v;
     } else if (x < nG + nW) {
       const int64_t y = x - nG;
-      const int r = static_cast<int>(y / E), c = static_cast<int>(y % E);
-      float v;
-      if (r < p.d) v = c < p.D ? p.wq[r * p.ldwq + c] : (p.bq ? p.bq[r] : 0.f);
-      else v = c < p.D ? p.wk[(r - p.d) * p.ldwk + c] : (p.bk ? p.bk[r - p.d] : 0.f);
+      const int r = static_cast<int>(y / LE), c = static_cast<int>(y % LE);
+      float v = 0.f;
+      if (c < E) {
+        if (r < p.d) v = c < p.D ? p.wq[r * p.ldwq + c] : (p.bq ? p.bq[r] : 0.f);
+        else v = c < p.D ? p.wk[(r - p.d) * p.ldwk + c] : (p.bk ? p.bk[r - p.d] : 0.f);
+      }
       p.Wqk[y] = v;
     } else {
       const int64_t y = x - nG - nW;
-      const int i = static_cast<int>(y / d1), j = static_cast<int>(y % d1);
-      float v;
-      if (j < p.d) {
-        if (i < p.D) v = p.wv ? p.wv[j * p.ldwv + i] : (i == j ? 1.f : 0.f);
-        else v = (p.wv && p.bv) ? p.bv[j] : 0.f;
-      } else {
-        v = i == p.D ? 1.f : 0.f;
+      const int i = static_cast<int>(y / L1), j = static_cast<int>(y % L1);
+      float v = 0.f;
+      if (i < E && j < d1) {
+        if (j < p.d) {
+          if (i < p.D) v = p.wv ? p.wv[j * p.ldwv + i] : (i == j ? 1.f : 0.f);
+          else v = (p.wv && p.bv) ? p.bv[j] : 0.f;
+        } else {
+          v = i == p.D ? 1.f : 0.f;
+        }
       }
       p.Vx[y] = v;
     }
@@ -146,13 +156,14 @@ __global__ __launch_bounds__(kSmThreads) void k_small_out(const float* __restric
                                                           const float* __restrict__ scal, float n_total, int D, int d,
                                                           float* __restrict__ M, int64_t ldm, float* __restrict__ m,
                                                           float* __restrict__ w, float* __restrict__ beta) {
-  const int d1 = d + 1;
+  const int d1 = d + 1, L1 = static_cast<int>(ld4(d1));
   const int64_t total = static_cast<int64_t>(D + 1) * d1;
   const float c = scal[2];
   for (int64_t x = static_cast<int64_t>(blockIdx.x) * kSmThreads + threadIdx.x; x < total;
        x += static_cast<int64_t>(gridDim.x) * kSmThreads) {
     const int i = static_cast<int>(x / d1), j = static_cast<int>(x % d1);
-    const float v = fmaf(c, T[x], n_total * Vx[x]);
+    const int64_t q = static_cast<int64_t>(i) * L1 + j;
+    const float v = fmaf(c, T[q], n_total * Vx[q]);
     if (i < D && j < d) M[i * ldm + j] = v;
     else if (i == D && j < d) m[j] = v;
     else if (i < D) w[i] = v;
@@ -160,25 +171,29 @@ __global__ __launch_bounds__(kSmThreads) void k_small_out(const float* __restric
   }
 }
 
-// gOut from the reduced gradients (dM [D, d], dw [D], dm [d], dbeta [1]); gc = <gOut, T>; gs = -gc c / (2 ssq).  One block.
+// gOut from the reduced gradients (dM [D, d], dw [D], dm [d], dbeta [1]); gc = <gOut, T>; gs = -gc c / (2 ssq).  One block:
+// a thread owns columns j = tid, tid + 1024, ... and walks the rows (coalesced, no integer division).
 __global__ __launch_bounds__(kRedThreads) void k_small_bwd_prep(const float* __restrict__ dM, int64_t lddm,
                                                                 const float* __restrict__ dw, const float* __restrict__ dm,
                                                                 const float* __restrict__ dbeta, const float* __restrict__ T,
                                                                 const float* __restrict__ scal, int D, int d,
                                                                 float* __restrict__ gOut, float* __restrict__ gs) {
   __shared__ float red[kRedThreads / 64];
-  const int d1 = d + 1;
-  const int64_t total = static_cast<int64_t>(D + 1) * d1;
+  const int d1 = d + 1, L1 = static_cast<int>(ld4(d1)), LE = static_cast<int>(ld4(D + 1));
   float acc = 0.f;
-  for (int64_t x = threadIdx.x; x < total; x += kRedThreads) {
-    const int i = static_cast<int>(x / d1), j = static_cast<int>(x % d1);
-    float v;
-    if (i < D && j < d) v = dM[i * lddm + j];
-    else if (i == D && j < d) v = dm[j];
-    else if (i < D) v = dw[i];
-    else v = dbeta[0];
-    gOut[x] = v;
-    acc = fmaf(v, T[x], acc);
+  for (int j = threadIdx.x; j < L1; j += kRedThreads) {
+    for (int i = 0; i < LE; ++i) {
+      float v = 0.f;
+      if (i <= D && j < d1) {
+        if (i < D && j < d) v = dM[i * lddm + j];
+        else if (i == D && j < d) v = dm[j];
+        else if (i < D) v = dw[i];
+        else v = dbeta[0];
+      }
+      const int64_t q = static_cast<int64_t>(i) * L1 + j;
+      gOut[q] = v;
+      acc = fmaf(v, T[q], acc);
+    }
   }
   const float gc = block_sum_fixed(acc, red);
   if (threadIdx.x == 0) {
@@ -212,6 +227,7 @@ struct UnpackArgs {
 
 __global__ __launch_bounds__(kSmThreads) void k_small_bwd_unpack(UnpackArgs p) {
   const int E = p.D + 1, d1 = p.d + 1;
+  const int LE = static_cast<int>(ld4(E)), L1 = static_cast<int>(ld4(d1));
   const int64_t nD = static_cast<int64_t>(p.D) * E;            // Dsym rows + the ds column
   const int64_t nW = static_cast<int64_t>(2 * p.d) * E;
   const int64_t nV = static_cast<int64_t>(E) * p.d;
@@ -219,13 +235,13 @@ __global__ __launch_bounds__(kSmThreads) void k_small_bwd_unpack(UnpackArgs p) {
        x += static_cast<int64_t>(gridDim.x) * kSmThreads) {
     if (x < nD) {
       const int i = static_cast<int>(x / E), j = static_cast<int>(x % E);
-      const float v = p.gGt[static_cast<int64_t>(i) * E + j] + p.gGt[static_cast<int64_t>(j) * E + i];
+      const float v = p.gGt[static_cast<int64_t>(i) * LE + j] + p.gGt[static_cast<int64_t>(j) * LE + i];
       if (j < p.D) p.Dsym[i * p.lddd + j] = v;
       else p.ds[i] = v;
     } else if (x < nD + nW) {
       const int64_t y = x - nD;
       const int r = static_cast<int>(y / E), c = static_cast<int>(y % E);
-      const float v = p.gWqk[y];
+      const float v = p.gWqk[static_cast<int64_t>(r) * LE + c];
       if (r < p.d) {
         if (c < p.D) { if (p.gwq) p.gwq[r * p.ldgq + c] = v; }
         else if (p.gbq) p.gbq[r] = v;
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(kSmThreads) void k_small_bwd_unpack(UnpackArgs p) {
     } else {
       const int64_t y = x - nD - nW;
       const int i = static_cast<int>(y / p.d), j = static_cast<int>(y % p.d);     // gVx[i, j] -> gwv[j, i] / gbv[j]
-      const float v = p.gVx[static_cast<int64_t>(i) * d1 + j];
+      const float v = p.gVx[static_cast<int64_t>(i) * L1 + j];
       if (i < p.D) { if (p.gwv) p.gwv[j * p.ldgv + i] = v; }
       else if (p.gbv) p.gbv[j] = v;
     }
@@ -277,7 +293,9 @@ extern "C" int sgf_attn_h_small_fwd(const float* G, int64_t ldg, const float* s,
               "sgf_attn_h_small_fwd: saved buffer of %zu bytes, need %zu", saved_bytes, static_cast<size_t>(L.total) * sizeof(float));
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* base = static_cast<float*>(saved);
-  const int D = d_in, d = d_out, E = D + 1, d1 = d + 1;
+  // E, d1: the PADDED extents (multiples of 4).  Pad rows / columns of every operand are zero (k_small_pack, k_small_bwd_prep)
+  // and every product below maps zero pads to zero pads, so the padded products equal the logical ones exactly.
+  const int D = d_in, d = d_out, E = static_cast<int>(ld4(D + 1)), d1 = static_cast<int>(ld4(d + 1));
   float *Gt = base + L.gt, *Wqk = base + L.wqk, *Vx = base + L.vx, *PG = base + L.pg, *SZ = base + L.sz, *T = base + L.t,
         *scal = base + L.scal;
   PackArgs pa{G, ldg, s, n_rows, wq, bq, wk, bk, wv, bv, ldw, ldw, ldw, D, d, Gt, Wqk, Vx};
@@ -320,7 +338,9 @@ extern "C" int sgf_attn_h_small_bwd(const float* dM, int64_t lddm, const float* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(saved);
   float* wsp = static_cast<float*>(workspace);
-  const int D = d_in, d = d_out, E = D + 1, d1 = d + 1;
+  // E, d1: the PADDED extents (multiples of 4).  Pad rows / columns of every operand are zero (k_small_pack, k_small_bwd_prep)
+  // and every product below maps zero pads to zero pads, so the padded products equal the logical ones exactly.
+  const int D = d_in, d = d_out, E = static_cast<int>(ld4(D + 1)), d1 = static_cast<int>(ld4(d + 1));
   const float *Gt = base + L.gt, *Wqk = base + L.wqk, *Vx = base + L.vx, *PG = base + L.pg, *SZ = base + L.sz, *T = base + L.t,
               *scal = base + L.scal;
   float *gOut = wsp + W.gout, *gSZ = wsp + W.gsz, *gPG = wsp + W.gpg, *gWqk = wsp + W.gwqk, *gGt = wsp + W.ggt, *gVx = wsp + W.gvx,

@@ -1633,4 +1633,12 @@ def out_linear(x, w, b):
         wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
         bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
         return _Linear.apply(wp, bp, None, x)[:, :m]
+    if x.dtype == _BF16 and x.dim() == 2 and m % 8 != 0 and not K.gcn_epilogue_supported(w.shape[1], m, _BF16):
+        # bf16 storage and a class count whose rows would not be 16-byte aligned (the 100M recipe: C = 172 -> 344-byte rows):
+        # W / b padded with zero rows to the next multiple of 8, so that sgf_gemm stages the logits' gradient with 16-byte
+        # loads in the backward (dx = g W) as it stages x in the forward; the result is sliced, autograd slices back
+        pad = (m + 7) // 8 * 8 - m
+        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
+        return _Linear.apply(wp, bp, None, x)[:, :m]
     return _Linear.apply(w, b, None, x)

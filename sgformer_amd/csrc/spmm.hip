@@ -616,8 +616,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_sub(
   store4<T>(y + row * ldy + fc, acc);
 }
 
-// one workgroup per queued (row, segment): wave w takes the entries e0 + w*UNROLL + j*4*UNROLL ...;
-// lane l owns features [4l, 4l+4) of each 256-feature panel; partial[slot][d] fp32
+// one workgroup per queued (row, segment): wave w takes the 64-entry pieces w, w + NW, ... of the segment;
+// lane l owns features [4l, 4l+4) of each 256-feature panel; partial[slot][d] fp32.
+// r05: a piece's source ids and values arrive as ONE coalesced vector load each (lane j <- entry j) and are handed to the
+// gathers through v_readlane — the row index of a gather is then wave-uniform (scalar address arithmetic, one vector load
+// per entry, UNROLL of them in flight) where the first form issued two same-address vector loads and a 64-bit multiply per
+// entry and lane: on the R-MAT graph (hub rows of 10^4-10^5 entries: 45 % of the stored entries take this path) the
+// kernel moved its bytes at 3.9 TB/s against 7.2 for the row kernel next to it (profiles/r05_spmm_pmc.md).
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_long_seg(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
@@ -640,13 +645,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_spmm_long_seg(
       const bool active = fc < d;
       const T* xl = x + (active ? fc : 0);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int64_t e = e0 + wave * UNROLL; e < e1; e += kWavesPerBlock * UNROLL) {
+      for (int64_t e = e0 + wave * 64; e < e1; e += kWavesPerBlock * 64) {
+        const int64_t mine = e + lane;
+        const int32_t c_l = mine < e1 ? colind[mine] : 0;              // lane j <- entry j of this piece
+        const float v_l = mine < e1 ? val[mine] : 0.f;
+        const int n = e1 - e < 64 ? static_cast<int>(e1 - e) : 64;     // wave-uniform
+        for (int j0 = 0; j0 < n; j0 += UNROLL) {
+          float4 xv[UNROLL];
+          float vv[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-          if (e + u < e1) {
-            const float4 xv = load4<T>(xl + static_cast<int64_t>(colind[e + u]) * ldx);
-            fma4(acc, val[e + u], xv);
+          for (int u = 0; u < UNROLL; ++u) {
+            const int j = j0 + u < n ? j0 + u : n - 1;                  // (a clamped repeat carries weight 0)
+            const int32_t cj = __builtin_amdgcn_readlane(c_l, j);
+            vv[u] = j0 + u < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_l), j)) : 0.f;
+            xv[u] = load4<T>(xl + static_cast<int64_t>(cj) * ldx);
           }
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+            if (j0 + u < n) fma4(acc, vv[u], xv[u]);
         }
       }
       red[wave][lane] = acc;

@@ -60,6 +60,15 @@ def _side_stream(device):
     return s
 
 
+class _Holder:
+    """Where SGFormer.forward keeps the entry copy of a feature tensor when there is no graph view to keep it with."""
+    _x_cache = None
+
+
+import weakref as _weakref
+_entry_cache = _weakref.WeakKeyDictionary()
+
+
 def _stem_w(lin: nn.Linear, x):
     """lin.weight for an input SGFormer.forward zero-padded to a multiple of 4 columns (pokec: f = 65 -> 68; sgf_pad_rows):
     zero weight columns for the padding, differentiable — autograd slices dW back to the parameter's shape."""
@@ -587,7 +596,9 @@ class SGFormer(nn.Module):
             elif x.dtype != cdt:
                 x = x.to(cdt)
         elif perm is not None or pad or x.dtype != cdt:
-            holder = view if view is not None else self
+            # (kept with the graph view, or — without one — in a weak table keyed on the module: NOT an attribute of the
+            # module, which `copy.deepcopy(model)` of 100M/nb-sample.py:197 would duplicate together with the features)
+            holder = view if view is not None else _entry_cache.setdefault(self, _Holder())
             key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, cdt, bool(pad), perm is not None)
             hit = getattr(holder, "_x_cache", None)
             if hit is None or hit[0] != key:
@@ -598,7 +609,7 @@ class SGFormer(nn.Module):
                 else:
                     xe = x.to(cdt)
                 hit = (key, xe, x)
-                object.__setattr__(holder, "_x_cache", hit)
+                holder._x_cache = hit
             x = hit[1]
         # K10: the first Linear of both branches reads the same x — one pass, two outputs, the GCN stem's BatchNorm
         # sums on the way (bf16 storage, <= 128 input features)

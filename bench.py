@@ -81,8 +81,19 @@ def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
         return None, None
     if table.get("_source_sha16") != spmm_source_sha16():
         return None, "profiles/r05_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
-    e = table.get(f"{graph_kind}/{dtype}/{kernel}/{'reordered' if reordered else 'given'}")
-    return (e["hbm_bytes_per_launch"], "profiles/r05_spmm_pmc.json") if e else (None, None)
+    tag = "reordered" if reordered else "given"
+    e = table.get(f"{graph_kind}/{dtype}/{kernel}/{tag}")
+    if not e:
+        return None, None
+    total = e["hbm_bytes_per_launch"]
+    if kernel in ("k_spmm_row", "k_spmm_seg_bf16x2"):
+        # one sgf_spmm call = the row kernel + the long-row path (hub rows: k_spmm_long_seg / _fin), timed together by the
+        # HIP events above — so their traffic is reported together too (R-MAT: 29.8 + 24.1 + 0.1 GB)
+        for extra in ("k_spmm_long_seg", "k_spmm_long_fin"):
+            x = table.get(f"{graph_kind}/{dtype}/{extra}/{tag}") or table.get(f"{graph_kind}/{dtype}/{extra}/given")
+            if x:
+                total += x["hbm_bytes_per_launch"]
+    return total, "profiles/r05_spmm_pmc.json"
 
 
 def parse():

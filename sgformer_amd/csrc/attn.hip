@@ -324,27 +324,31 @@ __global__ void k_gram_finalize(const float* __restrict__ partial, int nblk, int
   }
 }
 
-// sgf_attn_h_bwd_reduce: hstats = [ dM (d*d) | dw (d) | dm (d) | dbeta ] from the per-block partials.
+// sgf_attn_h_bwd_reduce: hstats = [ dM (d*d) | dw (d) | dm (d) | dbeta ] from the per-block partials.  Four threads per
+// element, each walking every fourth partial, added in the fixed order (s0 + s1) + (s2 + s3) — as k_gram_finalize (r05: one
+// thread per element walked all 256 partials in a single dependent chain: 91 us per call).
 __global__ void k_hbwd_finalize(const float* __restrict__ partial, int nblk, int d, int DP, int RG,
                                 float* __restrict__ out) {
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t idx = tid >> 2;
+  const int q = static_cast<int>(tid & 3);
   const int64_t nmat = static_cast<int64_t>(d) * d;
+  float s = 0.f;
   if (idx < nmat) {
     const int m = static_cast<int>(idx / d);
     const int dd = static_cast<int>(idx % d);
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = q; b < nblk; b += 4) {
       const float* part = partial + static_cast<int64_t>(b) * kPartialStride;
       for (int g = 0; g < RG; ++g) s += part[(g * DP + m) * DP + dd];
     }
-    out[idx] = s;
   } else if (idx < nmat + 2 * d + 1) {
     const int j = static_cast<int>(idx - nmat);
     const int off = j < d ? kTileElems + j : (j < 2 * d ? kVecB + (j - d) : kTileElems + DP);
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * kPartialStride + off];
-    out[idx] = s;
+    for (int b = q; b < nblk; b += 4) s += partial[static_cast<int64_t>(b) * kPartialStride + off];
   }
+  const float s01 = s + __shfl_xor(s, 1, 64);
+  const float t = s01 + __shfl_xor(s01, 2, 64);
+  if (q == 0 && idx < nmat + 2 * d + 1) out[idx] = t;
 }
 
 // sdot = <S0,dS0> + <z0,dz0> over all heads: one block, fixed-order tree -> deterministic.
@@ -1577,7 +1581,7 @@ int h_bwd_reduce_t(const void* h, int64_t ldh, const void* g, int64_t ldg, const
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<T, kModeBwdH>(DP);
   const int64_t len = sgf_attn_h_bstats_len(d);
-  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
                      a.partial, nblk, d, DP, RG, hstats);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -1722,7 +1726,7 @@ extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const vo
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<uint16_t, kModeBwdHS>(DP);
   const int64_t len = sgf_attn_h_bstats_len(d);
-  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, st, a.partial, nblk, d,
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, a.partial, nblk, d,
                      DP, RG, hstats);
   SGF_LAUNCH_CHECK();
   return SGF_OK;

@@ -111,9 +111,10 @@ int sgf_subgraph_emit(const int64_t* edge_index, int64_t nnz, int64_t n, const i
  *     sgf_csr_build returns for torch_geometric's subgraph(subset, edge_index, relabel_nodes=True);
  *     edge_index_b int64 [2, total] (optional): that edge list in (target, source) order — the same multiset of edges as
  *     the reference's, whose order (the parent's edge order) no consumer on the path depends on.
- * Two calls around ONE host read:  _plan -> total[0] = number of kept entries, total[1] = 1 if `subset` repeats a node or
- * holds an id outside [0, n) (then call _emit with total = 0, which only resets the table, and use sgf_subgraph_* instead);
- * _emit with the value read.  local_of: int32 [n] owned by the caller, all -1 between calls (the library restores it).
+ * Two calls around ONE host read:  _plan -> total (int64 [3]): total[0] = number of kept entries, total[1] = 1 if `subset`
+ * repeats a node or holds an id outside [0, n) (then call _emit with total = 0, which only resets the table, and use
+ * sgf_subgraph_* instead), total[2] = the longest row of the batch CSR (<= sgf_spmm's long-row threshold: sgf_spmm_split is
+ * not needed for it); _emit with the value read.  local_of: int32 [n] owned by the caller, all -1 between calls (the library restores it).
  * deg_b has m + 1 slots (the last one is scratch).  Workspaces: _plan_workspace_bytes(m), _emit_workspace_bytes(m, total). */
 size_t sgf_subgraph_csr_plan_workspace_bytes(int64_t m);
 size_t sgf_subgraph_csr_emit_workspace_bytes(int64_t m, int64_t total);

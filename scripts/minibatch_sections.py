@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=12)
     ap.add_argument("--batch", type=int, default=100000)
+    ap.add_argument("--loss-detail", action="store_true")
+    ap.add_argument("--gather-detail", action="store_true")
     a = ap.parse_args()
     launch.limit_host_threads()
     dev = torch.device("cuda:0")
@@ -39,6 +41,10 @@ def main():
     criterion = torch.nn.NLLLoss()
     idx = torch.randperm(n)
     names = ["gather", "subgraph", "forward", "loss", "backward", "optimizer"]
+    if a.gather_detail:
+        names[1:1] = ["gather_x", "gather_y_host", "gather_y_copy"]
+    if a.loss_detail:
+        names[names.index("loss") + 1:names.index("loss") + 1] = ["loss_rows", "loss_targets", "loss_criterion"]
     issue = {k: 0.0 for k in names}
     done = {k: 0.0 for k in names}
 
@@ -62,7 +68,13 @@ def main():
 
         def gather():
             return train_mask[idx_i], x[idx_i].to(dev), true_label[idx_i].to(dev)
-        train_mask_i, x_i, y_i = section("gather", gather)
+        if a.gather_detail:
+            train_mask_i = section("gather", lambda: train_mask[idx_i])
+            x_i = section("gather_x", lambda: x[idx_i].to(dev))
+            y_host = section("gather_y_host", lambda: true_label[idx_i])
+            y_i = section("gather_y_copy", lambda: y_host.to(dev))
+        else:
+            train_mask_i, x_i, y_i = section("gather", gather)
         ei_i = section("subgraph", lambda: batching.subgraph(idx_i, ei, num_nodes=n, relabel_nodes=True)[0].to(dev))
         opt.zero_grad()
         out_i = section("forward", lambda: model(x_i, ei_i))
@@ -70,7 +82,13 @@ def main():
         def loss_fn():
             o = F.log_softmax(out_i, dim=1)
             return criterion(o[train_mask_i], y_i.squeeze(1)[train_mask_i])
-        loss = section("loss", loss_fn)
+        if a.loss_detail:
+            o = section("loss", lambda: F.log_softmax(out_i, dim=1))
+            rows = section("loss_rows", lambda: o[train_mask_i])
+            tgt = section("loss_targets", lambda: y_i.squeeze(1)[train_mask_i])
+            loss = section("loss_criterion", lambda: criterion(rows, tgt))
+        else:
+            loss = section("loss", loss_fn)
         section("backward", loss.backward)
         section("optimizer", opt.step)
     nb = a.batches

@@ -100,8 +100,9 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
         sub = subset.contiguous().long()
         got = ops.K.subgraph_csr(parent.rowptr, parent.colind, n, sub, parent.local_of, True)
         if got is not None:
-            rowptr_b, colind_b, val_b, deg_b, out = got
+            rowptr_b, colind_b, val_b, deg_b, out, longest = got
             out._sgf_trusted = True
+            out._sgf_max_in_degree = longest              # (read with the batch's size: no long-row path for most batches)
             out._sgf_csr = (rowptr_b, colind_b, val_b, deg_b)
             out._sgf_symmetric = parent.symmetric
             return out, None

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kSmThreads) void k_small_out(const float* __restric
 }
 
 // gOut from the reduced gradients (dM [D, d], dw [D], dm [d], dbeta [1]); gc = <gOut, T>; gs = -gc c / (2 ssq).  One block:
-// a thread owns columns j = tid, tid + 1024, ... and walks the rows (coalesced, no integer division).
+// a thread owns a column (and, with threads to spare, every R-th row of it) and walks the rows (coalesced).
 __global__ __launch_bounds__(kRedThreads) void k_small_bwd_prep(const float* __restrict__ dM, int64_t lddm,
                                                                 const float* __restrict__ dw, const float* __restrict__ dm,
                                                                 const float* __restrict__ dbeta, const float* __restrict__ T,
@@ -181,18 +181,25 @@ __global__ __launch_bounds__(kRedThreads) void k_small_bwd_prep(const float* __r
   __shared__ float red[kRedThreads / 64];
   const int d1 = d + 1, L1 = static_cast<int>(ld4(d1)), LE = static_cast<int>(ld4(D + 1));
   float acc = 0.f;
-  for (int j = threadIdx.x; j < L1; j += kRedThreads) {
-    for (int i = 0; i < LE; ++i) {
-      float v = 0.f;
-      if (i <= D && j < d1) {
-        if (i < D && j < d) v = dM[i * lddm + j];
-        else if (i == D && j < d) v = dm[j];
-        else if (i < D) v = dw[i];
-        else v = dbeta[0];
+  // R row groups share a column when the block has threads to spare (d = 256: 260 columns, 3 groups): thread (q, j) walks
+  // rows q, q + R, ... — independent loads, four in flight; the block sum below adds the threads in a fixed order
+  const int R = L1 < kRedThreads ? kRedThreads / L1 : 1;
+  const int q0 = static_cast<int>(threadIdx.x) / L1, j0 = static_cast<int>(threadIdx.x) % L1;
+  if (q0 < R) {
+    for (int j = j0; j < L1; j += (R > 1 ? L1 : kRedThreads)) {
+#pragma unroll 4
+      for (int i = q0; i < LE; i += R) {
+        float v = 0.f;
+        if (i <= D && j < d1) {
+          if (i < D && j < d) v = dM[i * lddm + j];
+          else if (i == D && j < d) v = dm[j];
+          else if (i < D) v = dw[i];
+          else v = dbeta[0];
+        }
+        const int64_t q = static_cast<int64_t>(i) * L1 + j;
+        gOut[q] = v;
+        acc = fmaf(v, T[q], acc);
       }
-      const int64_t q = static_cast<int64_t>(i) * L1 + j;
-      gOut[q] = v;
-      acc = fmaf(v, T[q], acc);
     }
   }
   const float gc = block_sum_fixed(acc, red);

@@ -93,8 +93,10 @@ template <bool FILL>
 __global__ __launch_bounds__(kThreads) void k_walk(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                    const int64_t* __restrict__ subset, int64_t m, int64_t n,
                                                    const int32_t* __restrict__ local_of, int32_t* __restrict__ cnt,
-                                                   const int64_t* __restrict__ rowptr_b, int32_t* __restrict__ out) {
+                                                   const int64_t* __restrict__ rowptr_b, int32_t* __restrict__ out,
+                                                   int32_t* __restrict__ longest) {
   const int lane = threadIdx.x & (kWave - 1);
+  int wave_max = 0;
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x / kWave);
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   for (int64_t j = wave0; j < m; j += nwaves) {
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(kThreads) void k_walk(const int64_t* __restrict__ r
       total += __popcll(mask);
     }
     if (!FILL && lane == 0) cnt[j] = total;
+    if (!FILL) wave_max = max(wave_max, total);
   }
+  if (!FILL && lane == 0 && wave_max > 0) atomicMax(longest, wave_max);      // one per wave: the longest row of the batch CSR
 }
 
 __global__ __launch_bounds__(kThreads) void k_off32(const int64_t* __restrict__ rowptr_b, int64_t m1, int32_t* __restrict__ off32) {
@@ -125,11 +129,13 @@ __global__ __launch_bounds__(kThreads) void k_off32(const int64_t* __restrict__ 
     off32[j] = static_cast<int32_t>(rowptr_b[j]);
 }
 
-// total[0] = number of kept entries, total[1] = duplicate / out-of-range flag: the caller's one host read covers both
-__global__ void k_total(const int64_t* __restrict__ rowptr_b, int64_t m, const int32_t* __restrict__ dup, int64_t* __restrict__ total) {
+// total[0] = number of kept entries, total[1] = duplicate / out-of-range flag, total[2] = the longest row of the batch CSR
+// (its largest induced in-degree: what the SpMM needs to know to skip its long-row path): the caller's one host read covers all
+__global__ void k_total(const int64_t* __restrict__ rowptr_b, int64_t m, const int32_t* __restrict__ flags, int64_t* __restrict__ total) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     total[0] = rowptr_b[m];
-    total[1] = *dup;
+    total[1] = flags[0];
+    total[2] = flags[1];
   }
 }
 
@@ -191,13 +197,13 @@ extern "C" int sgf_subgraph_csr_plan(const int64_t* rowptr, const int32_t* colin
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
   int32_t* dup = reinterpret_cast<int32_t*>(ws + p.flag);
-  SGF_CHECK_HIP(hipMemsetAsync(dup, 0, 4, st));
+  SGF_CHECK_HIP(hipMemsetAsync(dup, 0, 8, st));               // [duplicate flag | longest row]
   SGF_CHECK_HIP(hipMemsetAsync(deg_b + m, 0, 4, st));          // deg_b has m + 1 slots: the scan's last input is 0
   if (m > 0) {
     hipLaunchKernelGGL(k_mark, dim3(grid_rows(m, kThreads)), dim3(kThreads), 0, st, subset, m, n, local_of, dup);
     SGF_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_walk<false>), dim3(grid_rows(m, kWavesPerBlock)), dim3(kThreads), 0, st, rowptr, colind, subset, m, n,
-                       local_of, deg_b, static_cast<const int64_t*>(nullptr), static_cast<int32_t*>(nullptr));
+                       local_of, deg_b, static_cast<const int64_t*>(nullptr), static_cast<int32_t*>(nullptr), dup + 1);
     SGF_LAUNCH_CHECK();
   }
   size_t tb = p.tmp_bytes;
@@ -230,7 +236,7 @@ extern "C" int sgf_subgraph_csr_emit(const int64_t* rowptr, const int32_t* colin
     hipLaunchKernelGGL(k_off32, dim3(grid_rows(m + 1, kThreads)), dim3(kThreads), 0, st, rowptr_b, m + 1, off32);
     SGF_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_walk<true>), dim3(grid_rows(m, kWavesPerBlock)), dim3(kThreads), 0, st, rowptr, colind, subset, m, n,
-                       local_of, static_cast<int32_t*>(nullptr), rowptr_b, tmpcol);
+                       local_of, static_cast<int32_t*>(nullptr), rowptr_b, tmpcol, static_cast<int32_t*>(nullptr));
     SGF_LAUNCH_CHECK();
     int bits = 1;
     while ((int64_t{1} << bits) < m) ++bits;

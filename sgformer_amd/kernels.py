@@ -154,17 +154,18 @@ class HipKernels:
     @staticmethod
     def subgraph_csr(rowptr, colind, n: int, subset: torch.Tensor, local_of: torch.Tensor, want_edges: bool):
         """Induced subgraph + its normalised CSR from the parent CSR (sgf_subgraph_csr_*): (rowptr_b, colind_b, val_b, deg_b,
-        edge_index_b | None), or None when `subset` repeats a node / leaves the graph (the caller takes sgf_subgraph_*)."""
+        edge_index_b | None, longest row), or None when `subset` repeats a node / leaves the graph (the caller takes
+        sgf_subgraph_*)."""
         dev, m = rowptr.device, int(subset.numel())
         lib = _lib.load()
         rowptr_b = torch.empty(m + 1, dtype=torch.int64, device=dev)
         deg_b = torch.empty(m + 1, dtype=torch.int32, device=dev)
-        total = torch.empty(2, dtype=torch.int64, device=dev)
+        total = torch.empty(3, dtype=torch.int64, device=dev)
         ws = _workspace(dev, "subgraph_csr_plan", lib.sgf_subgraph_csr_plan_workspace_bytes(m))
         with torch.cuda.device(dev):
             _lib.call("sgf_subgraph_csr_plan", _ptr(rowptr), _ptr(colind), n, _ptr(subset), m, _ptr(local_of), _ptr(rowptr_b),
                       _ptr(deg_b), _ptr(total), _ptr(ws), ws.numel(), _stream(dev))
-            t, bad = total.tolist()                         # the one host read of the batch
+            t, bad, longest = total.tolist()                # the one host read of the batch
             t = 0 if bad else int(t)
             colind_b = torch.empty(t, dtype=torch.int32, device=dev)
             val_b = torch.empty(t, dtype=_F32, device=dev)
@@ -174,7 +175,7 @@ class HipKernels:
                       _ptr(deg_b), t, _ptr(colind_b), _ptr(val_b), _ptr(ei_b), _ptr(ws2), ws2.numel(), _stream(dev))
         if bad:
             return None
-        return rowptr_b, colind_b, val_b, deg_b[:m], ei_b
+        return rowptr_b, colind_b, val_b, deg_b[:m], ei_b, int(longest)
 
     # ---- N2: trainer prologue (to_undirected / remove_self_loops / add_self_loops) ----
     @staticmethod

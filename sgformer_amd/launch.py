@@ -248,12 +248,17 @@ def unpatch_nll_loss():
 
 
 def limit_host_threads():
-    """torch's CPU kernels (the trainer's host-side index / mask ops) slow DOWN beyond ~16 threads on the
-    256-thread hosts of MI355X boxes and their OpenMP team then competes with the launch thread (the 75 ms
-    stalls of profiles/r01_minibatch_probe.md).  Respect OMP_NUM_THREADS if the user set it."""
+    """The mini-batch trainer's host lines (large/main-batch.py:134-146) index 100 k-element masks and labels per batch:
+    torch's CPU kernels split that over its OpenMP team, and on the 256-thread hosts of MI355X boxes every parallel region
+    then waits for its slowest thread, on a shared host for milliseconds (r01: 75 ms stalls with the default 128+ threads;
+    r05, epoch of 25 batches, same box, back to back: 16 threads 11.1 / 11.6, 1 thread 15.6 / 15.7, 4 threads 17.4 / 17.7
+    M nodes/s — profiles/r05_minibatch_threads.md).  4 threads; OMP_NUM_THREADS set by the user is respected."""
     import torch
     if "OMP_NUM_THREADS" not in os.environ:
-        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        torch.set_num_threads(max(1, min(HOST_THREADS, os.cpu_count() or 1)))
+
+
+HOST_THREADS = 4
 
 
 def _select_device(argv):

@@ -111,6 +111,16 @@ class LazyLogSoftmax(_torch.Tensor):
                 and not isinstance(args[1], LazyLogSoftmax) and args[1].dim() == 1 and args[1].dtype == _torch.long
                 and args[1].device == args[0]._sgf_logits.device and _idx_is_unique(args[1])):
             return LazyLogSoftmax(args[0]._sgf_logits, args[1], args[0]._sgf_orig)
+        if (func is _torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], LazyLogSoftmax)
+                and args[0]._sgf_idx is None and args[0]._sgf_cache is None and _torch.is_tensor(args[1])
+                and not isinstance(args[1], LazyLogSoftmax) and args[1].dim() == 1 and args[1].dtype == _torch.bool
+                and args[1].shape[0] == args[0].shape[0]):
+            # `out_i[train_mask_i]` of the mini-batch trainer (large/main-batch.py:146; the mask lives on the HOST there): the
+            # rows of a boolean mask are its nonzero positions — ascending, each once — so the lazy rows need no uniqueness
+            # check.  nonzero() runs where the mask is (ATen's own indexing does the same), only the positions cross over.
+            idx = args[1].nonzero().view(-1)
+            if idx.numel() > 0:                 # (an empty selection: ATen's path and its nan)
+                return LazyLogSoftmax(args[0]._sgf_logits, idx.to(args[0]._sgf_logits.device), args[0]._sgf_orig)
         with _torch._C.DisableTorchFunctionSubclass():
             if func in _META:                  # shape / dtype / device ... live on the wrapper: nothing is computed for them
                 return func(*args, **kwargs)
@@ -129,5 +139,5 @@ def lazy_rows_nll(rows: "LazyLogSoftmax", target, ignore_index=-100):
     n = logits.shape[0]
     labels = _torch.full((n,), -1, dtype=_torch.long, device=logits.device)
     labels[idx] = target                    # the kernels index labels by NODE id; ignore_index (< 0) adds nothing there
-    denom = (target != ignore_index).sum().clamp_(min=1).to(_torch.float32)
+    denom = (target != ignore_index).sum().to(_torch.float32)          # (all targets ignored: 0 / 0 = nan, as ATen)
     return ops.nll_loss_rows(logits, labels, idx, 1.0) / denom

@@ -566,6 +566,13 @@ class SGFormer(nn.Module):
         ops._require_cuda(x, edge_index)
         out_dtype = x.dtype if getattr(self, 'logits_dtype', None) is None else self.logits_dtype
         cdt = self.compute_dtype if self.compute_dtype is not None else x.dtype
+        if getattr(edge_index, "_sgf_csr", None) is not None:
+            # a mini-batch whose CSR came with its edge list (batching.subgraph): batches of one node count replay ONE captured
+            # hipGraph per direction instead of ~150 launches (sgformer_amd/graphed.py; SGF_BATCH_GRAPH=0 turns it off)
+            from . import graphed
+            out = graphed.maybe_step(self, x, edge_index, cdt, out_dtype)
+            if out is not None:
+                return out
         # The graph is resolved once per forward.  If its cached view carries a locality-restoring node
         # order (ops.GraphView), the rows of x are permuted here — fused with the storage cast — and the
         # logits un-permuted on the way out; every op in between is permutation-equivariant.
@@ -611,6 +618,20 @@ class SGFormer(nn.Module):
                 hit = (key, xe, x)
                 holder._x_cache = hit
             x = hit[1]
+        return self._core(x, edge_index, view, repart, out_dtype)
+
+    def _entry_copy_uncached(self, x, cdt):
+        """The entry copy for ONE use of x (a mini-batch's features): zero-padding to a multiple of 4 columns and the
+        storage cast in one pass — the captured step of sgformer_amd.graphed calls this inside its graph."""
+        f = x.shape[1]
+        fp = (f + 3) // 4 * 4
+        if fp != f and hasattr(ops.K, "pad_rows"):
+            return ops.K.pad_rows(x, None, fp, cdt)
+        return x if x.dtype == cdt else x.to(cdt)
+
+    def _core(self, x, edge_index, view, repart, out_dtype):
+        """Everything between the entry copy and the logits: stems, both branches, combine + head (large/ours.py:265-276).
+        `edge_index`: the reference's tensor, or an object with the CSR arrays (ops.CSRGraph, graphed.StaticCSR)."""
         # K10: the first Linear of both branches reads the same x — one pass, two outputs, the GCN stem's BatchNorm
         # sums on the way (bf16 storage, <= 128 input features)
         stem_t = stem_g = None

@@ -1,0 +1,104 @@
+"""The mini-batch step as hipGraph replays (sgformer_amd/graphed.py) against the same step issued launch by launch."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cuda, monkeypatch, graphs: bool, dtype, batches: int, move_at=None):
+    """`batches` training steps of large/main-batch.py:134-151 on induced subgraphs of ONE node count; returns the per-step
+    logits, the final parameters and BatchNorm buffers."""
+    from sgformer_amd import batching, graphed, launch, ops, synth
+    from sgformer_amd.ours import SGFormer
+    monkeypatch.setenv("SGF_BATCH_GRAPH", "1" if graphs else "0")
+    n, f, c, d, m = 30000, 100, 47, 64, 6144
+    ei = synth.synthetic_graph(n, 14.0, seed=11)
+    x, y, _ = synth.synthetic_task(n, f, c, seed=11)
+    x, y = x.to(cuda), y.to(cuda)
+    torch.manual_seed(5)
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=dtype, **synth.RECIPES["ogbn-products"]).to(cuda)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-5)
+    gen = torch.Generator().manual_seed(17)
+    before = dict(graphed.counters)
+    logits = []
+    batching._parents.clear()
+    for step in range(batches):
+        if move_at is not None and step == move_at:
+            # evaluate_large's round trip (large/eval.py:41 + main-batch.py:131): the parameters come back at NEW addresses
+            model.to("cpu")
+            model.to(cuda)
+            model.train()
+        idx = torch.randperm(n, generator=gen)[:m]
+        ei_i, _ = batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)
+        model.train()
+        opt.zero_grad()
+        out = model(x[idx.to(cuda)], ei_i)
+        logits.append(out.detach().float().clone())
+        loss = F.nll_loss(F.log_softmax(out.float(), dim=1), y[idx.to(cuda)])
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    used = {k: graphed.counters[k] - before[k] for k in before}
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # evaluation after training runs the eager path on whatever graph it is given
+    model.eval()
+    with torch.no_grad():
+        idx = torch.arange(m)
+        ei_i, _ = batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)
+        ev = model(x[:m], ei_i).float().clone()
+    ops.graph_cache.clear()
+    return logits, state, used, ev
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, None], ids=["bf16", "f32"])
+def test_replayed_steps_equal_the_eager_steps(cuda, monkeypatch, dtype):
+    """7 Adam steps on batches of one size: step 1 eager, step 2 captures (and already returns the captured graphs' result),
+    steps 3-7 replay — every step's logits, the final parameters and the BatchNorm running statistics equal the all-eager
+    run's bit for bit (same kernels, same order, same arithmetic)."""
+    eager = _run(cuda, monkeypatch, False, dtype, 7)
+    graph = _run(cuda, monkeypatch, True, dtype, 7)
+    assert eager[2] == {"captures": 0, "replays": 0}
+    assert graph[2] == {"captures": 1, "replays": 6}
+    for i, (a, b) in enumerate(zip(eager[0], graph[0])):
+        assert torch.equal(a, b), f"step {i}: max |diff| {float((a - b).abs().max())}"
+    for k in eager[1]:
+        assert torch.equal(eager[1][k], graph[1][k]), k
+    assert torch.equal(eager[3], graph[3])
+
+
+def test_parameters_that_moved_are_recaptured(cuda, monkeypatch):
+    """The trainer's evaluation moves the model to the host and back (large/eval.py:41): the captured launches hold the old
+    addresses, so the next step captures again — and stays equal to the eager run."""
+    eager = _run(cuda, monkeypatch, False, torch.bfloat16, 6, move_at=4)
+    graph = _run(cuda, monkeypatch, True, torch.bfloat16, 6, move_at=4)
+    assert graph[2] == {"captures": 2, "replays": 5}
+    for i, (a, b) in enumerate(zip(eager[0], graph[0])):
+        assert torch.equal(a, b), f"step {i}: max |diff| {float((a - b).abs().max())}"
+    for k in eager[1]:
+        assert torch.equal(eager[1][k], graph[1][k]), k
+
+
+def test_ineligible_calls_keep_the_eager_path(cuda, monkeypatch):
+    """Active dropout, features that require a gradient, evaluation and small batches never capture."""
+    from sgformer_amd import batching, graphed, synth
+    from sgformer_amd.ours import SGFormer
+    monkeypatch.setenv("SGF_BATCH_GRAPH", "1")
+    n, f, c, d, m = 20000, 100, 47, 64, 5000
+    ei = synth.synthetic_graph(n, 10.0, seed=2)
+    x = torch.randn(m, f, device=cuda)
+    batching._parents.clear()
+    ei_i, _ = batching.subgraph(torch.arange(m), ei, num_nodes=n, relabel_nodes=True)
+    before = dict(graphed.counters)
+    drop = SGFormer(f, d, c, trans_dropout=0.5, gnn_dropout=0.5, compute_dtype=torch.bfloat16, **synth.RECIPES["ogbn-products"]).to(cuda)
+    plain = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16, **synth.RECIPES["ogbn-products"]).to(cuda)
+    for _ in range(3):
+        drop.train()(x, ei_i).sum().backward()
+        plain.train()(x.clone().requires_grad_(True), ei_i).sum().backward()
+        plain.eval()
+        with torch.no_grad():
+            plain(x, ei_i)
+        small, _ = batching.subgraph(torch.arange(1000), ei, num_nodes=n, relabel_nodes=True)
+        plain.train()(x[:1000], small).sum().backward()
+    assert graphed.counters == before

@@ -125,6 +125,7 @@ def test_subgraph_from_the_parent_csr_is_bit_exact(cuda, kind):
     rb, cb, vb, db = (t.cpu().numpy() for t in out._sgf_csr)
     assert np.array_equal(rb, rowptr) and np.array_equal(cb, colind.astype(np.int32)) and np.array_equal(db, deg.astype(np.int32))
     assert np.array_equal(vb.view(np.uint32), val.view(np.uint32))
+    assert out._sgf_max_in_degree == (int(np.diff(rowptr).max()) if m else 0)     # total[2] of sgf_subgraph_csr_plan
     # the emitted edge list is in (target, source) order: exactly the CSR's
     assert np.array_equal(out[1].cpu().numpy(), np.repeat(np.arange(m), np.diff(rowptr))) and np.array_equal(out[0].cpu().numpy(), colind)
     parent = next(iter(batching._parents.values()))[1]

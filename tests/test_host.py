@@ -733,6 +733,16 @@ def test_launcher_runs_the_trainers_three_loss_lines_in_one_pass():
         mask = torch.zeros(n, dtype=torch.bool)
         mask[idx] = True
         assert torch.equal(F.log_softmax(logits, dim=1)[mask].detach(), full[mask].detach())
+        # the mini-batch trainer's form (large/main-batch.py:146): rows picked by a BOOLEAN mask -> one pass as well
+        before = len(calls)
+        got_m = criterion(F.log_softmax(logits, dim=1)[mask], label.squeeze(1)[mask])
+        gm, = torch.autograd.grad(got_m, logits)
+        ref_m = nll0(ls0(logits, dim=1)[mask], label.squeeze(1)[mask])
+        grm, = torch.autograd.grad(ref_m, logits)
+        assert len(calls) == before + 1 and abs(float(got_m) - float(ref_m)) <= 1e-6 and float((gm - grm).abs().max()) <= 1e-7
+        none = torch.zeros(n, dtype=torch.bool)                                              # an empty mask: ATen's nan, not a crash
+        assert torch.isnan(criterion(F.log_softmax(logits, dim=1)[none], label.squeeze(1)[none]))
+        calls[:] = calls[:2]
         rows = F.log_softmax(logits, dim=1)[idx]
         assert torch.equal(rows[:5].detach(), full[idx][:5].detach())                       # a second index: real rows
         w = torch.rand(c, generator=g)

@@ -99,7 +99,7 @@ def _eligible(model, x, edge_index) -> bool:
     if not getattr(edge_index, "_sgf_symmetric", False) or x.shape[0] < _MIN_NODES:
         return False
     if not model.use_graph or model.graph_conv._shard is not None or getattr(model, "overlap_branches", False):
-        return False
+        return False          # (two-stream branches inside a capture: tried in r05, does not survive hipStreamEndCapture)
     for branch in (model.trans_conv, model.graph_conv):
         p = getattr(branch, "dropout", 0.0)
         if p is not None and p > 0.0:

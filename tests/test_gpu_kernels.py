@@ -1432,10 +1432,21 @@ def test_trainer_loss_lines_in_one_pass(cuda, dtype):
         assert isinstance(out, LazyLogSoftmax) and calls == [1] and out.shape == (n, c)
         assert full == [], "the one-pass path must not compute the full log-softmax"
         g_got, = torch.autograd.grad(loss, logits)
+        # large/main-batch.py:146: the rows are picked by a BOOLEAN mask that lives on the host
+        mask = torch.zeros(n, dtype=torch.bool)
+        mask[idx.cpu()] = True
+        t_m = label.squeeze(1)[mask]
+        loss_m = nn.NLLLoss()(F.log_softmax(logits, dim=1)[mask], t_m)
+        assert calls == [1, 1] and full == []
+        g_m, = torch.autograd.grad(loss_m, logits)
     finally:
         ops.K.nll_fwd = real
         LazyLogSoftmax._sgf_value = value
         launch.unpatch_nll_loss()
+    ref_m = F.nll_loss(F.log_softmax(ref_in, dim=1)[mask], t_m)
+    g_ref_m, = torch.autograd.grad(ref_m, ref_in)
+    assert abs(float(loss_m) - float(ref_m)) <= 1e-6 * max(1.0, abs(float(ref_m)))
+    assert float((g_m.float() - g_ref_m).abs().max()) <= (1e-6 if dtype == torch.float32 else 2.0 ** -8) * float(g_ref_m.abs().max())
     assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
     tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
     assert float((g_got.float() - g_ref).abs().max()) <= tol * float(g_ref.abs().max())

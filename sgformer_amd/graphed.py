@@ -16,6 +16,9 @@ exactly as the eager path issues them) and replayed for every later batch of tha
     offset is a launch argument), one GPU, a symmetric batch graph (batching.subgraph's promise for a symmetric parent: the
     backward multiplies with the same arrays), features that do not require a gradient.  Everything else — evaluation, the
     first batch of a size (it warms the caches the capture must not contain), odd shapes — runs the eager path;
+  * a replay writes into the graphs' static buffers: the logits are handed out as a copy, and while a replayed forward's
+    backward is still outstanding (its logits alive, no gradient yet — two forwards before one backward) the next call of
+    that size runs eager; at most 4 batch sizes per model stay captured (least recently used ones give their pools back);
   * the captured kernels hold the PARAMETERS' device addresses: `evaluate_large` moves the model to the host and back every
     `eval_step` epochs (large/eval.py:41, large/main-batch.py:131), so every replay first compares the parameters' addresses
     with the captured ones and re-captures when they moved.
@@ -26,6 +29,7 @@ from __future__ import annotations
 
 import os
 import weakref
+from collections import OrderedDict
 
 import torch
 import torch.nn as nn
@@ -38,6 +42,7 @@ _F32 = torch.float32
 _table: "weakref.WeakKeyDictionary[nn.Module, dict]" = weakref.WeakKeyDictionary()
 _MIN_NODES = 4096          # below this a step is too small to matter; keep the eager path
 _SEEN_BEFORE_CAPTURE = 1   # eager batches of a size before its capture (the first one warms caches)
+_MAX_CAPTURED = 4          # captured batch sizes kept per model (each holds the activations of one step in its own pool)
 counters = {"captures": 0, "replays": 0}      # process-wide, for tests and the bench line
 
 
@@ -91,6 +96,16 @@ class _Entry:
         self.params = ()
         self.param_ptrs = None
         self.failed = False
+        self.pending = None        # weakref to the last replay's backward hook until that backward has run
+
+    def busy(self) -> bool:
+        """A replayed forward whose backward has not run yet while its autograd graph is still alive: its saved activations
+        live in the graphs' static buffers, which another replay would overwrite (two forwards before one backward)."""
+        return self.pending is not None and self.pending() is not None
+
+    def release(self):
+        self.core = self.graph = self.pending = None
+        self.params, self.param_ptrs = (), None
 
 
 def _eligible(model, x, edge_index) -> bool:
@@ -153,22 +168,28 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
     """The logits of model(x, edge_index) from a captured step, or None (the caller runs the eager path)."""
     if not _eligible(model, x, edge_index):
         return None
-    per_model = _table.setdefault(model, {})
+    per_model = _table.setdefault(model, OrderedDict())
     key = (int(x.shape[0]), int(x.shape[1]), x.dtype, cdt, out_dtype)
     entry = per_model.get(key)
     if entry is None:
         entry = per_model[key] = _Entry()
+    per_model.move_to_end(key)
     if entry.failed:
         return None
     entry.seen += 1
-    if entry.seen <= _SEEN_BEFORE_CAPTURE:
+    if entry.seen <= _SEEN_BEFORE_CAPTURE or entry.busy():
         return None
     csr = edge_index._sgf_csr
     nnz = int(csr[1].numel())
     stale = entry.core is not None and (nnz > entry.graph.cap or any(a is not b for a, b in zip(entry.params, model.parameters()))
                                         or entry.param_ptrs != tuple(p.data_ptr() for p in entry.params))
     if entry.core is None or stale:
-        entry.core = entry.graph = None          # (frees the old graphs' pool before the new capture)
+        entry.release()                          # (frees the old graphs' pool before the new capture)
+        held = [e for e in per_model.values() if e.core is not None]
+        for e in held[:max(0, len(held) - (_MAX_CAPTURED - 1))]:
+            if not e.busy():
+                e.release()                      # least recently used sizes give their pools back; they re-capture if they return
+                e.seen = 0
         try:
             _capture(model, entry, x, edge_index, cdt, out_dtype)
         except Exception as exc:                 # capture is an optimisation: never let it break a training run
@@ -178,4 +199,25 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
             return None
     entry.graph.load(*csr[:3])
     counters["replays"] += 1
-    return entry.core(x, *entry.params)
+    # the graphs' output is a STATIC buffer the next replay overwrites: hand out a copy (19 MB at 100 k x 47: ~10 us), so that
+    # logits a caller keeps across batches stay what they were
+    out = entry.core(x, *entry.params).clone()
+    if not out.requires_grad:               # (every parameter frozen: no backward will come)
+        return out
+    done = _Done(entry)
+    out.register_hook(done)                 # (kept by the autograd node of `out`: lives exactly as long as a backward through
+    entry.pending = weakref.ref(done)       #  this replay is still possible, also after `out` itself is gone)
+    return out
+
+
+class _Done:
+    """Tensor hook on the replayed logits: their gradient arrived, so this backward call runs the captured backward."""
+
+    def __init__(self, entry):
+        self.entry = weakref.ref(entry)
+
+    def __call__(self, grad):
+        e = self.entry()
+        if e is not None:
+            e.pending = None
+        return None

@@ -102,3 +102,51 @@ def test_ineligible_calls_keep_the_eager_path(cuda, monkeypatch):
         small, _ = batching.subgraph(torch.arange(1000), ei, num_nodes=n, relabel_nodes=True)
         plain.train()(x[:1000], small).sum().backward()
     assert graphed.counters == before
+
+
+def test_two_forwards_before_one_backward_and_kept_logits(cuda, monkeypatch):
+    """What a replay must not break: logits a caller keeps across batches stay what they were (the graphs' output buffer is
+    static: a copy is handed out), and a second forward of the same size BEFORE the first one's backward — its logits
+    dropped, only the loss kept — runs eager instead of overwriting the activations that backward still needs."""
+    from sgformer_amd import batching, graphed, ops, synth
+    from sgformer_amd.ours import SGFormer
+    n, f, c, d, m = 30000, 100, 47, 64, 6144
+    ei = synth.synthetic_graph(n, 14.0, seed=11)
+    x, y, _ = synth.synthetic_task(n, f, c, seed=11)
+    x, y = x.to(cuda), y.to(cuda)
+    gen = torch.Generator().manual_seed(3)
+    batches = []
+    batching._parents.clear()
+    for _ in range(4):
+        idx = torch.randperm(n, generator=gen)[:m]
+        batches.append((x[idx.to(cuda)], batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)[0], y[idx.to(cuda)]))
+
+    def run(graphs):
+        monkeypatch.setenv("SGF_BATCH_GRAPH", "1" if graphs else "0")
+        torch.manual_seed(5)
+        model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16,
+                         **synth.RECIPES["ogbn-products"]).to(cuda).train()
+        before = dict(graphed.counters)
+        kept = []
+        for xb, eb, yb in batches[:2]:                       # eager, then capture + replay
+            model.zero_grad()
+            out = model(xb, eb)
+            kept.append(out)
+            F.nll_loss(F.log_softmax(out.float(), dim=1), yb).backward()
+        snapshot = kept[1].detach().clone()
+        model.zero_grad()
+        loss_a = F.nll_loss(F.log_softmax(model(*batches[2][:2]).float(), dim=1), batches[2][2])      # replay; logits dropped
+        loss_b = F.nll_loss(F.log_softmax(model(*batches[3][:2]).float(), dim=1), batches[3][2])      # must NOT replay
+        (loss_a + loss_b).backward()
+        grads = [p.grad.detach().clone() for p in model.parameters()]
+        used = {k: graphed.counters[k] - before[k] for k in before}
+        assert torch.equal(kept[1].detach(), snapshot), "logits kept from an earlier batch changed under a later replay"
+        ops.graph_cache.clear()
+        return grads, used, float(loss_a), float(loss_b)
+
+    g_eager, used_e, la_e, lb_e = run(False)
+    g_graph, used_g, la_g, lb_g = run(True)
+    assert used_e == {"captures": 0, "replays": 0} and used_g == {"captures": 1, "replays": 2}
+    assert (la_e, lb_e) == (la_g, lb_g)
+    for a, b in zip(g_eager, g_graph):
+        assert torch.equal(a, b)

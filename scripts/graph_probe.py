@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Which part of the step does not survive HIP stream capture?  Captures forward and backward of one piece of the model in
-torch.cuda.graph and replays them.    python scripts/graph_probe.py --piece {full,trans,gcn,linear,spmm,combine,stem}"""
+torch.cuda.graph and replays them.    python scripts/graph_probe.py --piece {full,trans,gcn,linear,spmm,combine}
+    python scripts/graph_probe.py --mgc after-eager            # the capture of sgformer_amd.graphed after an eager step: fine
+    python scripts/graph_probe.py --mgc after-eager --naive    # the same through the module's own parameters: segfault (r05)"""
 import argparse
 import os
 import sys
@@ -18,7 +20,11 @@ def main():
     ap.add_argument("--piece", default="full")
     ap.add_argument("--log", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")
-    ap.add_argument("--mgc", choices=["direct", "after-eager", "after-eager-step"], default=None)
+    ap.add_argument("--mgc", choices=["direct", "after-eager", "after-eager-step"], default=None,
+                    help="capture through sgformer_amd.graphed._capture, optionally after an eager training step")
+    ap.add_argument("--naive", action="store_true",
+                    help="with --mgc: torch.cuda.make_graphed_callables on the module itself (its parameters' own gradient "
+                         "accumulators, warm-up on a side stream) — after an eager step this crashes in hipStreamEndCapture")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n, f, c, d, m = 30000, 100, 47, 64, 6144
@@ -57,10 +63,16 @@ def main():
                 opt.zero_grad()
             torch.cuda.synchronize()
             print("eager step ok", flush=True)
-        entry = graphed._Entry()
-        graphed._capture(model, entry, xi, ei_i, torch.bfloat16, torch.float32)
-        print("make_graphed_callables ok", flush=True)
-        out = entry.core(xi, *entry.params)
+        if a.naive:
+            core = graphed._Core(model, graph, torch.bfloat16, torch.float32).train()
+            fn = torch.cuda.make_graphed_callables(core, (xi.detach(),), allow_unused_input=True)
+            print("make_graphed_callables ok", flush=True)
+            out = fn(xi)
+        else:
+            entry = graphed._Entry()
+            graphed._capture(model, entry, xi, ei_i, torch.bfloat16, torch.float32)
+            print("make_graphed_callables ok", flush=True)
+            out = entry.core(xi, *entry.params)
         out.float().sum().backward()
         torch.cuda.synchronize()
         print("replayed through autograd:", float(out.detach().float().abs().sum()), flush=True)

@@ -130,6 +130,8 @@ def parse():
                          "(large/main-batch.py:129-151, batch_size 100000 as in large/run.sh:15-19) as the unchanged trainer "
                          "runs it under sgformer_amd.launch; value = N / epoch time")
     ap.add_argument("--batch-size", type=int, default=100000)
+    ap.add_argument("--no-minibatch-leg", action="store_true",
+                    help="skip the mini-batch epoch appended to `structured` (ogbn-products, N = 1)")
     return ap.parse_args()
 
 
@@ -766,6 +768,17 @@ def main():
                      "(synth.synthetic_graph_rmat)",
             "nnz": q["nnz"], "value": q["n"] * 3 / q["elapsed"], "unit": "nodes/s", "steps": 3,
             "ms_per_step": round(q["elapsed"] / 3 * 1e3, 3), "graph_view": q["view"], "roofline": q["roof"]}
+        if args.workload == "ogbn-products" and not args.nodes and not args.no_minibatch_leg:
+            # ... and the reference's OTHER way through the same model (large/main-batch.py, the recipe of large/run.sh:15-19):
+            # one epoch of random-partition mini-batches, the trainer's loop lines verbatim (= `--mode minibatch`); last, because
+            # it sets the host thread count the launcher uses for that trainer
+            q = run_minibatch(args, dev, 3, 1)
+            structured["minibatch_epoch"] = {
+                "what": "one EPOCH of large/main-batch.py:129-151 on the same uniform graph: random partitions of "
+                        f"{args.batch_size} nodes, induced subgraph + its CSR per batch (sgf_subgraph_csr_*), model steps replayed "
+                        "as hipGraphs (sgformer_amd/graphed.py), the trainer's own host lines, loss lines and Adam",
+                "value": q["n"] * 3 / q["elapsed"], "unit": "nodes/s", "steps": 3, "ms_per_epoch": round(q["elapsed"] / 3 * 1e3, 3),
+                "loss": q["loss"], "minibatch": q["breakdown"], "roofline": q["roof"]}
 
     if rank == 0:
         n, f, c, d, weak = r["n"], r["f"], r["c"], r["d"], r["weak"]

@@ -38,8 +38,19 @@ from . import ops
 
 _F32 = torch.float32
 
-# per model: {(n, f, x dtype, compute dtype): _Entry}
-_table: "weakref.WeakKeyDictionary[nn.Module, dict]" = weakref.WeakKeyDictionary()
+class _PerModel(OrderedDict):
+    """{(n, f, x dtype, compute dtype, logits dtype): _Entry} of ONE model, kept in the module's __dict__ (so that it dies with
+    the model: an entry holds the model through its captured callable, a cycle the garbage collector resolves — a global table
+    keyed on the model would pin it).  Copies and pickles of the model start without captures (100M/nb-sample.py:197
+    deep-copies its best model; hipGraphs can be neither copied nor pickled)."""
+
+    def __deepcopy__(self, memo):
+        return _PerModel()
+
+    def __reduce__(self):
+        return (_PerModel, ())
+
+
 _MIN_NODES = 4096          # below this a step is too small to matter; keep the eager path
 _SEEN_BEFORE_CAPTURE = 1   # eager batches of a size before its capture (the first one warms caches)
 _MAX_CAPTURED = 4          # captured batch sizes kept per model (each holds the activations of one step in its own pool)
@@ -116,7 +127,7 @@ def _eligible(model, x, edge_index) -> bool:
     if not model.use_graph or model.graph_conv._shard is not None or getattr(model, "overlap_branches", False):
         return False          # (two-stream branches inside a capture: tried in r05, does not survive hipStreamEndCapture)
     for branch in (model.trans_conv, model.graph_conv):
-        p = getattr(branch, "dropout", 0.0)
+        p = getattr(branch, "dropout", 1.0)        # (a branch without the attribute: unknown, stay eager)
         if p is not None and p > 0.0:
             return False
     return True
@@ -168,7 +179,9 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
     """The logits of model(x, edge_index) from a captured step, or None (the caller runs the eager path)."""
     if not _eligible(model, x, edge_index):
         return None
-    per_model = _table.setdefault(model, OrderedDict())
+    per_model = model.__dict__.get("_sgf_graphed")
+    if per_model is None:
+        per_model = model.__dict__["_sgf_graphed"] = _PerModel()
     key = (int(x.shape[0]), int(x.shape[1]), x.dtype, cdt, out_dtype)
     entry = per_model.get(key)
     if entry is None:

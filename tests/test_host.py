@@ -931,3 +931,23 @@ def test_feature_width_that_is_not_a_multiple_of_4_is_padded_once_at_the_entry(c
     if dtype is None:
         for k in ("graph_conv.fcs.0.weight", "trans_conv.fcs.0.weight"):
             assert _rel(dict(m.named_parameters())[k].grad, p64[k].grad) < 2e-3, k
+
+
+def test_captured_step_table_does_not_travel_with_copies_of_the_model():
+    """sgformer_amd.graphed keeps a model's captured steps in the module's __dict__; `copy.deepcopy(model)` (100M/nb-sample.py:197
+    snapshots its best model that way) and pickling must start without them — a hipGraph can be neither copied nor pickled."""
+    import copy
+    import pickle
+    import threading
+    from sgformer_amd import graphed
+    from sgformer_amd.ours import SGFormer
+    model = SGFormer(8, 16, 3, trans_num_layers=1, gnn_num_layers=1)
+    table = graphed._PerModel()
+    table[(1, 2)] = threading.Lock()                 # stands in for a captured graph: deepcopy / pickle of it raise
+    model.__dict__["_sgf_graphed"] = table
+    twin = copy.deepcopy(model)
+    assert isinstance(twin.__dict__["_sgf_graphed"], graphed._PerModel) and len(twin.__dict__["_sgf_graphed"]) == 0
+    assert len(model.__dict__["_sgf_graphed"]) == 1
+    again = pickle.loads(pickle.dumps(table))
+    assert isinstance(again, graphed._PerModel) and len(again) == 0
+    assert "_sgf_graphed" not in model.state_dict()

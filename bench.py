@@ -586,7 +586,7 @@ def run_minibatch(args, dev, steps, warmup):
             epoch(False)
         torch.cuda.synchronize()
         from sgformer_amd import graphed
-        replayed = graphed.enabled()
+        replayed, replays0 = graphed.enabled(), graphed.counters["replays"]
         timer.active = not replayed
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -594,6 +594,7 @@ def run_minibatch(args, dev, steps, warmup):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timer.active = False
+        replays = graphed.counters["replays"] - replays0          # (0: enabled, but no batch was eligible / the capture failed)
         if replayed:
             # the timed epochs replay captured steps (sgformer_amd/graphed.py): no per-launch events in there.  The SpMM
             # launches are timed in one more, UNTIMED epoch of eager steps — the same kernels on the same batches' sizes.
@@ -618,7 +619,8 @@ def run_minibatch(args, dev, steps, warmup):
         for k, a, b in zip(marks, e, e[1:]):
             gpu[k] += a.elapsed_time(b)
     nb = max(len(ev), 1)
-    breakdown = {"batches_per_epoch": num_batch, "batch_nodes": bs, "steps_replayed_as_hip_graphs": bool(replayed),
+    breakdown = {"batches_per_epoch": num_batch, "batch_nodes": bs, "steps_replayed_as_hip_graphs": bool(replayed and replays > 0),
+                 "replayed_steps_in_the_timed_epochs": int(replays),
                  "per_batch_ms_on_the_gpu_timeline": {k: round(v / nb, 3) for k, v in gpu.items()},
                  "per_batch_ms_host_issue": {k: round(v / nb * 1e3, 3) for k, v in host.items()},
                  "per_batch_ms_wall": round(elapsed / nb * 1e3, 3)}

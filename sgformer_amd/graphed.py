@@ -124,6 +124,9 @@ def _eligible(model, x, edge_index) -> bool:
         return False
     if not getattr(edge_index, "_sgf_symmetric", False) or x.shape[0] < _MIN_NODES:
         return False
+    csr = edge_index._sgf_csr
+    if csr[0].numel() != x.shape[0] + 1 or csr[1].numel() != edge_index.shape[1]:
+        return False          # (not the CSR of THIS call's graph: the eager path builds its own, as ops.CSRGraph decides too)
     if not model.use_graph or model.graph_conv._shard is not None or getattr(model, "overlap_branches", False):
         return False          # (two-stream branches inside a capture: tried in r05, does not survive hipStreamEndCapture)
     for branch in (model.trans_conv, model.graph_conv):

@@ -233,10 +233,11 @@ class CpuKernels:
     @staticmethod
     def spmm(rowptr, colind, val, x, n_rows, out=None, long_segments=0, stream_hint=False):
         y = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
-        if n_rows > 0 and colind.numel() > 0:
-            counts = (rowptr[1:] - rowptr[:-1])
+        nnz = int(rowptr[n_rows]) if n_rows > 0 else 0      # the kernels bound their work by rowptr: arrays may be longer
+        if nnz > 0:
+            counts = (rowptr[1:n_rows + 1] - rowptr[:n_rows])
             rows = torch.repeat_interleave(torch.arange(n_rows), counts)
-            y.index_add_(0, rows, val.to(x.dtype).unsqueeze(1) * x[colind.long()])
+            y.index_add_(0, rows, val[:nnz].to(x.dtype).unsqueeze(1) * x[colind[:nnz].long()])
         if out is not None:
             out.copy_(y)
             return out

@@ -951,3 +951,44 @@ def test_captured_step_table_does_not_travel_with_copies_of_the_model():
     again = pickle.loads(pickle.dumps(table))
     assert isinstance(again, graphed._PerModel) and len(again) == 0
     assert "_sgf_graphed" not in model.state_dict()
+
+
+def test_model_core_on_fixed_capacity_csr_arrays_equals_the_forward():
+    """What sgformer_amd.graphed captures, on the CPU kernel table: SGFormer._core on a StaticCSR (fixed-capacity arrays with a
+    stale tail beyond the batch's entries, A^T == A) after _entry_copy_uncached == model(x, edge_index), logits and gradients —
+    for two different graphs loaded into the SAME arrays one after the other."""
+    from sgformer_amd import graphed, ops, synth
+    from sgformer_amd.ours import SGFormer
+    from tests.cpu_kernels import CpuKernels
+    prev = ops.set_kernels(CpuKernels())
+    try:
+        n, f, c, d = 300, 10, 5, 16
+        torch.manual_seed(0)
+        model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **synth.RECIPES["ogbn-products"]).train()
+        static = None
+        for seed in (1, 2):
+            ei = synth.synthetic_graph(n, 6.0 + seed, seed=seed)
+            x = torch.randn(n, f, generator=torch.Generator().manual_seed(seed))
+            g = ops.CSRGraph(ei, n)
+            g.transposed()
+            assert g.symmetric
+            if static is None:
+                static = graphed.StaticCSR(n, g.nnz * 2 + 100, torch.device("cpu"), 0)
+                static.colind.fill_(n - 1)                       # a stale tail that would be wrong if it were read
+                static.val.fill_(7.0)
+            static.load(g.rowptr, g.colind, g.val)
+            assert static.nnz == g.nnz and static.transposed()[1] is static.colind
+            bn = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+            want = model(x, ei)
+            gw = torch.autograd.grad(want.sum(), list(model.parameters()), allow_unused=True)
+            model.load_state_dict(bn, strict=False)              # same BatchNorm buffers for the second evaluation
+            got = model._core(model._entry_copy_uncached(x, x.dtype), static, None, None, x.dtype)
+            gg = torch.autograd.grad(got.sum(), list(model.parameters()), allow_unused=True)
+            assert torch.allclose(got, want, atol=1e-6, rtol=1e-6)
+            for a, b in zip(gg, gw):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+            ops.graph_cache.clear()
+    finally:
+        ops.set_kernels(prev)

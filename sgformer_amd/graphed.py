@@ -27,6 +27,7 @@ SGF_BATCH_GRAPH=0 turns the whole mechanism off.  Nothing here runs on the full-
 """
 from __future__ import annotations
 
+import gc
 import os
 import weakref
 from collections import OrderedDict
@@ -38,8 +39,9 @@ from . import ops
 
 _F32 = torch.float32
 
+
 class _PerModel(OrderedDict):
-    """{(n, f, x dtype, compute dtype, logits dtype): _Entry} of ONE model, kept in the module's __dict__ (so that it dies with
+    """{(n, f, x dtype, compute dtype, logits dtype, device): _Entry} of ONE model, kept in the module's __dict__ (so that it dies with
     the model: an entry holds the model through its captured callable, a cycle the garbage collector resolves — a global table
     keyed on the model would pin it).  Copies and pickles of the model start without captures (100M/nb-sample.py:197
     deep-copies its best model; hipGraphs can be neither copied nor pickled)."""
@@ -167,14 +169,22 @@ def _capture(model, entry: _Entry, x, edge_index, cdt, out_dtype):
         return torch.func.functional_call(core, dict(zip(names, ps)), (x,))
 
     saved = [(b, b.detach().clone()) for b in model.buffers()]
+    # Dead captures (a released entry, a model that went away) are reference cycles: the cyclic collector destroys their
+    # hipGraphs at some later allocation — inside THIS capture, if it gets the chance, and destroying a graph / freeing its pool
+    # while a stream is capturing crashes.  Collect them now, and keep the collector off until the capture has ended.
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     try:
         fn = torch.cuda.make_graphed_callables(step, (x.detach(),) + aliases, num_warmup_iters=0, allow_unused_input=True)
     finally:
+        if gc_was_on:
+            gc.enable()
         with torch.no_grad():           # (captured launches do not execute; kept in case a torch version warms up anyway)
             for b, v in saved:
                 b.copy_(v)
     entry.core, entry.graph, entry.params = fn, graph, params
-    entry.param_ptrs = tuple(p.data_ptr() for p in params)
+    entry.param_ptrs = tuple((p.data_ptr(), p.requires_grad) for p in params)
     counters["captures"] += 1
 
 
@@ -185,7 +195,7 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
     per_model = model.__dict__.get("_sgf_graphed")
     if per_model is None:
         per_model = model.__dict__["_sgf_graphed"] = _PerModel()
-    key = (int(x.shape[0]), int(x.shape[1]), x.dtype, cdt, out_dtype)
+    key = (int(x.shape[0]), int(x.shape[1]), x.dtype, cdt, out_dtype, x.device)
     entry = per_model.get(key)
     if entry is None:
         entry = per_model[key] = _Entry()
@@ -197,8 +207,10 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
         return None
     csr = edge_index._sgf_csr
     nnz = int(csr[1].numel())
+    # captured launches hold the parameters' addresses and which of them get a gradient: moved (the trainer's evaluation
+    # round trip), replaced or (un)frozen parameters mean a new capture
     stale = entry.core is not None and (nnz > entry.graph.cap or any(a is not b for a, b in zip(entry.params, model.parameters()))
-                                        or entry.param_ptrs != tuple(p.data_ptr() for p in entry.params))
+                                        or entry.param_ptrs != tuple((p.data_ptr(), p.requires_grad) for p in entry.params))
     if entry.core is None or stale:
         entry.release()                          # (frees the old graphs' pool before the new capture)
         held = [e for e in per_model.values() if e.core is not None]

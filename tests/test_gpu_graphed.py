@@ -80,6 +80,41 @@ def test_parameters_that_moved_are_recaptured(cuda, monkeypatch):
         assert torch.equal(eager[1][k], graph[1][k]), k
 
 
+def test_a_parameter_frozen_after_the_capture_is_recaptured(cuda, monkeypatch):
+    """The captured backward computes gradients for the parameters that required one AT CAPTURE: freezing / unfreezing a
+    parameter afterwards must capture again, not return stale (or no) gradients."""
+    from sgformer_amd import batching, graphed, ops, synth
+    from sgformer_amd.ours import SGFormer
+    monkeypatch.setenv("SGF_BATCH_GRAPH", "1")
+    n, f, c, d, m = 20000, 100, 47, 64, 5000
+    ei = synth.synthetic_graph(n, 10.0, seed=2)
+    x = torch.randn(m, f, device=cuda)
+    batching._parents.clear()
+    ei_i, _ = batching.subgraph(torch.arange(m), ei, num_nodes=n, relabel_nodes=True)
+    torch.manual_seed(1)
+    model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16, **synth.RECIPES["ogbn-products"]).to(cuda).train()
+    before = dict(graphed.counters)
+
+    def step():
+        model.zero_grad()
+        model(x, ei_i).float().sum().backward()
+        return {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+
+    step()
+    full = step()                                        # capture 1
+    model.fc.weight.requires_grad_(False)
+    frozen = step()                                      # capture 2: fc.weight gets no gradient any more
+    model.fc.weight.requires_grad_(True)
+    again = step()                                       # capture 3: and gets it again
+    assert {k: graphed.counters[k] - before[k] for k in before} == {"captures": 3, "replays": 3}
+    assert full["fc.weight"] is not None and frozen["fc.weight"] is None
+    for k in full:
+        assert torch.equal(full[k], again[k]), k
+        if k != "fc.weight":
+            assert torch.equal(full[k], frozen[k]), k
+    ops.graph_cache.clear()
+
+
 def test_ineligible_calls_keep_the_eager_path(cuda, monkeypatch):
     """Active dropout, features that require a gradient, evaluation and small batches never capture."""
     from sgformer_amd import batching, graphed, synth

@@ -8,7 +8,7 @@ ifdef PROBES
 HIPFLAGS += -DSGF_PROBES
 endif
 CSRC := sgformer_amd/csrc
-SRCS := $(CSRC)/capi.hip $(CSRC)/csr.hip $(CSRC)/spmm.hip $(CSRC)/attn.hip $(CSRC)/fused.hip $(CSRC)/subgraph.hip $(CSRC)/reorder.hip $(CSRC)/spmm_plan.hip $(CSRC)/prologue.hip $(CSRC)/head.hip $(CSRC)/rowgemm.hip $(CSRC)/spmm_tile.hip $(CSRC)/spmm_pack.hip $(CSRC)/sampler.hip $(CSRC)/linear_f32.hip $(CSRC)/gemm.hip $(CSRC)/attn_small.hip $(CSRC)/comm.hip $(CSRC)/subgraph_csr.hip
+SRCS := $(CSRC)/capi.hip $(CSRC)/csr.hip $(CSRC)/spmm.hip $(CSRC)/attn.hip $(CSRC)/fused.hip $(CSRC)/subgraph.hip $(CSRC)/reorder.hip $(CSRC)/spmm_plan.hip $(CSRC)/prologue.hip $(CSRC)/head.hip $(CSRC)/rowgemm.hip $(CSRC)/spmm_tile.hip $(CSRC)/spmm_pack.hip $(CSRC)/sampler.hip $(CSRC)/linear_f32.hip $(CSRC)/gemm.hip $(CSRC)/attn_small.hip $(CSRC)/comm.hip $(CSRC)/subgraph_csr.hip $(CSRC)/gramx.hip
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB  := sgformer_amd/lib/libsgf.so
 
@@ -18,7 +18,7 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/spmm_shared.h include/sgf.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/spmm_shared.h $(CSRC)/reduce_shared.h include/sgf.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""A/B of the node reductions: csrc/gramx.hip (tiles by LDS-DMA) against the register-staged k_reduce_bf16 (attn.hip),
+interleaved in ONE process on the same tensors (SGF_GRAMX toggled through sgf_reload_env).
+
+    python scripts/gramx_probe.py [--nodes 2449029] [--rounds 5]
+
+One JSON line per case: median launch time of both arms (HIP events on the launch stream, finalize kernels included),
+algorithmic bytes, GB/s and the fraction of the 6.3 TB/s a device copy reaches."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgformer_amd import _lib, ops  # noqa: E402
+
+
+def switch(on):
+    os.environ["SGF_GRAMX"] = "1" if on else "0"
+    _lib.load().sgf_reload_env()
+
+
+def timed(fn, reps=5):
+    fn()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    return sorted(x.elapsed_time(y) for x, y in evs)[len(evs) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=2449029)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    n, d = args.nodes, args.hidden
+    K = ops.K
+    g = torch.Generator().manual_seed(0)
+
+    def act(w=d):
+        return torch.randn(n, w, generator=g).to(dev, torch.bfloat16)
+
+    h, gy, x0 = act(), act(), act()
+    gp = act(48)
+    rowscal = torch.rand(n, 2, generator=g).to(dev)
+    dw = torch.empty(d, 2 * d, device=dev)
+    T = n * d * 2
+    cases = [
+        ("sgf_gram(h, h)  G", T, lambda: K.gram(h, h)),
+        ("sgf_gram(gy, h)  dW", 2 * T, lambda: K.gram(gy, h)),
+        ("sgf_gram(gp[n,48], h)  head dW", T + n * 96, lambda: K.gram(gp, h)),
+        ("sgf_gram2(gy; h, x0)  paired", 3 * T, lambda: K.gram2(gy, h, x0, dw[:, :d], dw[:, d:])),
+        ("sgf_attn_h_bwd_reduce_scaled", 2 * T + n * 8, lambda: K.attn_h_bwd_reduce_scaled(h, gy, rowscal)),
+        ("copy (yardstick)", 2 * T, lambda: h.clone()),
+    ]
+    for name, nbytes, fn in cases:
+        res = {"old": [], "new": []}
+        for _ in range(args.rounds):
+            for arm in ("old", "new"):
+                switch(arm == "new")
+                res[arm].append(timed(fn))
+        row = {"n": n, "d": d, "case": name, "algorithmic_GB": round(nbytes / 1e9, 3)}
+        for arm in ("old", "new"):
+            ms = sorted(res[arm])[len(res[arm]) // 2]
+            row[arm + "_ms"] = round(ms, 4)
+            row[arm + "_of_copy"] = round(nbytes / ms / 1e6 / 6300.0, 3)
+        print(json.dumps(row), flush=True)
+    switch(True)
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,7 @@
 //
 // DP = d rounded up to 64 / 128 / 256; columns >= d and rows >= n are zero-filled in LDS.
 #include "common.h"
+#include "reduce_shared.h"
 
 namespace sgf {
 namespace {
@@ -38,11 +39,12 @@ namespace {
 // shared geometry
 // ------------------------------------------------------------------------------------------------
 constexpr int kRedThreads = 1024;
-constexpr int kTileElems = 65536;                  // RG * DP * DP, identical for every DP
-constexpr int kVecB = kTileElems + 264;            // second column-sum vector (kModeBwdH) + 1 scalar
-constexpr int kVecC = kTileElems + 528;            // third column-sum vector (kModeGramLN)
-constexpr int kPartialStride = kTileElems + 792;   // + [DP colsum | ssq_a | ssq_q | pad][DP colsum_b | s | pad][DP colsum_c | pad]
-constexpr int kMaxBlocks = kNumCU;                 // persistent: one block per CU
+// the per-block partial layout is shared with csrc/gramx.hip (reduce_shared.h)
+constexpr int kTileElems = kRedTileElems;          // RG * DP * DP, identical for every DP
+constexpr int kVecB = kRedVecB;                    // second column-sum vector (kModeBwdH) + 1 scalar
+constexpr int kVecC = kRedVecC;                    // third column-sum vector (kModeGramLN)
+constexpr int kPartialStride = kRedPartialStride;  // + [DP colsum | ssq_a | ssq_q | pad][DP colsum_b | s | pad][DP colsum_c | pad]
+constexpr int kMaxBlocks = kRedMaxBlocks;          // persistent: one block per CU
 
 constexpr int kModeFwd = 0;  // reduce: A=K, B=V          apply: out
 constexpr int kModeBwd = 1;  // reduce: A=Q, B=dnum
@@ -1352,6 +1354,19 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
     const int mb = m - mi < 256 ? m - mi : 256;
     for (int ki = 0; ki < k; ki += 256) {
       const int kb = k - ki < 256 ? k - ki : 256;
+      const T* ap = static_cast<const T*>(a) + mi;
+      const T* bp = static_cast<const T*>(b) + ki;
+      if (sizeof(T) == 2 && gramx_supported(ap, lda, mb, bp, ldb, kb, n)) {   // tiles by LDS-DMA (csrc/gramx.hip)
+        int nblk = 0;
+        int rc = gramx_gram(ap, lda, mb, bp, ldb, nullptr, 0, kb, n, static_cast<float*>(ws), &nblk, st);
+        if (rc != SGF_OK) return rc;
+        const int64_t len = static_cast<int64_t>(mb) * kb + mb;
+        float* cs = (colsum_a != nullptr && ki == 0) ? colsum_a + mi : nullptr;
+        hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(ws), nblk, mb, kb, 256, 1, c + static_cast<int64_t>(mi) * ldc + ki, ldc, cs);
+        SGF_LAUNCH_CHECK();
+        continue;
+      }
       const int DP = padded_dim(mb > kb ? mb : kb);
       const int R = reduce_rows_per_tile<T, kModeGram>(DP);
       const int64_t ntiles = (n + R - 1) / R;
@@ -1495,6 +1510,19 @@ extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, 
   SGF_REQUIRE(aligned4<uint16_t>(a, lda) && aligned4<uint16_t>(b1, ldb1) && aligned4<uint16_t>(b2, ldb2), SGF_E_INVALID,
               "%s: a / b must be 4-element aligned with ld %% 4 == 0", fn);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gramx_supported(a, lda, m, b1, ldb1, k, n) && gramx_supported(a, lda, m, b2, ldb2, k, n)) {   // csrc/gramx.hip
+    int np = 0;
+    float* part = static_cast<float*>(workspace);
+    int rc = gramx_gram(a, lda, m, b1, ldb1, b2, ldb2, k, n, part, &np, st);
+    if (rc != SGF_OK) return rc;
+    const int64_t len = static_cast<int64_t>(m) * k + m;
+    const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+    hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part, np, m, k, 256, 1, c1, ldc1, colsum_a);
+    hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part + static_cast<int64_t>(np) * kPartialStride, np, m, k,
+                       256, 1, c2, ldc2, static_cast<float*>(nullptr));
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int DP = padded_dim(m > k ? m : k);
   int64_t pairs = ntiles / 2 < kMaxBlocks / 2 ? ntiles / 2 : kMaxBlocks / 2;
   pairs = pairs / 8 * 8;                               // whole groups of 8 pairs = 16 consecutive blocks (>= 8: ntiles >= 16)
@@ -1712,6 +1740,16 @@ extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const vo
               SGF_E_INVALID, "sgf_attn_h_bwd_reduce_scaled: h / g must be 4-element aligned with ld %% 4 == 0");
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_attn_workspace_bytes(n, 1, d), SGF_E_WORKSPACE,
               "sgf_attn_h_bwd_reduce_scaled: workspace too small");
+  if (gramx_supported(h, ldh, d, g, ldg, d, n)) {       // csrc/gramx.hip
+    int nb = 0;
+    rc = gramx_bwdhs(h, ldh, g, ldg, rowscal, d, n, static_cast<float*>(workspace), &nb, st);
+    if (rc != SGF_OK) return rc;
+    const int64_t len = sgf_attn_h_bstats_len(d);
+    hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), nb, d, 256, 1, hstats);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int DP = padded_dim(d);
   const int R = reduce_rows_per_tile<uint16_t, kModeBwdHS>(DP);
   const int64_t ntiles = (n + R - 1) / R;

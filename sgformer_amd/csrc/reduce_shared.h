@@ -1,0 +1,27 @@
+// reduce_shared.h — the per-block partial layout of the node reductions (csrc/attn.hip, csrc/gramx.hip) and the entry points
+// of the LDS-DMA reduce kernels (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+namespace sgf {
+
+// One partial per workgroup: [RG x DP x DP result | DP column sums | 2 scalars | pad][DP second vector | scalar | pad]
+// [DP third vector | pad]; the finalize kernels of attn.hip add the partials in a fixed order (no atomics anywhere).
+constexpr int kRedTileElems = 65536;                       // RG * DP * DP, identical for every DP
+constexpr int kRedVecB = kRedTileElems + 264;              // second column-sum vector + 1 scalar
+constexpr int kRedVecC = kRedTileElems + 528;              // third column-sum vector
+constexpr int kRedPartialStride = kRedTileElems + 792;
+constexpr int kRedMaxBlocks = kNumCU;                      // persistent: one block per CU
+
+// ---- csrc/gramx.hip: C = A^T B over the rows of two bf16 operands, tiles by LDS-DMA, fragments by transposing LDS reads ----
+// (partials in the layout above with DP = 256, RG = 1)
+bool gramx_supported(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k, int64_t n);
+// plain (b2 == nullptr) or paired (b2 != nullptr: partials [role][pair]) Gram; *nblk = partials per product
+int gramx_gram(const void* a, int64_t lda, int m, const void* b, int64_t ldb, const void* b2, int64_t ldb2, int k, int64_t n,
+               float* partial, int* nblk, hipStream_t st);
+// the attention backward reduce with the per-row scalars (1/den, dden) read: A = h, B = g / den; colsum = sum h dden,
+// second vector = sum g / den, scalar = sum dden
+int gramx_bwdhs(const void* h, int64_t ldh, const void* g, int64_t ldg, const float* rowscal, int d, int64_t n, float* partial,
+                int* nblk, hipStream_t st);
+
+}  // namespace sgf

@@ -1,0 +1,142 @@
+"""csrc/gramx.hip — the LDS-DMA node reductions behind sgf_gram / sgf_gram2 / sgf_attn_h_bwd_reduce_scaled (bf16, n >= 4096,
+16-byte aligned rows): against fp64 of the same bf16 operands, against the register-staged kernels they replace
+(SGF_GRAMX=0), on ragged row counts (the cleared tail of the last stage), strided operands (a column slice of a wider
+buffer), narrow operands (the head's dW: m = 48; clamped image columns) and every slot of the 4-stage ring.
+
+Reference lines: large/ours.py:36-40,:77,:198,:275 differentiated (dW = g^T x, db = sum g) and :130-151 (attention
+backward, SURVEY.md Appendix B: dS = sum_n q_n^T dnum_n, dz = sum_n q_n dden_n)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def _switch(on: bool):
+    from sgformer_amd import _lib
+    os.environ["SGF_GRAMX"] = "1" if on else "0"
+    _lib.load().sgf_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    os.environ.pop("SGF_GRAMX", None)
+    from sgformer_amd import _lib
+    _lib.load().sgf_reload_env()
+
+
+# n: one stage per block and fewer blocks than CUs; exactly the ring depth per block; ragged tails of 1 / 31 rows; several
+# laps of the ring
+@pytest.mark.parametrize("n", [4096, 4097, 4127, 8192 + 5, 32 * 256 * 4, 32 * 256 * 4 + 17, 100003, 300000])
+@pytest.mark.parametrize("m,k", [(256, 256), (48, 256), (256, 104), (128, 128), (64, 200), (8, 8), (200, 56)])
+def test_gramx_matches_fp64_and_old_kernel(cuda, n, m, k):
+    from sgformer_amd import ops
+    if n > 100003 and (m, k) not in ((256, 256), (48, 256)):
+        pytest.skip("large n: the production shapes only")
+    K = ops.K
+    g = torch.Generator().manual_seed(n + 7 * m + k)
+    a = (torch.randn(n, m, generator=g) * 0.5 + 0.3).bfloat16().to(cuda)
+    b = (torch.randn(n, k, generator=g) * 1.5 - 0.2).bfloat16().to(cuda)
+    _switch(True)
+    c, cs = K.gram(a, b)
+    c2, cs2 = K.gram(a, b)
+    assert torch.equal(c, c2) and torch.equal(cs, cs2)              # deterministic
+    ad, bd = a.double(), b.double()
+    ref = ad.t() @ bd
+    assert _rel(c, ref) <= 5e-6, _rel(c, ref)
+    assert _rel(cs, ad.sum(0)) <= 5e-6
+    _switch(False)
+    c_old, cs_old = K.gram(a, b)
+    assert _rel(c, c_old) <= 2e-6 and _rel(cs, cs_old) <= 2e-6      # only the summation order differs
+
+
+def test_gramx_is_transpose_aware(cuda):
+    """asymmetric operands: C = A^T B and not B^T A / a row-column swap of the fragments (cdna_hip_programming.md §3)."""
+    from sgformer_amd import ops
+    n, m, k = 8192, 256, 256
+    a = torch.zeros(n, m)
+    b = torch.zeros(n, k)
+    rows = torch.arange(n)
+    a[rows, rows % m] = 1.0                                         # A^T B [i, j] = sum over rows with row % m == i of B[row, j]
+    b[:] = (torch.arange(k).float() * 0.5 + 1.0)[None, :] * ((rows % 7).float() + 1.0)[:, None]
+    _switch(True)
+    c, cs = ops.K.gram(a.bfloat16().to(cuda), b.bfloat16().to(cuda))
+    ref = a.bfloat16().double().t() @ b.bfloat16().double()
+    assert _rel(c, ref) <= 1e-6
+    assert torch.equal(cs.cpu(), a.sum(0))
+
+
+@pytest.mark.parametrize("n", [5000, 65536 + 9])
+def test_gramx_strided_operands_and_sliced_output(cuda, n):
+    """operands that are column slices of a wider buffer ([Q | K | V] style: ld = 3 d), output into a column slice."""
+    from sgformer_amd import ops
+    g = torch.Generator().manual_seed(n)
+    wide = torch.randn(n, 768, generator=g).bfloat16().to(cuda)
+    a, b = wide[:, 256:512], wide[:, 512:768]
+    _switch(True)
+    big = torch.full((256, 256 + 12), 7.0, device=cuda)
+    ops.K.gram(a, b, out=big[:, 4:260], want_colsum=False)
+    assert _rel(big[:, 4:260], a.double().t() @ b.double()) <= 5e-6
+    assert bool((big[:, :4] == 7.0).all()) and bool((big[:, 260:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,m,k", [(4099, 128, 128), (50001, 256, 256), (20000, 48, 256), (262144 + 33, 256, 256)])
+def test_gramx_paired(cuda, n, m, k):
+    from sgformer_amd import ops
+    K = ops.K
+    g = torch.Generator().manual_seed(n + m)
+    a = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    b1 = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    b2 = (torch.randn(n, k, generator=g) + 0.5).bfloat16().to(cuda)
+    _switch(True)
+    dw = torch.empty(m, 2 * k, device=cuda)
+    cs = K.gram2(a, b1, b2, dw[:, :k], dw[:, k:], want_colsum=True)
+    ad = a.double()
+    assert _rel(dw[:, :k], ad.t() @ b1.double()) <= 2e-6
+    assert _rel(dw[:, k:], ad.t() @ b2.double()) <= 2e-6
+    assert _rel(cs, ad.sum(0)) <= 2e-6 or float(ad.sum(0).abs().max()) < 1e-2
+    dw2 = torch.empty_like(dw)
+    cs2 = K.gram2(a, b1, b2, dw2[:, :k], dw2[:, k:], want_colsum=True)
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)
+    _switch(False)
+    dw3 = torch.empty_like(dw)
+    K.gram2(a, b1, b2, dw3[:, :k], dw3[:, k:], want_colsum=False)
+    assert _rel(dw, dw3) <= 2e-6
+
+
+@pytest.mark.parametrize("n,d", [(4096, 256), (4097, 64), (20001, 256), (100003, 128), (300007, 256)])
+def test_gramx_attention_backward_reduce(cuda, n, d):
+    """sgf_attn_h_bwd_reduce_scaled on the DMA kernel: hstats = [h^T dnum | sum h dden | sum dnum | sum dden] with
+    dnum = g / den re-rounded to bf16 for the matrix cores (2e-3 on the matrix, as the register-staged kernel) and the
+    vectors in fp32 (1e-5); identical run to run; and against the old kernel."""
+    from sgformer_amd import ops
+    K = ops.K
+    g_ = torch.Generator().manual_seed(n + d)
+    h = torch.randn(n, d, generator=g_).bfloat16().to(cuda)
+    g = torch.randn(n, d, generator=g_).bfloat16().to(cuda)
+    inv = (1.0 / (1.0 + torch.rand(n, generator=g_))).to(cuda)
+    dden = torch.randn(n, generator=g_).to(cuda)
+    rowscal = torch.stack([inv, dden], 1).contiguous()
+    _switch(True)
+    hs = K.attn_h_bwd_reduce_scaled(h, g, rowscal)
+    hs2 = K.attn_h_bwd_reduce_scaled(h, g, rowscal)
+    assert torch.equal(hs, hs2)
+    hd, gd = h.double(), g.double()
+    dnum = gd * inv.double()[:, None]
+    assert _rel(hs[:d * d].reshape(d, d), hd.t() @ dnum) <= 2e-3
+    assert _rel(hs[d * d:d * d + d], (hd * dden.double()[:, None]).sum(0)) <= 1e-5
+    assert _rel(hs[d * d + d:d * d + 2 * d], dnum.sum(0)) <= 1e-5
+    assert abs(float(hs[-1]) - float(dden.double().sum())) <= 1e-5 * max(1.0, float(dden.double().abs().sum()))
+    # the matrix against fp64 of the ROUNDED dnum: fp32 sums of exact products
+    dnum_r = (g.float() * inv[:, None]).bfloat16().double()
+    assert _rel(hs[:d * d].reshape(d, d), hd.t() @ dnum_r) <= 5e-6
+    _switch(False)
+    hs_old = K.attn_h_bwd_reduce_scaled(h, g, rowscal)
+    assert _rel(hs, hs_old) <= 2e-6

@@ -70,7 +70,24 @@ PRODUCTION_CASES = {
 }
 
 
-def run_case(name, variant, n, f, d, c, avg_deg, directed, kw, store32=False):
+def hub_graph(n, avg_deg, seed, hubs=(1100, 1700, 2600)):
+    """The uniform graph of synth.synthetic_graph plus a few HUB nodes joined to 1100 / 1700 / 2600 others (both directions):
+    rows longer than the kernels' long-row threshold (1024 stored entries) next to ordinary ones — the path R-MAT / power-law
+    graphs take (k_spmm_long_seg), at a size the reference runs in seconds.  Same prologue as the trainer: symmetric, coalesced,
+    one self-loop per node (large/main.py:75-79)."""
+    ei = synthetic_graph(n, avg_deg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    src, dst = [ei[0]], [ei[1]]
+    for h, k in enumerate(hubs):
+        nb = torch.randperm(n, generator=g)[:k]
+        nb = nb[nb != h]
+        src += [torch.full_like(nb, h), nb]
+        dst += [nb, torch.full_like(nb, h)]
+    key = torch.unique(torch.cat(src) * n + torch.cat(dst))          # coalesce (the uniform part already holds the loops)
+    return torch.stack([key // n, key % n])
+
+
+def run_case(name, variant, n, f, d, c, avg_deg, directed, kw, store32=False, graph=None):
     ref = ref_shim.load_reference(variant)
     torch.set_default_dtype(torch.float64)
     try:
@@ -94,7 +111,7 @@ def run_case(name, variant, n, f, d, c, avg_deg, directed, kw, store32=False):
                 for v_ in model.state_dict().values():
                     if v_.is_floating_point():
                         v_.copy_(v_.float().double())
-        ei = synthetic_graph(n, avg_deg, seed=len(name), directed=directed)
+        ei = graph(n, avg_deg, len(name)) if graph is not None else synthetic_graph(n, avg_deg, seed=len(name), directed=directed)
         y = torch.randint(0, c, (n,))
         idx = torch.randperm(n)[: n // 2]
         sd0 = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
@@ -226,11 +243,27 @@ def run_medium_case(name, n, f, d, c, avg_deg, gcn_layers, cfg):
     return out
 
 
+# r06: the products recipe at production width on a graph with HUB rows — the long-row path of the SpMM
+# (rows beyond 1024 stored entries are reduced by whole workgroups) against numbers of the live reference.
+HUB_CASES = {
+    "products_d256_hub": ("large", 4096, 100, 256, 47, 10.0, False, dict(CASES["products_recipe"][7])),
+}
+
+
 def main():
     if not ref_shim.reference_available():
         raise SystemExit("reference not mounted: golden vectors can only be generated in the build container")
     dst = os.path.join(ROOT, "tests", "golden")
     os.makedirs(dst, exist_ok=True)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None     # regenerate ONE fixture
+    for name, spec in HUB_CASES.items():
+        if only in (None, name):
+            out = run_case(name, *spec, store32=True, graph=hub_graph)
+            path = os.path.join(dst, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")
+    if only in HUB_CASES:
+        return
     for name, spec in CASES.items():
         out = run_case(name, *spec)
         path = os.path.join(dst, name + ".npz")

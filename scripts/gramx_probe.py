@@ -52,6 +52,11 @@ def main():
     gp = act(48)
     rowscal = torch.rand(n, 2, generator=g).to(dev)
     dw = torch.empty(d, 2 * d, device=dev)
+    xf = act(104)
+    mean, rstd = torch.randn(d, generator=g).to(dev) * 0.1, (1.0 + torch.rand(d, generator=g)).to(dev)
+    gamma, beta = (1.0 + 0.1 * torch.randn(d, generator=g)).to(dev), (0.1 * torch.randn(d, generator=g)).to(dev)
+    stats = torch.randn(2 * d, generator=g).to(dev)
+    rmean, rrstd = torch.randn(n, generator=g).to(dev) * 0.1, (1.0 + torch.rand(n, generator=g)).to(dev)
     T = n * d * 2
     cases = [
         ("sgf_gram(h, h)  G", T, lambda: K.gram(h, h)),
@@ -59,6 +64,8 @@ def main():
         ("sgf_gram(gp[n,48], h)  head dW", T + n * 96, lambda: K.gram(gp, h)),
         ("sgf_gram2(gy; h, x0)  paired", 3 * T, lambda: K.gram2(gy, h, x0, dw[:, :d], dw[:, d:])),
         ("sgf_attn_h_bwd_reduce_scaled", 2 * T + n * 8, lambda: K.attn_h_bwd_reduce_scaled(h, gy, rowscal)),
+        ("sgf_gram_bn_bwd (g1, g2, z; x[n,104])", 3 * T + n * 208, lambda: K.gram_bn_bwd(h, gy, x0, mean, rstd, gamma, beta, True, stats, 1.0 / n, True, xf)),
+        ("sgf_gram_ln_bwd (g, hpre; x[n,104])", 2 * T + n * 216, lambda: K.gram_ln_bwd(gy, h, rmean, rrstd, gamma, beta, True, xf)),
         ("copy (yardstick)", 2 * T, lambda: h.clone()),
     ]
     for name, nbytes, fn in cases:

@@ -1419,6 +1419,19 @@ extern "C" int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int
   SGF_REQUIRE(aligned4<uint16_t>(g1, ldg1) && (!g2 || aligned4<uint16_t>(g2, ldg2)) && aligned4<uint16_t>(z, ldz) &&
                   aligned4<uint16_t>(b, ldb),
               SGF_E_INVALID, "%s: operands must be 4-element aligned with ld %% 4 == 0", fn);
+  if (gramt_supported(m, k, n) && gramt_aligned(g1, ldg1) && gramt_aligned(g2, ldg2) && gramt_aligned(z, ldz) &&
+      gramt_aligned(b, ldb)) {                          // the operand formed in LDS from DMA-streamed tiles (csrc/gramx.hip)
+    int nb = 0;
+    float* part = static_cast<float*>(workspace);
+    int rc = gramt_bn(g1, ldg1, g2, ldg2, z, ldz, mean, rstd, gamma, beta, relu, stats, inv_n, training, m, b, ldb, k, n, part,
+                      &nb, st);
+    if (rc != SGF_OK) return rc;
+    const int64_t len = static_cast<int64_t>(m) * k + m;
+    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
+                       1, c, ldc, colsum);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int DP = padded_dim(m > k ? m : k);
   const int R = reduce_rows_per_tile<uint16_t, kModeGramBN>(DP);
   const int64_t ntiles = (n + R - 1) / R;
@@ -1467,6 +1480,19 @@ extern "C" int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int6
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE, "%s: workspace too small", fn);
   SGF_REQUIRE(aligned4<uint16_t>(g, ldg) && aligned4<uint16_t>(xin, ldx) && aligned4<uint16_t>(b, ldb), SGF_E_INVALID,
               "%s: operands must be 4-element aligned with ld %% 4 == 0", fn);
+  if (gramt_supported(m, k, n) && gramt_aligned(g, ldg) && gramt_aligned(xin, ldx) && gramt_aligned(b, ldb)) {   // csrc/gramx.hip
+    int nb = 0;
+    float* part = static_cast<float*>(workspace);
+    int rc = gramt_ln(g, ldg, xin, ldx, mean, rstd, gamma, beta, relu, m, b, ldb, k, n, part, &nb, st);
+    if (rc != SGF_OK) return rc;
+    const int64_t len = static_cast<int64_t>(m) * k + m;
+    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
+                       1, c, ldc, colsum);
+    if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, part, nb, kVecB, m, dbeta);
+    if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, part, nb, kVecC, m, dgamma);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const int DP = m;                                    // a LayerNorm row = exactly one patch row of DP / 4 lanes
   const int R = reduce_rows_per_tile<uint16_t, kModeGramLN>(DP);
   const int64_t ntiles = (n + R - 1) / R;

@@ -10,7 +10,20 @@
 #include "common.h"
 
 #include <dlfcn.h>
+// The library is bound with dlopen(), so its headers are not a build requirement either: without them the few types and
+// enumerators used here are declared locally (values fixed by NCCL's / RCCL's public ABI, nccl.h).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+#endif
 
 namespace sgf {
 namespace {
@@ -142,14 +155,19 @@ extern "C" int sgf_comm_all_to_all(void* comm, const void* send, const int64_t* 
   Comm* c = static_cast<Comm*>(comm);
   hipStream_t st = static_cast<hipStream_t>(stream);
   SGF_RCCL(rccl().GroupStart());
-  for (int p = 0; p < c->world; ++p) {
+  // An error inside the group must not return with the group open (every later collective of this thread would be queued
+  // and never launched): remember the first one, close the group, then report it.
+  ncclResult_t first = ncclSuccess;
+  for (int p = 0; p < c->world && first == ncclSuccess; ++p) {
     if (send_bytes_host[p] > 0)
-      SGF_RCCL(rccl().Send(static_cast<const char*>(send) + send_offset_host[p], static_cast<size_t>(send_bytes_host[p]), ncclInt8, p,
-                           c->comm, st));
-    if (recv_bytes_host[p] > 0)
-      SGF_RCCL(rccl().Recv(static_cast<char*>(recv) + recv_offset_host[p], static_cast<size_t>(recv_bytes_host[p]), ncclInt8, p,
-                           c->comm, st));
+      first = rccl().Send(static_cast<const char*>(send) + send_offset_host[p], static_cast<size_t>(send_bytes_host[p]), ncclInt8,
+                          p, c->comm, st);
+    if (first == ncclSuccess && recv_bytes_host[p] > 0)
+      first = rccl().Recv(static_cast<char*>(recv) + recv_offset_host[p], static_cast<size_t>(recv_bytes_host[p]), ncclInt8, p,
+                          c->comm, st);
   }
-  SGF_RCCL(rccl().GroupEnd());
+  const ncclResult_t end = rccl().GroupEnd();
+  SGF_REQUIRE(first == ncclSuccess, SGF_E_HIP, "sgf_comm_all_to_all: send / recv -> %s", rccl().GetErrorString(first));
+  SGF_REQUIRE(end == ncclSuccess, SGF_E_HIP, "sgf_comm_all_to_all: group end -> %s", rccl().GetErrorString(end));
   return SGF_OK;
 }

@@ -54,8 +54,28 @@ struct GramxArgs {
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// two fp32 -> packed bf16, round to nearest even: v_cvt_pk_bf16_f32 (the same rounding as common.h's f32_to_bf16)
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
+  const f32v2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2));
+}
+// sum over the 32 lanes of this lane's half of the wave, the same value in all of them, on the VALU alone (four DPP butterfly
+// steps inside the rows of 16, then one v_permlane16_swap): no LDS round trips (a __shfl_xor chain is five dependent
+// ds_bpermute, and with 2 waves per SIMD nothing hides them)
+__device__ __forceinline__ float half_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf,
+                                                                 false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  const uint32_t u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // r[0] = rows {0, 0, 2, 2}, r[1] = rows {1, 1, 3, 3}
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // 64 lanes x 16 bytes -> LDS [dst, dst + 1024), lane l at l * 16 (dst wave-uniform).  M0 is written and restored in the
@@ -83,6 +103,8 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -318,6 +340,284 @@ __global__ __launch_bounds__(kGxThreads) void k_gramx(GramxArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gramt: the Gram whose A operand is FORMED from streamed tensors — the stems' dW / db without a materialised input
+// gradient (sgf_gram_bn_bwd: A = BatchNorm'(relu'(g1 + g2)) from g1, g2, z; sgf_gram_ln_bwd: A = LayerNorm'(relu'(g)) from g,
+// the LayerNorm's input and its saved row statistics), B = x [n, k <= 128] (the features).
+//   * the raw streams land ROW-MAJOR (a DMA piece = two whole 512-byte rows: wave w requests rows 4 w .. 4 w + 3 of every
+//     stage and is the wave that transforms them: half a wave per row, lane = a group of 8 columns, so a LayerNorm's row sums
+//     are 5 shuffles inside the half-wave and the per-column coefficients of this lane sit in registers for the whole kernel);
+//   * the formed operand is rounded to bf16 once (the tensor sgf_bn_bwd_apply / sgf_ln_bwd would have written) and stored into
+//     a separate A image in the transposing-read layout (16-byte scattered stores, 4-way conflicted: 2 per thread and stage);
+//   * x arrives in the transposing-read layout, 128 columns wide (one piece per wave and stage);
+//   * wave w owns the 32 x 128 block of C = A^T x below A's columns [32 w, 32 w + 32): one A fragment, four B fragments and
+//     four MFMAs per k-step.
+// Ring: 2 stages of 56 KiB (three raw streams) or 3 stages of 40 KiB (two).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kGtBN = 0, kGtLN = 1;
+constexpr int kGtBBytes = kGxRows * 256;           // x image: 32 rows x 128 columns = 8 KiB
+
+struct GramtArgs {
+  const void* r0;   // BN: g1      LN: g
+  const void* r1;   // BN: g2 (or null)
+  const void* r2;   // BN: z       LN: the LayerNorm's input
+  const void* b;    // x
+  int64_t ld0, ld1, ld2, ldb;
+  int64_t n;
+  int32_t m, k;
+  const float *mean, *rstd;      // BN: per column   LN: per row
+  const float *gamma, *beta;     // per column (null: 1 / 0)
+  const float* stats;            // BN, training: [sum dz' | sum dz' xhat] over the rows
+  float inv_n;
+  int32_t training, relu;
+  float* partial;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kGxThreads) void k_gramt(GramtArgs p) {
+  constexpr int NR = MODE == kGtBN ? 3 : 2;                        // raw streams
+  constexpr int NST = MODE == kGtBN ? 2 : 3;                       // ring depth
+  constexpr int kStage = NR * kGxOpBytes + kGtBBytes;
+  constexpr int kRing = NST * kStage;
+  constexpr int kAimg = kRing;                                     // the formed operand: one image of 16 KiB
+  constexpr int kScal = kAimg + kGxOpBytes;                        // LN: [mean 64 | rstd 64] floats per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kScal + NST * 512];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = lane & 31;                                        // this lane's columns: 8 cg .. 8 cg + 7
+  const int hw = lane >> 5;
+  const bool col_ok = 8 * cg < p.m;
+
+  const int64_t total = (p.n + kGxRows - 1) / kGxRows;
+  const int nq = blockIdx.x < total ? static_cast<int>((total - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+  const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(SGF_LDS(unsigned char, smem)));
+  const bool has1 = MODE == kGtBN && p.r1 != nullptr;
+
+  // ---- staging ----
+  const unsigned char* gr[3] = {static_cast<const unsigned char*>(p.r0), static_cast<const unsigned char*>(p.r1),
+                                static_cast<const unsigned char*>(p.r2)};
+  const int64_t pitch[3] = {p.ld0 * 2, p.ld1 * 2, p.ld2 * 2};
+  const int64_t pitch_b = p.ldb * 2;
+  const int rcol = (col_ok ? 8 * cg : p.m - 8) * 2;                // byte offset of this lane's columns in a raw row
+  // x piece of this wave: (2 s + r) = wave >> 1, p = wave & 1
+  const int brow = 16 * (wave >> 2) + 4 * ((wave >> 1) & 1) + 8 * ((lane >> 4) & 1) + ((lane >> 1) & 3);
+  int bcol = 64 * (wave & 1) + 32 * (lane >> 5) + 16 * ((lane >> 3) & 1) + 8 * (lane & 1);
+  bcol = bcol + 8 <= p.k ? bcol : p.k - 8;
+  const int nps = (MODE == kGtBN ? (has1 ? 7 : 5) : 5) + ((MODE == kGtLN && wave < 2) ? 1 : 0);
+
+  auto issue = [&](int q) {
+    const int64_t row0 = (blockIdx.x + static_cast<int64_t>(q) * gridDim.x) * kGxRows;
+    const uint32_t base = smem_lds + static_cast<uint32_t>((q % NST) * kStage);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int64_t r = row0 + 4 * wave + 2 * j + hw;
+      r = r < p.n ? r : p.n - 1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int img = MODE == kGtBN ? i : (i == 0 ? 0 : 1);      // LN: r0 -> image 0, r2 -> image 1
+        if (MODE == kGtLN && i == 1) continue;
+        if (MODE == kGtBN && i == 1 && !has1) continue;
+        dma16(gr[i] + r * pitch[i] + rcol, base + img * kGxOpBytes + (2 * wave + j) * 1024);
+      }
+    }
+    {
+      int64_t r = row0 + brow;
+      r = r < p.n ? r : p.n - 1;
+      dma16(static_cast<const unsigned char*>(p.b) + r * pitch_b + bcol * 2, base + NR * kGxOpBytes + wave * 1024);
+    }
+    if (MODE == kGtLN && wave < 2) {                               // 64 row statistics (the stage's 32 and the next 32)
+      int64_t r = row0 + lane;
+      r = r < p.n ? r : p.n - 1;
+      dma4(reinterpret_cast<const unsigned char*>((wave == 0 ? p.mean : p.rstd) + r),
+           smem_lds + static_cast<uint32_t>(kScal + (q % NST) * 512 + wave * 256));
+    }
+  };
+
+  // ---- this lane's per-column coefficients ----
+  float bmu[8], brs[8], bga[8], bbe[8], bk0[8], bk1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * cg + e;
+    const bool ok = c < p.m;
+    bga[e] = ok ? (p.gamma ? p.gamma[c] : 1.f) : 0.f;
+    bbe[e] = ok ? (p.beta ? p.beta[c] : 0.f) : 0.f;
+    if (MODE == kGtBN) {
+      bmu[e] = ok ? p.mean[c] : 0.f;
+      brs[e] = ok ? p.rstd[c] : 0.f;
+      bk0[e] = (ok && p.training) ? p.stats[c] * p.inv_n : 0.f;
+      bk1[e] = (ok && p.training) ? p.stats[p.m + c] * p.inv_n : 0.f;
+    } else {
+      bmu[e] = brs[e] = bk0[e] = bk1[e] = 0.f;
+    }
+  }
+  // the coefficient loads are CONSUMED here: hipcc places its wait for a load at the first use, and a first use inside the
+  // stage loop would be a vmcnt(0) there — every DMA in flight waited for, every stage
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    asm volatile("" : "+v"(bga[e]), "+v"(bbe[e]));
+    if (MODE == kGtBN) asm volatile("" : "+v"(bmu[e]), "+v"(brs[e]), "+v"(bk0[e]), "+v"(bk1[e]));
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float csa[8], csb[8], csc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csa[e] = csb[e] = csc[e] = 0.f;
+  const float inv_d = 1.0f / static_cast<float>(p.m);
+  const int ntb = (p.k + 31) / 32 > 4 ? 4 : (p.k + 31) / 32;
+  const bool act = 32 * wave < p.m;
+
+#pragma unroll 1
+  for (int q = 0; q < NST - 1 && q < nq; ++q) issue(q);
+
+#pragma unroll 1
+  for (int q = 0; q < nq; ++q) {
+    const int later = nq - 1 - q < NST - 2 ? nq - 1 - q : NST - 2;
+    wait_vm(nps * later);
+    __syncthreads();                                     // stage q has landed; every wave is done with stage q - 1 and the A image
+    if (q + NST - 1 < nq) issue(q + NST - 1);
+    unsigned char* st = smem + (q % NST) * kStage;
+    const float* scal = reinterpret_cast<const float*>(smem + kScal + (q % NST) * 512);
+    const int64_t row0 = (blockIdx.x + static_cast<int64_t>(q) * gridDim.x) * kGxRows;
+    const int valid = p.n - row0 < kGxRows ? static_cast<int>(p.n - row0) : kGxRows;
+
+    // ---- form the A operand: rows 4 wave .. 4 wave + 3, half a wave per row ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = 4 * wave + 2 * j + hw;
+      const bool rok = rr < valid;
+      const int slot = (2 * wave + j) * 1024 + lane * 16;
+      const uint4 v0 = *reinterpret_cast<const uint4*>(st + slot);
+      const uint4 v2 = *reinterpret_cast<const uint4*>(st + (NR - 1) * kGxOpBytes + slot);
+      const uint32_t u0[4] = {v0.x, v0.y, v0.z, v0.w}, u2[4] = {v2.x, v2.y, v2.z, v2.w};
+      float gv[8], zv[8], dv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gv[2 * e] = bf_lo(u0[e]); gv[2 * e + 1] = bf_hi(u0[e]);
+        zv[2 * e] = bf_lo(u2[e]); zv[2 * e + 1] = bf_hi(u2[e]);
+      }
+      if (MODE == kGtBN) {
+        if (has1) {
+          const uint4 v1 = *reinterpret_cast<const uint4*>(st + kGxOpBytes + slot);
+          const uint32_t u1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gv[2 * e] += bf_lo(u1[e]); gv[2 * e + 1] += bf_hi(u1[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                   // sgf_bn_bwd_apply's arithmetic
+          const float xh = (zv[e] - bmu[e]) * brs[e];
+          float gg = gv[e];
+          if (p.relu) gg = (xh * bga[e] + bbe[e]) > 0.f ? gg : 0.f;
+          gg -= bk0[e] + xh * bk1[e];
+          dv[e] = rok ? bga[e] * brs[e] * gg : 0.f;
+        }
+      } else {                                           // sgf_ln_bwd's arithmetic
+        const float mu = scal[rr], rs = scal[64 + rr];
+        float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[e] = (zv[e] - mu) * rs;
+          float gm = gv[e];
+          if (p.relu) gm = fmaf(xh[e], bga[e], bbe[e]) > 0.f ? gm : 0.f;
+          gm = (rok && 8 * cg + e < p.m) ? gm : 0.f;
+          dxh[e] = gm * bga[e];
+          s1 += dxh[e];
+          s2 = fmaf(dxh[e], xh[e], s2);
+          csb[e] += gm;
+          csc[e] = fmaf(gm, xh[e], csc[e]);
+        }
+        s1 = half_sum(s1) * inv_d;
+        s2 = half_sum(s2) * inv_d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] = (rok && 8 * cg + e < p.m) ? rs * (dxh[e] - s1 - xh[e] * s2) : 0.f;
+      }
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = pack_bf16(dv[2 * e], dv[2 * e + 1]);
+        csa[2 * e] += bf_lo(o[e]);
+        csa[2 * e + 1] += bf_hi(o[e]);
+      }
+      // the slot of (row rr, column group cg) in the transposing-read image
+      const int r16 = rr & 15;
+      const int unit = (2 * (rr >> 4) + ((r16 >> 2) & 1)) * 8 + (cg >> 2);
+      const int u = 16 * (r16 >> 3) + 8 * ((cg >> 1) & 1) + 2 * (r16 & 3) + (cg & 1);
+      *reinterpret_cast<uint4*>(smem + kAimg + unit * 512 + u * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();                                     // the A image is complete
+
+    // ---- matrix cores ----
+    if (act) {
+      const unsigned char* sa = smem + kAimg;
+      const unsigned char* sb = st + NR * kGxOpBytes;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af, bfr[4];
+        {
+          const unsigned char* u = sa + ((2 * s) * 8 + wave) * 512 + lane * 8;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u + 8 * 512));
+          af[0] = r0[0]; af[1] = r0[1]; af[2] = r0[2]; af[3] = r0[3];
+          af[4] = r1[0]; af[5] = r1[1]; af[6] = r1[2]; af[7] = r1[3];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          const unsigned char* u = sb + ((2 * s) * 4 + tn) * 512 + lane * 8;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u + 4 * 512));
+          bfr[tn][0] = r0[0]; bfr[tn][1] = r0[1]; bfr[tn][2] = r0[2]; bfr[tn][3] = r0[3];
+          bfr[tn][4] = r1[0]; bfr[tn][5] = r1[1]; bfr[tn][6] = r1[2]; bfr[tn][7] = r1[3];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          if (tn < ntb) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[tn], acc[tn], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial ----
+  float* part = p.partial + static_cast<int64_t>(blockIdx.x) * kRedPartialStride;
+  if (act) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+      if (tn < ntb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          part[(32 * wave + mfma32_row(r, lane)) * 256 + 32 * tn + (lane & 31)] = acc[tn][r];
+  }
+  __syncthreads();
+  float* fl = reinterpret_cast<float*>(smem);
+  const int ridx = 2 * wave + hw;                        // 16 threads share a column group
+  auto park = [&](const float (&v)[8], int off) {
+    *reinterpret_cast<float4*>(&fl[off + ridx * 256 + 8 * cg]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&fl[off + ridx * 256 + 8 * cg + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+  };
+  park(csa, 0);
+  if (MODE == kGtLN) {
+    park(csb, 4096);
+    park(csc, 8192);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    constexpr int NV = MODE == kGtLN ? 3 : 1;
+    const int dst[3] = {kRedTileElems, kRedVecB, kRedVecC};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += fl[4096 * v + r * 256 + tid];
+      part[dst[v] + tid] = s;
+    }
+  }
+  if (tid == 0) part[kRedTileElems + 256] = part[kRedTileElems + 257] = 0.f;
+}
+
 bool aligned16(const void* p, int64_t ld) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 8 == 0; }
 
 }  // namespace
@@ -358,6 +658,41 @@ int gramx_bwdhs(const void* h, int64_t ldh, const void* g, int64_t ldg, const fl
   const int grid = static_cast<int>(total < kRedMaxBlocks ? total : kRedMaxBlocks);
   *nblk = grid;
   hipLaunchKernelGGL((k_gramx<kGxBwdHS>), dim3(grid), dim3(kGxThreads), 0, st, x);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+bool gramt_supported(int m, int k, int64_t n) {
+  static EnvInt on{"SGF_GRAMX", 1};
+  return on.get() != 0 && m >= 8 && m <= 256 && m % 8 == 0 && k >= 8 && k <= 128 && k % 8 == 0 && n >= 4096;
+}
+bool gramt_aligned(const void* p, int64_t ld) { return p == nullptr || aligned16(p, ld); }
+
+int gramt_bn(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, const void* z, int64_t ldz, const float* mean,
+             const float* rstd, const float* gamma, const float* beta, int relu, const float* stats, float inv_n, int training,
+             int m, const void* b, int64_t ldb, int k, int64_t n, float* partial, int* nblk, hipStream_t st) {
+  const int64_t total = (n + kGxRows - 1) / kGxRows;
+  GramtArgs a{};
+  a.r0 = g1; a.ld0 = ldg1; a.r1 = g2; a.ld1 = ldg2; a.r2 = z; a.ld2 = ldz; a.b = b; a.ldb = ldb; a.n = n; a.m = m; a.k = k;
+  a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.stats = stats; a.inv_n = inv_n; a.training = training;
+  a.relu = relu; a.partial = partial;
+  const int grid = static_cast<int>(total < kRedMaxBlocks ? total : kRedMaxBlocks);
+  *nblk = grid;
+  hipLaunchKernelGGL((k_gramt<kGtBN>), dim3(grid), dim3(kGxThreads), 0, st, a);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+int gramt_ln(const void* g, int64_t ldg, const void* xin, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+             const float* beta, int relu, int m, const void* b, int64_t ldb, int k, int64_t n, float* partial, int* nblk,
+             hipStream_t st) {
+  const int64_t total = (n + kGxRows - 1) / kGxRows;
+  GramtArgs a{};
+  a.r0 = g; a.ld0 = ldg; a.r2 = xin; a.ld2 = ldx; a.b = b; a.ldb = ldb; a.n = n; a.m = m; a.k = k;
+  a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.relu = relu; a.partial = partial;
+  const int grid = static_cast<int>(total < kRedMaxBlocks ? total : kRedMaxBlocks);
+  *nblk = grid;
+  hipLaunchKernelGGL((k_gramt<kGtLN>), dim3(grid), dim3(kGxThreads), 0, st, a);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

@@ -24,4 +24,15 @@ int gramx_gram(const void* a, int64_t lda, int m, const void* b, int64_t ldb, co
 int gramx_bwdhs(const void* h, int64_t ldh, const void* g, int64_t ldg, const float* rowscal, int d, int64_t n, float* partial,
                 int* nblk, hipStream_t st);
 
+// the stems' dW / db with the A operand formed in LDS from the streamed tensors (k_gramt): BatchNorm / LayerNorm backward;
+// every tensor operand 16-byte aligned with ld % 8 == 0 (gramt_aligned), k <= 128.  LN: second / third vector = dbeta / dgamma
+bool gramt_supported(int m, int k, int64_t n);
+bool gramt_aligned(const void* p, int64_t ld);
+int gramt_bn(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, const void* z, int64_t ldz, const float* mean,
+             const float* rstd, const float* gamma, const float* beta, int relu, const float* stats, float inv_n, int training,
+             int m, const void* b, int64_t ldb, int k, int64_t n, float* partial, int* nblk, hipStream_t st);
+int gramt_ln(const void* g, int64_t ldg, const void* xin, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+             const float* beta, int relu, int m, const void* b, int64_t ldb, int k, int64_t n, float* partial, int* nblk,
+             hipStream_t st);
+
 }  // namespace sgf

@@ -16,6 +16,9 @@ exactly as the eager path issues them) and replayed for every later batch of tha
     offset is a launch argument), one GPU, a symmetric batch graph (batching.subgraph's promise for a symmetric parent: the
     backward multiplies with the same arrays), features that do not require a gradient.  Everything else — evaluation, the
     first batch of a size (it warms the caches the capture must not contain), odd shapes — runs the eager path;
+  * a replay reads its batch from a PRIVATE static input (a copy of the capture batch's features, never the caller's
+    tensor), and runs only while no parameter carries a gradient (a replayed backward hands out static gradient buffers that
+    autograd adopts as `p.grad`: gradient accumulation over several batches stays on the eager path);
   * a replay writes into the graphs' static buffers: the logits are handed out as a copy, and while a replayed forward's
     backward is still outstanding (its logits alive, no gradient yet — two forwards before one backward) the next call of
     that size runs eager; at most 4 batch sizes per model stay captured (least recently used ones give their pools back);
@@ -176,7 +179,11 @@ def _capture(model, entry: _Entry, x, edge_index, cdt, out_dtype):
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
-        fn = torch.cuda.make_graphed_callables(step, (x.detach(),) + aliases, num_warmup_iters=0, allow_unused_input=True)
+        # the sample input becomes the graphs' STATIC input, into which every later replay copies its batch: a private
+        # buffer, not the caller's tensor (a trainer that keeps same-sized device batches across epochs would otherwise find
+        # its capture batch overwritten by the last batch's features)
+        x_static = x.detach().clone()
+        fn = torch.cuda.make_graphed_callables(step, (x_static,) + aliases, num_warmup_iters=0, allow_unused_input=True)
     finally:
         if gc_was_on:
             gc.enable()
@@ -204,6 +211,12 @@ def maybe_step(model, x, edge_index, cdt, out_dtype):
         return None
     entry.seen += 1
     if entry.seen <= _SEEN_BEFORE_CAPTURE or entry.busy():
+        return None
+    # A replayed backward hands out the graphs' STATIC gradient buffers, and autograd's AccumulateGrad adopts a gradient it
+    # solely owns as `p.grad`: with a gradient still in place (accumulation over several batches, zero_grad(set_to_none=False))
+    # the next replay would overwrite it before adding to it.  The reference trainers clear their gradients every batch
+    # (large/main-batch.py:142); anything else keeps the eager path.
+    if any(p.grad is not None for p in model.parameters()):
         return None
     csr = edge_index._sgf_csr
     nnz = int(csr[1].numel())

@@ -165,12 +165,19 @@ class HipKernels:
         with torch.cuda.device(dev):
             _lib.call("sgf_subgraph_csr_plan", _ptr(rowptr), _ptr(colind), n, _ptr(subset), m, _ptr(local_of), _ptr(rowptr_b),
                       _ptr(deg_b), _ptr(total), _ptr(ws), ws.numel(), _stream(dev))
-            t, bad, longest = total.tolist()                # the one host read of the batch
-            t = 0 if bad else int(t)
-            colind_b = torch.empty(t, dtype=torch.int32, device=dev)
-            val_b = torch.empty(t, dtype=_F32, device=dev)
-            ei_b = torch.empty((2, t), dtype=torch.int64, device=dev) if want_edges else None
-            ws2 = _workspace(dev, "subgraph_csr_emit", lib.sgf_subgraph_csr_emit_workspace_bytes(m, t))
+            # the plan MARKED the parent's shared `local_of` table; only the emit call clears the marks again.  Whatever fails
+            # in between (the host read, an allocation) must not leave them behind: later batches would pick up stale local
+            # ids for nodes outside their subset.
+            try:
+                t, bad, longest = total.tolist()            # the one host read of the batch
+                t = 0 if bad else int(t)
+                colind_b = torch.empty(t, dtype=torch.int32, device=dev)
+                val_b = torch.empty(t, dtype=_F32, device=dev)
+                ei_b = torch.empty((2, t), dtype=torch.int64, device=dev) if want_edges else None
+                ws2 = _workspace(dev, "subgraph_csr_emit", lib.sgf_subgraph_csr_emit_workspace_bytes(m, t))
+            except BaseException:
+                local_of.fill_(-1)
+                raise
             _lib.call("sgf_subgraph_csr_emit", _ptr(rowptr), _ptr(colind), n, _ptr(subset), m, _ptr(local_of), _ptr(rowptr_b),
                       _ptr(deg_b), t, _ptr(colind_b), _ptr(val_b), _ptr(ei_b), _ptr(ws2), ws2.numel(), _stream(dev))
         if bad:

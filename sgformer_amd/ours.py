@@ -70,12 +70,21 @@ _entry_cache = _weakref.WeakKeyDictionary()
 
 
 def _stem_w(lin: nn.Linear, x):
-    """lin.weight for an input SGFormer.forward zero-padded to a multiple of 4 columns (pokec: f = 65 -> 68; sgf_pad_rows):
+    """lin.weight for an input SGFormer.forward zero-padded to whole 16-byte rows (pokec: f = 65 -> 68 / 72; sgf_pad_rows):
     zero weight columns for the padding, differentiable — autograd slices dW back to the parameter's shape."""
-    pad = x.shape[1] - lin.weight.shape[1]
-    if pad < 0:
-        raise RuntimeError(f"input has {x.shape[1]} features, the layer expects {lin.weight.shape[1]}")
+    f = lin.weight.shape[1]
+    pad = x.shape[1] - f
+    # only the entry copy's own padding is accepted (_entry_width): an input with other extra columns raises, as nn.Linear does
+    if pad != 0 and x.shape[1] not in ((f + 3) // 4 * 4, (f + 7) // 8 * 8):
+        raise RuntimeError(f"input has {x.shape[1]} features, the layer expects {f}")
     return lin.weight if pad == 0 else F.pad(lin.weight, (0, pad))
+
+
+def _entry_width(f: int, cdt) -> int:
+    """Width of the entry copy of f features: rows of whole 16 bytes — 8 bf16 elements (ogbn-products: 100 -> 104, so that
+    the stems' weight gradients stream x by LDS-DMA, csrc/gramx.hip) or 4 fp32 elements (pokec: 65 -> 68)."""
+    q = 8 if cdt == torch.bfloat16 else 4
+    return (f + q - 1) // q * q
 
 
 def _lin(x, lin: nn.Linear):
@@ -595,7 +604,7 @@ class SGFormer(nn.Module):
         # pinned so that a recycled data_ptr cannot alias it).
         perm = view.perm if view is not None else None
         f = x.shape[1]
-        fp = (f + 3) // 4 * 4
+        fp = _entry_width(f, cdt)
         pad = fp != f and not x.requires_grad and hasattr(ops.K, "pad_rows")
         if x.requires_grad:
             if perm is not None:
@@ -624,7 +633,7 @@ class SGFormer(nn.Module):
         """The entry copy for ONE use of x (a mini-batch's features): zero-padding to a multiple of 4 columns and the
         storage cast in one pass — the captured step of sgformer_amd.graphed calls this inside its graph."""
         f = x.shape[1]
-        fp = (f + 3) // 4 * 4
+        fp = _entry_width(f, cdt)
         if fp != f and hasattr(ops.K, "pad_rows"):
             return ops.K.pad_rows(x, None, fp, cdt)
         return x if x.dtype == cdt else x.to(cdt)

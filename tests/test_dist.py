@@ -642,4 +642,7 @@ def test_bench_dry_run_of_the_multi_gpu_configs_prints_exchange_bytes_and_a_labe
                                                      or workload.endswith("-weak"))
     m = out["scaling_model"]
     assert m["label"].startswith("MODEL") and "not a measurement" in m["label"]
-    assert m["all_gather_bytes_received_per_rank_per_step"] > 0 and m["modelled_step_ms"] > 0
+    assert m["all_gather_bytes_received_per_rank_per_step"] > 0
+    # the model starts from THIS run's step time, not from a constant of an earlier round
+    assert abs(m["measured_step_ms"] - out["ms_per_step"]) < 1e-2 and "implied_compute_ms_per_rank" in m
+    assert "modelled_nodes_per_s" not in m and "modelled_efficiency" not in m

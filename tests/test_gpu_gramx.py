@@ -140,3 +140,83 @@ def test_gramx_attention_backward_reduce(cuda, n, d):
     _switch(False)
     hs_old = K.attn_h_bwd_reduce_scaled(h, g, rowscal)
     assert _rel(hs, hs_old) <= 2e-6
+
+
+# ---- k_gramt: the stems' dW / db with the A operand formed in LDS (sgf_gram_bn_bwd / sgf_gram_ln_bwd) ---------------------
+@pytest.mark.parametrize("n", [4096, 4099, 8192 + 31, 65536 + 7, 300001])
+@pytest.mark.parametrize("m,k", [(256, 104), (256, 128), (128, 104), (64, 64), (256, 8), (200, 72)])
+@pytest.mark.parametrize("two,relu,training", [(True, True, True), (False, True, True), (True, False, False)])
+def test_gramt_bn(cuda, n, m, k, two, relu, training):
+    """large/ours.py:77-80 differentiated (GraphConv's stem: Linear -> BatchNorm -> relu): dW = dz^T x, db = sum dz with
+    dz = BatchNorm'(relu'(g1 + g2)) never written.  fp64 on the same bf16 operands, dz rounded to bf16 once; and the
+    register-staged kernel on the same inputs."""
+    from sgformer_amd import ops
+    if n > 65536 + 7 and (m, k) != (256, 104):
+        pytest.skip("large n: the production shape only")
+    K = ops.K
+    g = torch.Generator().manual_seed(3 * n + m + k + two)
+    g1 = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    g2 = torch.randn(n, m, generator=g).bfloat16().to(cuda) if two else None
+    z = (torch.randn(n, m, generator=g) * 1.3 + 0.2).bfloat16().to(cuda)
+    x = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    mean = (torch.randn(m, generator=g) * 0.2 + 0.2).to(cuda)
+    rstd = (1.0 / (1.0 + torch.rand(m, generator=g))).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(m, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(m, generator=g)).to(cuda)
+    gsum = g1.float() + (g2.float() if two else 0.0)
+    stats = K.bn_bwd_stats2(g1, g2, z, mean, rstd, gamma, beta, relu)
+    inv_n = 1.0 / n
+    _switch(True)
+    dw, db = K.gram_bn_bwd(g1, g2, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, x)
+    dw2, db2 = K.gram_bn_bwd(g1, g2, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    xh = (z.double() - mean.double()) * rstd.double()
+    gm = gsum.double() * ((xh * gamma.double() + beta.double()) > 0) if relu else gsum.double()
+    corr = (stats[:m].double() * inv_n + xh * stats[m:].double() * inv_n) if training else 0.0
+    dz_r = (gamma.double() * rstd.double() * (gm - corr)).float().bfloat16().double()
+    ref = dz_r.t() @ x.double()
+    assert _rel(dw, ref) <= 3e-4, _rel(dw, ref)
+    assert _rel(db, dz_r.sum(0)) <= 3e-4 or float(dz_r.sum(0).abs().max()) < 1e-2
+    _switch(False)
+    dw_old, db_old = K.gram_bn_bwd(g1, g2, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, x)
+    assert _rel(dw, dw_old) <= 5e-5 and (_rel(db, db_old) <= 5e-5 or float(db_old.abs().max()) < 1e-2)
+
+
+@pytest.mark.parametrize("n", [4096, 4099, 8192 + 31, 65536 + 7, 300001])
+@pytest.mark.parametrize("m,k", [(256, 104), (256, 128), (128, 104), (64, 64), (256, 8)])
+@pytest.mark.parametrize("relu,affine", [(True, True), (False, True), (True, False)])
+def test_gramt_ln(cuda, n, m, k, relu, affine):
+    """large/ours.py:198-201 differentiated (TransConv's stem: Linear -> LayerNorm -> relu): dW = dl^T x, db = sum dl,
+    d gamma = sum g' xhat, d beta = sum g' with dl = LayerNorm'(relu'(g)) never written."""
+    from sgformer_amd import ops
+    if n > 65536 + 7 and (m, k) != (256, 104):
+        pytest.skip("large n: the production shape only")
+    K = ops.K
+    g = torch.Generator().manual_seed(5 * n + m + k)
+    gr = torch.randn(n, m, generator=g).bfloat16().to(cuda)
+    xin = (torch.randn(n, m, generator=g) * 1.7 + 0.3).bfloat16().to(cuda)
+    x = torch.randn(n, k, generator=g).bfloat16().to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(m, generator=g)).to(cuda) if affine else None
+    beta = (0.2 * torch.randn(m, generator=g)).to(cuda) if affine else None
+    mean = xin.float().mean(1)
+    rstd = (xin.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    _switch(True)
+    dw, db, dg, dbt = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
+    dw2, db2, dg2, dbt2 = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dg, dg2) and torch.equal(dbt, dbt2)
+    xh = (xin.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    ga = gamma.double() if affine else 1.0
+    be = beta.double() if affine else 0.0
+    gm = gr.double() * ((xh * ga + be) > 0) if relu else gr.double()
+    dxh = gm * ga
+    dl = rstd.double()[:, None] * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True))
+    dl_r = dl.float().bfloat16().double()
+    ref = dl_r.t() @ x.double()
+    assert _rel(dw, ref) <= 3e-4, _rel(dw, ref)
+    assert _rel(db, dl_r.sum(0)) <= 3e-4 or float(dl_r.sum(0).abs().max()) < 1e-2
+    assert bool(((dg.double() - (gm * xh).sum(0)).abs() <= 2e-6 * (gm * xh).abs().sum(0).clamp_min(1e-3)).all())
+    assert bool(((dbt.double() - gm.sum(0)).abs() <= 2e-6 * gm.abs().sum(0).clamp_min(1e-3)).all())
+    _switch(False)
+    dw_old, db_old, dg_old, dbt_old = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
+    assert _rel(dw, dw_old) <= 3e-4
+    assert _rel(dg, dg_old) <= 1e-5 and _rel(dbt, dbt_old) <= 1e-5

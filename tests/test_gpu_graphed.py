@@ -185,3 +185,59 @@ def test_two_forwards_before_one_backward_and_kept_logits(cuda, monkeypatch):
     assert (la_e, lb_e) == (la_g, lb_g)
     for a, b in zip(g_eager, g_graph):
         assert torch.equal(a, b)
+
+
+def test_cached_batches_survive_replays_and_accumulation_stays_eager(cuda, monkeypatch):
+    """Two things a replay must not do to a caller that is not the reference trainer:
+    (1) a trainer that keeps same-sized DEVICE batches across epochs: the capture's static input is a private buffer, so
+        the cached feature tensors are what they were after any number of replays, and the logits of epoch 2 equal epoch 1's
+        eager logits for the same parameters;
+    (2) gradient accumulation over two batches without zero_grad: a replayed backward hands out static gradient buffers, so
+        with a gradient in place the step runs eager and p.grad == g1 + g2 of the eager run, bit for bit."""
+    from sgformer_amd import batching, graphed, ops, synth
+    from sgformer_amd.ours import SGFormer
+    n, f, c, d, m = 20000, 100, 47, 64, 5000
+    ei = synth.synthetic_graph(n, 10.0, seed=3)
+    gen = torch.Generator().manual_seed(4)
+    batching._parents.clear()
+    batches = []
+    for _ in range(2):
+        idx = torch.randperm(n, generator=gen)[:m]
+        ei_i, _ = batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)
+        batches.append((torch.randn(m, f, generator=gen).to(cuda), ei_i))
+    kept = [b[0].clone() for b in batches]
+
+    def run(graphs: bool):
+        monkeypatch.setenv("SGF_BATCH_GRAPH", "1" if graphs else "0")
+        torch.manual_seed(1)
+        model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=torch.bfloat16,
+                         **synth.RECIPES["ogbn-products"]).to(cuda).train()
+        before = dict(graphed.counters)
+        outs = []
+        for epoch in range(3):                           # the SAME two cached batches, three epochs, parameters untouched
+            for xb, eb in batches:
+                model.zero_grad()
+                out = model(xb, eb)
+                out.float().sum().backward()
+                outs.append(out.detach().float().clone())
+        # accumulation: two backward passes into the same .grad
+        model.zero_grad()
+        for xb, eb in batches:
+            model(xb, eb).float().sum().backward()
+        acc = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        used = {k: graphed.counters[k] - before[k] for k in before}
+        ops.graph_cache.clear()
+        return outs, acc, used
+
+    eager = run(False)
+    graph = run(True)
+    assert graph[2]["captures"] == 1 and graph[2]["replays"] >= 5
+    for xb, k in zip(batches, kept):
+        assert torch.equal(xb[0], k)                     # (1) the caller's tensors are untouched
+    for i, (a, b) in enumerate(zip(eager[0], graph[0])):
+        assert torch.equal(a, b), f"call {i}"
+    for i in range(2):                                   # same parameters, same batch: every epoch returns the same logits
+        assert torch.equal(graph[0][i], graph[0][i + 2]) and torch.equal(graph[0][i], graph[0][i + 4])
+    assert eager[1].keys() == graph[1].keys()
+    for k in eager[1]:                                   # (2)
+        assert torch.equal(eager[1][k], graph[1][k]), k

@@ -49,7 +49,7 @@ if ROOT not in sys.path:
 
 from sgformer_amd import ops, synth  # noqa: E402,F401  (tests/bench_modes.py reaches ops through this module)
 from benchlib.cpu import cpu_baseline  # noqa: E402
-from benchlib.model import scaling_model  # noqa: E402
+from benchlib.model import per_rank_memory_model, scaling_model  # noqa: E402
 from benchlib.timers import SpmmTimer, step_roofline  # noqa: E402,F401
 from benchlib.workloads import _sharded, make_inputs, run_minibatch, run_workload  # noqa: E402,F401
 
@@ -288,6 +288,7 @@ def main():
                            "(tests/test_oracle.py against the live /root/reference); the reference itself is not on this box")
         if world > 1:
             line["scaling_model"] = scaling_model(args.workload, args.dtype, world, ms)
+            line["per_rank_memory_model"] = per_rank_memory_model(args.workload, world, args.dtype)
         if cpu is not None:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
         print(json.dumps(line), flush=True)

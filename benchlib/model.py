@@ -41,3 +41,36 @@ def scaling_model(workload: str, dtype: str, world: int, measured_step_ms: float
             "note": "exchanges counted WITHOUT overlap (dist.py overlaps the own-column product with the halo exchange, so the "
                     "implied compute share is a lower bound); on a uniform graph the halo is every remote row (all-gather "
                     "fallback), on a graph sgf_reorder can partition the halo plan sends the cut-edge rows only"}
+
+
+HBM_BYTES = 288e9          # MI355X: 288 GB of HBM3E per GPU
+
+
+def per_rank_memory_model(workload: str, world: int, dtype: str = "bf16"):
+    """Device memory ONE rank of the node-sharded step holds at the workload's full size, by formula (a MODEL: components
+    below; the one measured anchor is the 1-GPU share of config 5, 98.5 GB peak in profiles/r05_bench_p100.json against
+    114.5 GB by this formula — the allocator re-uses transients the formula counts side by side, so it errs high).
+      features        fp32 [n, f] as the trainer hands them in + the module's storage-dtype entry copy
+      edges           the rank's edge list, int64 [2, nnz]
+      csr             rowptr int64 + colind int32 + val fp32, twice when the rank's block is not symmetric (local_edges shards)
+      activations     21 [n, d] tensors alive at the peak of a step (stems 4, attention 2, 3 per GCN layer at Lg = 3, 6 backward
+                      transients) + logits and their gradient in fp32
+      exchange        node-sharded only: the SpMM operand of every other rank, worst case all of it (all-gather fallback on a
+                      graph without locality; the halo plan needs less)"""
+    n, deg, f, c, d = synth.SHAPES[workload]
+    weak = workload.endswith("-weak")
+    cfg = synth.RECIPES.get(workload, synth.RECIPES["ogbn-products"])
+    s = 4 if dtype == "f32" else 2
+    n_total = n * world if weak else n
+    rows = n_total // world
+    nnz = int(rows * (deg + 1))
+    lg = cfg["gnn_num_layers"]
+    T = rows * d * s
+    comp = {"features": rows * f * 4 + rows * ((f + 7) // 8 * 8) * s,
+            "edges": 2 * nnz * 8,
+            "csr": ((rows + 1) * 8 + nnz * 8) * (2 if world > 1 else 1),
+            "activations": (6 + 3 * lg + 6) * T + 2 * rows * c * 4,
+            "exchange": (n_total - rows) * d * s if world > 1 else 0}
+    total = sum(comp.values())
+    return {"label": "MODEL by formula — not a measurement", "per_rank_rows": rows, "per_rank_nnz": nnz,
+            "bytes": comp, "total_bytes": int(total), "hbm_bytes": int(HBM_BYTES), "fits": total < HBM_BYTES}

@@ -211,7 +211,12 @@ def run_workload(args, graph_kind, rank, world, dev, steps, warmup, with_aten=Fa
                      "repartition_bytes_per_step": ctx.bytes_repartition // max(warmup + steps, 1),
                      # exchanges that actually ran split (own-column product while the halo rows travelled), per step —
                      # 0 when the halo plan is off (all-gather fallback) or this rank has no halo
-                     "halo_exchanges_overlapped_per_step": getattr(ctx, "overlapped_exchanges", 0) // max(warmup + steps, 1)}
+                     "halo_exchanges_overlapped_per_step": getattr(ctx, "overlapped_exchanges", 0) // max(warmup + steps, 1),
+                     # which way the SpMM operand travelled: the halo plan (cut-edge rows only, all_to_all) when the largest
+                     # halo / remote-rows ratio over the ranks stays under SGF_HALO_MAX, else every remote row (all-gather)
+                     "spmm_exchange": None if getattr(ctx, "last_halo", None) is None else
+                     {"path": "halo" if ctx.last_halo[1] else "all_gather", "halo_fraction_max": round(ctx.last_halo[0], 4),
+                      "halo_max": ctx.halo_max, "overlap_own_columns": bool(getattr(ctx, "overlap", False))}}
     if medium:
         cfg = dict(gnn_num_layers=4, trans_num_layers=1)     # medium/run.sh:2-7 (for the whole-step byte formula)
     out = dict(n=n, f=f, c=c, d=d, weak=weak, cfg=cfg, nnz=int(ei.shape[1]), elapsed=elapsed, loss=loss_val, ms_aten=ms_aten, ms_fused=ms_fused, loss_mode=state["mode"],

@@ -54,6 +54,16 @@ def main(path: str, elem: int):
          ((T + 2 * (T + GC) + 3 * 3 * T) / 6) if r04 else 2 * T,
          "6 per step: G = h^T h (1T), the head's two dW (T + g each), three PAIRED dW of a GCN layer (dz, y, x0: 3T)" if r04
          else "reads 2 tensors", find),
+        # r06: the node reductions on csrc/gramx.hip (tiles by LDS-DMA, fragments by transposing LDS reads)
+        ("k_gramx<Gram>  (sgf_gram / sgf_gram2: G, dW)", ("k_gramx<0>",), (T + 2 * (T + GC) + 3 * 3 * T) / 6,
+         "6 per step: G = h^T h (1T, one image serves both operands), the head's two dW (T + g each), three PAIRED dW of a "
+         "GCN layer (dz, y, x0: 3T)", find),
+        ("k_gramx<BwdHS>  (sgf_attn_h_bwd_reduce_scaled)", ("k_gramx<1>",), 2 * T + N * 8 / 1e9,
+         "reads h, dout and 8 B of row scalars per node; dnum formed in LDS", find),
+        ("k_gramt<BN>  (sgf_gram_bn_bwd)", ("k_gramt<0>",), 3 * T + N * 104 * elem / 1e9,
+         "GraphConv stem: g1, g2, z -> dz formed in LDS, x [N,104]: dW, db without a stored dz", find),
+        ("k_gramt<LN>  (sgf_gram_ln_bwd)", ("k_gramt<1>",), 2 * T + N * 104 * elem / 1e9 + N * 8 / 1e9,
+         "TransConv stem: g, LayerNorm input, row statistics -> dl formed in LDS, x [N,104]: dW, db, dgamma, dbeta", find),
         ("k_reduce_bf16<256,GramBN,8>  (sgf_gram_bn_bwd)", ("k_reduce_bf16<256, 5, 8>",), 3 * T + XF,
          "GraphConv stem: g1, g2, z -> dz on the fly, x [N,100]: dW, db without a stored dz", find),
         ("k_reduce_bf16<256,GramLN,8>  (sgf_gram_ln_bwd)", ("k_reduce_bf16<256, 6, 8>",), 2 * T + XF,

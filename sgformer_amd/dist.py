@@ -75,6 +75,7 @@ class HaloPlan:
         dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=ctx.group)   # one decision for all ranks
         self.max_fraction = float(frac)
         self.enabled = self.max_fraction <= ctx.halo_max
+        ctx.last_halo = (self.max_fraction, self.enabled)       # (what bench.py prints as `spmm_exchange`)
         if not self.enabled:
             return
         owner = torch.div(remote, ctx.n_max, rounding_mode="floor")
@@ -411,6 +412,7 @@ class ShardContext:
         self.bytes_all_gathered = 0
         self.bytes_halo_sent = 0
         self.bytes_repartition = 0
+        self.last_halo = None           # (largest halo / remote-rows ratio over the ranks, halo path taken) of the last plan
         # SGF_DIST_REORDER=0 keeps the caller's node order across ranks (default: try sgf_reorder once per graph)
         self.reorder = os.environ.get("SGF_DIST_REORDER", "1") == "1" and not self.local_edges
         self.local_graph = False        # batch mode: the SpMM multiplies with this rank's own edges only (no halo)
@@ -438,6 +440,7 @@ class ShardContext:
         ctx.local_edges, ctx.local_graph, ctx.reorder = False, True, False
         ctx.halo_max = 0.0
         ctx.bytes_all_reduced = ctx.bytes_all_gathered = ctx.bytes_halo_sent = ctx.bytes_repartition = 0
+        ctx.last_halo = None
         return ctx
 
     def repartition_for(self, edge_index: torch.Tensor):

@@ -18,6 +18,19 @@ activation storage (fp32 master weights / accumulation); the default is the refe
 For `main-batch.py` the per-batch `torch_geometric.utils.subgraph` call is served by the GPU
 implementation in sgformer_amd.batching (`--sgf-host-subgraph 1` keeps PyG's host version).  The trainers' own
 `nn.NLLLoss()` runs as a gather + masked sum instead of ATen's one-block reduction (`--sgf-aten-loss 1` keeps ATen's).
+
+What the launcher rewires besides `ours`, and how to turn each off (every patch reaches the original for any call it does not
+cover; tests/test_launch_patches.py drives each with callers that are not the reference's trainers):
+
+    F.log_softmax / F.nll_loss          lazy log-softmax + one-pass loss on the training rows   --sgf-aten-loss 1
+    torch.optim.Adam.__init__           fused=True for all-CUDA float parameters                SGF_FUSED_ADAM=0
+    torch_geometric.utils.subgraph      device implementation (main-batch.py only)              --sgf-host-subgraph 1
+    torch_geometric.utils.to_undirected / remove_self_loops / add_self_loops                    --sgf-host-prologue 1
+    torch_geometric.loader.NeighborLoader (100M only)                                           --sgf-host-sampler 1
+    dataset.load_dataset (node features resident on the GPU, main-batch.py only)                --sgf-host-features 1
+    torch.set_num_threads(4)  (main-batch.py only)                                              OMP_NUM_THREADS=...
+
+    --sgf-patches minimal  (or SGF_PATCHES=minimal)   none of the above: the module drop-in only.
 """
 from __future__ import annotations
 
@@ -294,6 +307,9 @@ def main(argv=None):
     host_features = _pop_option(argv, "--sgf-host-features")   # any value: keep node features on the host
     aten_loss = _pop_option(argv, "--sgf-aten-loss")           # any value: keep ATen's nll_loss kernels
     host_sampler = _pop_option(argv, "--sgf-host-sampler")     # any value: keep PyG's host NeighborLoader (100M)
+    patches = _pop_option(argv, "--sgf-patches") or os.environ.get("SGF_PATCHES", "all")
+    if patches not in ("all", "minimal"):
+        raise SystemExit(f"sgformer_amd.launch: --sgf-patches {patches!r} (choose 'all' or 'minimal')")
     if not argv or argv[0] in ("-h", "--help"):
         raise SystemExit(__doc__)
     trainer = os.path.abspath(argv[0])
@@ -316,6 +332,12 @@ def main(argv=None):
     if variant in ("100M", "100m"):
         patch_100m_data_utils()
     _select_device(argv)
+    if patches == "minimal":
+        # the module drop-in ONLY: `ours` (and, for the medium / 100M trainers, the two repairs above, which touch the
+        # TRAINER's own modules) — nothing of torch, torch_geometric or the host thread pool is rewired: F.log_softmax,
+        # F.nll_loss, torch.optim.Adam, torch_geometric.utils.* and NeighborLoader stay what the environment provides
+        runpy.run_path(trainer, run_name="__main__")
+        return
     if host_subgraph is None and os.path.basename(trainer) == "main-batch.py":
         patch_subgraph()
     # --sgf-host-subgraph implies the host prologue: PyG's host subgraph() indexes a CPU mask with edge_index[0],

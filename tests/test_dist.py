@@ -646,3 +646,39 @@ def test_bench_dry_run_of_the_multi_gpu_configs_prints_exchange_bytes_and_a_labe
     # the model starts from THIS run's step time, not from a constant of an earlier round
     assert abs(m["measured_step_ms"] - out["ms_per_step"]) < 1e-2 and "implied_compute_ms_per_rank" in m
     assert "modelled_nodes_per_s" not in m and "modelled_efficiency" not in m
+
+
+def test_the_drivers_8_rank_line_for_config_5_and_its_per_rank_memory(tmp_path):
+    """the driver's own launch line for BASELINE config 5 — `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 ... bench.py --gpus 8 --workload papers100M-weak` — on this GPU-less host (dry run: gloo, CPU kernel
+    table, toy node count): eight ranks rendezvous, every rank generates only its own rows (synth.synthetic_graph_shard), the
+    line says which way the SpMM operand travelled, carries no scaling number that is not labelled a model, and the per-rank
+    device memory AT FULL SIZE (111 M nodes over 8 GPUs), by formula, stays under the 288 GB of one MI355X."""
+    import json
+    import subprocess
+    import sys
+    from benchlib.model import per_rank_memory_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "SGF_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "1"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+           "--nodes", "300", "--workload", "papers100M-weak"]
+    p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["dry_run"] is True
+    assert out["config"]["nodes"] == 8 * 300 and "nnz_per_rank" in out["config"]
+    ex = out["config"]["exchanged"]
+    assert ex["spmm_exchange"]["path"] in ("halo", "all_gather") and 0.0 <= ex["spmm_exchange"]["halo_fraction_max"] <= 1.0
+    assert ex["all_reduce_bytes_per_step"] > 0 and "halo_exchanges_overlapped_per_step" in ex
+    assert out["scaling_model"]["label"].startswith("MODEL") and out["per_rank_memory_model"]["label"].startswith("MODEL")
+    assert "efficiency" not in json.dumps(out)                    # the driver computes efficiency itself
+    # the full-size shape by formula: every component, their sum, and the 288 GB bound
+    m = per_rank_memory_model("papers100M-weak", 8, "bf16")
+    assert m["per_rank_rows"] == 13882494 and m["per_rank_rows"] * 8 >= 111_059_952
+    assert set(m["bytes"]) == {"features", "edges", "csr", "activations", "exchange"}
+    assert m["total_bytes"] == sum(m["bytes"].values()) and m["total_bytes"] < 288e9 and m["fits"]
+    assert m["bytes"]["exchange"] == (8 - 1) * 13882494 * 128 * 2
+    # the anchor: the measured peak of ONE GPU's share (profiles/r05_bench_p100.json: 98.49 GB) lies under the formula's figure
+    one = per_rank_memory_model("papers100M-shard8", 1, "bf16")
+    assert 98.49e9 < one["total_bytes"] < 1.35 * 98.49e9

@@ -241,3 +241,69 @@ def test_cached_batches_survive_replays_and_accumulation_stays_eager(cuda, monke
     assert eager[1].keys() == graph[1].keys()
     for k in eager[1]:                                   # (2)
         assert torch.equal(eager[1][k], graph[1][k]), k
+
+
+def _two_region_graph(n, dense, seed):
+    """sparse uniform graph over n nodes + a DENSE block among the first `dense` nodes + node 0 as a hub of nodes 1..6000,
+    symmetric, coalesced, one self-loop per node (the trainer's prologue)."""
+    from sgformer_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    sparse = synth.synthetic_graph(n, 6.0, seed=seed)
+    a = torch.randint(0, dense, (dense * 20,), generator=g)
+    b = torch.randint(0, dense, (dense * 20,), generator=g)
+    hub = torch.arange(1, 6001)
+    src = torch.cat([sparse[0], a, b, torch.zeros_like(hub), hub])
+    dst = torch.cat([sparse[1], b, a, hub, torch.zeros_like(hub)])
+    key = torch.unique(src * n + dst)
+    return torch.stack([key // n, key % n])
+
+
+def test_a_batch_beyond_the_captured_capacity_and_a_first_long_row(cuda, monkeypatch):
+    """(a) a later batch of a captured size whose nnz exceeds StaticCSR.cap (the fixed-capacity arrays the
+    captured SpMM launches read) is a new capture, not a truncated graph; (b) a batch with a row of thousands of entries
+    after a capture that was made without the long-row path (graphed._long_bound: the first batches had no such row) stays
+    correct — the captured row kernel handles any row length.  Every step against the all-eager run: (a) bit for bit, (b)
+    within fp32 summation-order noise (the eager run reduces the hub row through the long-row queue)."""
+    from sgformer_amd import batching, graphed, ops, synth
+    from sgformer_amd.ours import SGFormer
+    n, f, c, d, m = 40000, 100, 47, 64, 8192
+    ei = _two_region_graph(n, 8192, 4)
+    gen = torch.Generator().manual_seed(9)
+    tail = torch.arange(12000, n)
+    batches = [tail[torch.randperm(tail.numel(), generator=gen)[:m]] for _ in range(3)]            # sparse, no hub: the capture
+    batches.append(torch.arange(m))                                                                 # dense block + the hub row
+    batches.append(tail[torch.randperm(tail.numel(), generator=gen)[:m]])                          # and back
+    mix = torch.cat([torch.arange(0, 6100), tail[torch.randperm(tail.numel(), generator=gen)[:m - 6100]]])
+    batches.append(mix)                                                                             # hub row, modest nnz
+    x = torch.randn(n, f, generator=gen).to(cuda)
+
+    def run(graphs: bool):
+        monkeypatch.setenv("SGF_BATCH_GRAPH", "1" if graphs else "0")
+        batching._parents.clear()
+        torch.manual_seed(3)
+        model = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, **synth.RECIPES["ogbn-products"]).to(cuda).train()   # fp32
+        before = dict(graphed.counters)
+        outs, info = [], []
+        for idx in batches:
+            ei_i, _ = batching.subgraph(idx, ei, num_nodes=n, relabel_nodes=True)
+            model.zero_grad()
+            out = model(x[idx.to(cuda)], ei_i)
+            out.float().sum().backward()
+            outs.append(out.detach().float().clone())
+            info.append((int(ei_i.shape[1]), int(getattr(ei_i, "_sgf_max_in_degree", 0))))
+        used = {k: graphed.counters[k] - before[k] for k in before}
+        ops.graph_cache.clear()
+        return outs, used, info
+
+    eager, _, info = run(False)
+    graph, used, _ = run(True)
+    nnz = [i[0] for i in info]
+    assert nnz[3] > 1.25 * max(nnz[:3]) + 4096, nnz             # the dense batch does not fit the first capture's arrays
+    assert info[3][1] > ops.LONG_ROW and info[5][1] > ops.LONG_ROW and max(i[1] for i in info[:3]) <= ops.LONG_ROW, info
+    assert nnz[5] <= 1.25 * nnz[3] + 4096                        # the mixed batch fits the SECOND capture's arrays: a replay
+    assert used["captures"] == 2 and used["replays"] == 5, used
+    for i in (0, 1, 2, 4):                                       # same kernels, same order: bit-identical
+        assert torch.equal(eager[i], graph[i]), i
+    for i in (3, 5):                                             # the hub row: long-row queue (eager) vs row kernel (captured)
+        scale = float(eager[i].abs().max())
+        assert float((eager[i] - graph[i]).abs().max()) <= 2e-5 * max(1.0, scale), i

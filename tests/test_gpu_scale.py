@@ -429,3 +429,57 @@ def test_bf16_training_trajectory_tracks_fp32(cuda):
     assert curves["fp32"][-1] < 0.8 * curves["fp32"][0] and curves["bf16"][-1] < 0.8 * curves["bf16"][0], report
     for a, b in zip(curves["bf16"], curves["fp32"]):
         assert abs(a - b) <= 1e-2 * abs(b), report
+
+
+def test_bf16_training_trajectory_100_steps_with_adam_state(cuda):
+    """the trajectory test at 100 Adam steps (large/main.py:125-143's loop: zero_grad, forward, the three
+    loss lines, backward, the two-group Adam step), bf16 mode against fp32 mode of the same module from the same initial
+    parameters, and the OPTIMIZER STATE compared at the end: the first moments of every weight matrix point the same way
+    (cosine), the second moments agree in scale.  The loss curves stay together the whole way: 1 % while the loss is O(1),
+    2e-3 absolute once it has fallen below 0.2 (the bf16 run is not expected to track the fp32 run's fourth digit there)."""
+    from sgformer_amd import synth
+    from sgformer_amd.ours import SGFormer
+    cfg = dict(synth.RECIPES["ogbn-products"])
+    n, f, d, c = 30000, 100, 256, 47
+    ei = synth.synthetic_graph_community(n, 20.0, seed=3).to(cuda)
+    x, y, idx = synth.synthetic_task(n, f, c, seed=3)
+    teacher = torch.randn(f, c, generator=torch.Generator().manual_seed(1))
+    y = (x @ teacher).argmax(1)
+    x, y, idx = x.to(cuda), y.to(cuda), idx.to(cuda)
+    p = O.init_params(cfg, f, d, c, seed=2)
+    curves, moments = {}, {}
+    for tag, dtype in (("fp32", None), ("bf16", torch.bfloat16)):
+        m = SGFormer(f, d, c, trans_dropout=0.0, gnn_dropout=0.0, compute_dtype=dtype, **cfg)
+        m.load_state_dict({**m.state_dict(), **p})
+        m = m.to(cuda).train()
+        opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 1e-5}, {"params": m.params2, "weight_decay": 1e-5}],
+                               lr=0.01)
+        losses = []
+        for _ in range(100):
+            opt.zero_grad(set_to_none=True)
+            loss = O.nll_loss(m(x, ei).float(), y, idx)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves[tag] = losses
+        names = {id(prm): k for k, prm in m.named_parameters()}
+        moments[tag] = {names[id(prm)]: (st["exp_avg"].double().clone(), st["exp_avg_sq"].double().clone())
+                        for prm, st in opt.state.items()}
+    report = {"fp32": curves["fp32"][::10] + [curves["fp32"][-1]], "bf16": curves["bf16"][::10] + [curves["bf16"][-1]]}
+    worst_loss = 0.0
+    for a, b in zip(curves["bf16"], curves["fp32"]):
+        worst_loss = max(worst_loss, abs(a - b) / (1e-2 * abs(b) + 2e-3))
+    report["worst_loss_gap_over_bound"] = worst_loss
+    cos, ratio = {}, {}
+    for k, (m1, v1) in moments["fp32"].items():
+        if not k.endswith("weight") or m1.dim() != 2:
+            continue
+        m2, v2 = moments["bf16"][k]
+        cos[k] = float((m1 * m2).sum() / (m1.norm() * m2.norm()).clamp_min(1e-300))
+        ratio[k] = float(v2.sum() / v1.sum().clamp_min(1e-300))
+    report["exp_avg_cosine"], report["exp_avg_sq_ratio"] = cos, ratio
+    _report("bf16 vs fp32 trajectory, 100 Adam steps + optimizer state:", report)
+    assert curves["fp32"][-1] < 0.05 * curves["fp32"][0] and curves["bf16"][-1] < 0.05 * curves["bf16"][0], report
+    assert worst_loss <= 1.0, report
+    for k in cos:
+        assert cos[k] >= 0.5 and 0.25 <= ratio[k] <= 4.0, (k, report)

@@ -293,6 +293,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
         print(json.dumps(line), flush=True)
     if _sharded(world):
+        dist.barrier()                       # every rank is done with its collectives before any of them tears the group down
         dist.destroy_process_group()
 
 

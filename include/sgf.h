@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGF_VERSION 500 /* 0.5.0: sgf_gemm, sgf_attn_h_small_fwd / _bwd, sgf_pad_rows, sgf_attn_bwd_reduce_heads / _apply_heads, sgf_comm_*, sgf_subgraph_csr_* */
+#define SGF_VERSION 600 /* 0.6.0: sgf_gram2_bn_bwd; the node reductions (sgf_gram, sgf_gram2, sgf_gram_bn_bwd, sgf_gram_ln_bwd, sgf_attn_h_bwd_reduce_scaled) stream their tiles by LDS-DMA (csrc/gramx.hip) */
 
 #define SGF_F32 0
 #define SGF_BF16 1
@@ -623,6 +623,18 @@ int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int64_t ldg2, 
                     const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,
                     int32_t training, int32_t m, const void* b, int64_t ldb, int32_t k, int64_t n, int32_t dtype, float* c,
                     int64_t ldc, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* A GraphConv layer's BatchNorm backward AND both blocks of its weight gradient in ONE pass over (g, z) (large/ours.py:36-40,
+ * 87-93 differentiated; replaces sgf_bn_bwd_apply + sgf_gram2 — five [n, d] tensors of traffic instead of six):
+ *   dz[n, m] = sgf_bn_bwd_apply(g, z, ...)  (written: sgf_gcn_epilogue_dx2_acc reads it next),
+ *   c1[m, k] = dz^T b1, c2[m, k] = dz^T b2, colsum[m] = sum_n dz   (b1 = A x, b2 = x0: dW of W [A x | x0], db).
+ * bf16 storage, m, k multiples of 8 up to 256, n >= 16384, every tensor operand 16-byte aligned with ld % 8 == 0
+ * (sgf_gram2_bn_bwd_supported checks the sizes; a misaligned operand is SGF_E_INVALID).  workspace: sgf_gram_workspace_bytes. */
+int32_t sgf_gram2_bn_bwd_supported(int32_t m, int32_t k, int64_t n, int32_t dtype);
+int sgf_gram2_bn_bwd(const void* g, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n, int32_t training,
+                     int32_t m, const void* b1, int64_t ldb1, const void* b2, int64_t ldb2, int32_t k, int64_t n, int32_t dtype,
+                     void* dz, int64_t lddz, float* c1, int64_t ldc1, float* c2, int64_t ldc2, float* colsum, void* workspace,
+                     size_t workspace_bytes, void* stream);
 int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int32_t relu,
                      const float* stats, float inv_n, int32_t training, int64_t n, int32_t d,
@@ -659,6 +671,13 @@ int sgf_combine_fc_fwd_mapped(const void* x1, int64_t ld1, float a, const void* 
 int sgf_combine_fc_bwd_mapped(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d, int32_t classes,
                               float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2, int64_t ld2,
                               const int32_t* row_map, void* stream);
+/* sgf_combine_fc_bwd / _bwd_mapped (row_map may be null) that also leaves the logits' gradient in the storage dtype:
+ * g_out[n, 16 ceil(classes / 16)] bf16, zero-padded, in the module's row order (row j = row row_map[j] of dlogits) — the operand
+ * of dW = a g^T x1 + b g^T x2 (sgf_gram) — written from the matrix-core fragments the kernel holds anyway instead of by a
+ * cast and a pad pass over dlogits.  bf16 storage, classes <= 64; g_out 16-byte aligned, ldg % 8 == 0. */
+int sgf_combine_fc_bwd_g(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d, int32_t classes, float a,
+                         float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2, int64_t ld2, const int32_t* row_map,
+                         void* g_out, int64_t ldg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * T6 / K8 — the dense half of a GCN layer as one streaming pass.   Replaces, for large/ours.py:36-40,87-88

@@ -19,6 +19,7 @@ from sgformer_amd import _lib, ops  # noqa: E402
 
 
 def switch(on):
+    os.environ["SGF_GRAM_BN2"] = "1"        # (opt-in in the library; the layer case of this probe times it)
     os.environ["SGF_GRAMX"] = "1" if on else "0"
     _lib.load().sgf_reload_env()
 
@@ -53,6 +54,7 @@ def main():
     rowscal = torch.rand(n, 2, generator=g).to(dev)
     dw = torch.empty(d, 2 * d, device=dev)
     xf = act(104)
+    xs2 = act()
     mean, rstd = torch.randn(d, generator=g).to(dev) * 0.1, (1.0 + torch.rand(d, generator=g)).to(dev)
     gamma, beta = (1.0 + 0.1 * torch.randn(d, generator=g)).to(dev), (0.1 * torch.randn(d, generator=g)).to(dev)
     stats = torch.randn(2 * d, generator=g).to(dev)
@@ -66,14 +68,23 @@ def main():
         ("sgf_attn_h_bwd_reduce_scaled", 2 * T + n * 8, lambda: K.attn_h_bwd_reduce_scaled(h, gy, rowscal)),
         ("sgf_gram_bn_bwd (g1, g2, z; x[n,104])", 3 * T + n * 208, lambda: K.gram_bn_bwd(h, gy, x0, mean, rstd, gamma, beta, True, stats, 1.0 / n, True, xf)),
         ("sgf_gram_ln_bwd (g, hpre; x[n,104])", 2 * T + n * 216, lambda: K.gram_ln_bwd(gy, h, rmean, rrstd, gamma, beta, True, xf)),
+        ("bn_bwd_apply + gram2 | sgf_gram2_bn_bwd (g, z; y, x0)", 6 * T, None),
         ("copy (yardstick)", 2 * T, lambda: h.clone()),
     ]
+    lstats = K.bn_bwd_stats(gy, h, mean, rstd, gamma, beta, True)
+
+    def layer_old():
+        dzz = K.bn_bwd_apply(gy, h, mean, rstd, gamma, beta, True, lstats, 1.0 / n, True)
+        K.gram2(dzz, x0, xs2, dw[:, :d], dw[:, d:])
+
+    def layer_new():
+        K.gram2_bn_bwd(gy, h, mean, rstd, gamma, beta, True, lstats, 1.0 / n, True, x0, xs2, dw[:, :d], dw[:, d:])
     for name, nbytes, fn in cases:
         res = {"old": [], "new": []}
         for _ in range(args.rounds):
             for arm in ("old", "new"):
-                switch(arm == "new")
-                res[arm].append(timed(fn))
+                switch(arm == "new" or fn is None)       # (the layer case: both arms on the DMA kernels, fused vs two launches)
+                res[arm].append(timed(fn if fn is not None else (layer_new if arm == "new" else layer_old)))
         row = {"n": n, "d": d, "case": name, "algorithmic_GB": round(nbytes / 1e9, 3)}
         for arm in ("old", "new"):
             ms = sorted(res[arm])[len(res[arm]) // 2]

@@ -136,6 +136,10 @@ SIGNATURES = {
     "sgf_gram_bn_bwd_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "sgf_gram_bn_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float, c_int32,
                                   c_int32, _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P, _P, c_size_t, _P]),
+    "sgf_gram2_bn_bwd_supported": (c_int32, [c_int32, c_int32, c_int64, c_int32]),
+    "sgf_gram2_bn_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float, c_int32, c_int32, _P, c_int64,
+                                   _P, c_int64, c_int32, c_int64, c_int32, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
+                                   c_size_t, _P]),
     "sgf_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int32, _P, c_float,
                                    c_int32, c_int64, c_int32, c_int32, _P, c_int64, _P]),
     "sgf_dropout": (c_int32, [_P, c_int64, _P, c_int64, c_float, c_uint64, c_int64, c_int32, c_int32, _P,
@@ -154,6 +158,8 @@ SIGNATURES = {
                                      c_int64, _P, c_int64, _P]),
     "sgf_combine_fc_fwd_mapped": (c_int32, [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_int32, c_int32,
                                      c_int32, _P, c_int64, _P, _P]),
+    "sgf_combine_fc_bwd_g": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P, c_int64, _P,
+                                       c_int64, _P, _P, c_int64, _P]),
     "sgf_combine_fc_bwd_mapped": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int32, c_float, c_float, c_int32, _P,
                                      c_int64, _P, c_int64, _P, _P]),
     "sgf_gcn_epilogue_supported": (c_int32, [c_int32, c_int32, c_int32]),

@@ -1570,6 +1570,40 @@ extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, 
   return SGF_OK;
 }
 
+extern "C" int32_t sgf_gram2_bn_bwd_supported(int32_t m, int32_t k, int64_t n, int32_t dtype) {
+  return dtype == SGF_BF16 && gramb2_supported(m, k, n) ? 1 : 0;
+}
+
+extern "C" int sgf_gram2_bn_bwd(const void* g, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, int32_t relu, const float* stats, float inv_n,
+                                int32_t training, int32_t m, const void* b1, int64_t ldb1, const void* b2, int64_t ldb2, int32_t k,
+                                int64_t n, int32_t dtype, void* dz, int64_t lddz, float* c1, int64_t ldc1, float* c2, int64_t ldc2,
+                                float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* fn = "sgf_gram2_bn_bwd";
+  SGF_REQUIRE(sgf_gram2_bn_bwd_supported(m, k, n, dtype), SGF_E_UNSUPPORTED,
+              "%s: bf16 storage, m and k multiples of 8 up to 256, n >= 16384 (m=%d k=%d n=%lld dtype=%d)", fn, m, k,
+              static_cast<long long>(n), dtype);
+  SGF_REQUIRE(g && z && b1 && b2 && dz && c1 && c2 && mean && rstd && (!training || stats), SGF_E_INVALID, "%s: null pointer", fn);
+  SGF_REQUIRE(ldc1 >= k && ldc2 >= k && lddz >= m, SGF_E_INVALID, "%s: ldc < k or lddz < m", fn);
+  SGF_REQUIRE(gramt_aligned(g, ldg) && gramt_aligned(z, ldz) && gramt_aligned(b1, ldb1) && gramt_aligned(b2, ldb2) &&
+                  gramt_aligned(dz, lddz),
+              SGF_E_INVALID, "%s: operands must be 16-byte aligned with ld %% 8 == 0", fn);
+  SGF_REQUIRE(workspace && workspace_bytes >= sgf_gram_workspace_bytes(n, m, k), SGF_E_WORKSPACE, "%s: workspace too small", fn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int np = 0;
+  float* part = static_cast<float*>(workspace);
+  int rc = gramb2(g, ldg, z, ldz, mean, rstd, gamma, beta, relu, stats, inv_n, training, m, b1, ldb1, b2, ldb2, k, n, dz, lddz,
+                  part, &np, st);
+  if (rc != SGF_OK) return rc;
+  const int64_t len = static_cast<int64_t>(m) * k + m;
+  const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+  hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part, np, m, k, 256, 1, c1, ldc1, colsum);
+  hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part + static_cast<int64_t>(np) * kPartialStride, np, m, k, 256,
+                     1, c2, ldc2, static_cast<float*>(nullptr));
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
 extern "C" size_t sgf_gram_workspace_bytes(int64_t n, int32_t m, int32_t k) {
   (void)n; (void)m; (void)k;
   return static_cast<size_t>(kMaxBlocks) * kPartialStride * sizeof(float);

@@ -618,6 +618,216 @@ __global__ __launch_bounds__(kGxThreads) void k_gramt(GramtArgs p) {
   if (tid == 0) part[kRedTileElems + 256] = part[kRedTileElems + 257] = 0.f;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gramb2: a GraphConv layer's BatchNorm backward AND its weight gradients in one pass over (g, z) — replaces
+// sgf_bn_bwd_apply (reads g, z, writes dz) + sgf_gram2 (reads dz, y, x0): dz = BatchNorm'(relu'(g)) is formed in LDS as in
+// k_gramt<BN>, stored to HBM on the way (sgf_gcn_epilogue_dx2_acc needs it next) and multiplied with y (role 0) / x0 (role 1)
+// from the LDS image: 5 [n, d] tensors of traffic instead of 6, one launch instead of two.  Paired as k_gramx: blocks b and
+// b + 8 (one XCD) walk the same stages; both form dz (role 1 reads g, z through the XCD's L2), role 0 stores it.
+// Ring of 3 stages x 48 KiB (g, z row-major + the role's B image) + the A image = all 160 KiB of the CU's LDS.
+// ------------------------------------------------------------------------------------------------------------------------
+struct Gramb2Args {
+  const void *g, *z, *b, *b2;
+  void* dz;
+  int64_t ldg, ldz, ldb, ldb2, lddz;
+  int64_t n;
+  int32_t m, k;                  // columns of g / z / dz, columns of b / b2
+  const float *mean, *rstd, *gamma, *beta, *stats;
+  float inv_n;
+  int32_t training, relu;
+  float* partial;
+};
+
+__global__ __launch_bounds__(kGxThreads) void k_gramb2(Gramb2Args p) {
+  constexpr int NST = 3;
+  constexpr int kStage = 3 * kGxOpBytes;                           // g, z (row-major), B image
+  constexpr int kAimg = NST * kStage;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kAimg + kGxOpBytes];     // 160 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wd = wave & 1;
+  const int cg = lane & 31;
+  const int hw = lane >> 5;
+  const bool col_ok = 8 * cg < p.m;
+  const int role = (blockIdx.x >> 3) & 1;
+  const int64_t vblock = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);
+  const int64_t vgrid = gridDim.x / 2;
+
+  const int64_t total = (p.n + kGxRows - 1) / kGxRows;
+  const int nq = vblock < total ? static_cast<int>((total - vblock + vgrid - 1) / vgrid) : 0;
+  const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(SGF_LDS(unsigned char, smem)));
+
+  const unsigned char* gg = static_cast<const unsigned char*>(p.g);
+  const unsigned char* gz = static_cast<const unsigned char*>(p.z);
+  const unsigned char* gb = static_cast<const unsigned char*>(role ? p.b2 : p.b);
+  const int64_t pitch_g = p.ldg * 2, pitch_z = p.ldz * 2, pitch_b = (role ? p.ldb2 : p.ldb) * 2, pitch_dz = p.lddz * 2;
+  const int rcol = (col_ok ? 8 * cg : p.m - 8) * 2;
+  const int brow = 16 * (wave >> 2) + 4 * ((wave >> 1) & 1) + 8 * ((lane >> 4) & 1) + ((lane >> 1) & 3);
+  int bcol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = 64 * (2 * (wave & 1) + j) + 32 * (lane >> 5) + 16 * ((lane >> 3) & 1) + 8 * (lane & 1);
+    bcol[j] = c + 8 <= p.k ? c : p.k - 8;
+  }
+
+  auto issue = [&](int q) {
+    const int64_t row0 = (vblock + static_cast<int64_t>(q) * vgrid) * kGxRows;
+    const uint32_t base = smem_lds + static_cast<uint32_t>((q % NST) * kStage);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int64_t r = row0 + 4 * wave + 2 * j + hw;
+      r = r < p.n ? r : p.n - 1;
+      dma16(gg + r * pitch_g + rcol, base + (2 * wave + j) * 1024);
+      dma16(gz + r * pitch_z + rcol, base + kGxOpBytes + (2 * wave + j) * 1024);
+    }
+    int64_t r = row0 + brow;
+    r = r < p.n ? r : p.n - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(gb + r * pitch_b + bcol[j] * 2, base + 2 * kGxOpBytes + (2 * wave + j) * 1024);
+  };
+
+  float bmu[8], brs[8], bga[8], bbe[8], bk0[8], bk1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * cg + e;
+    const bool ok = c < p.m;
+    bga[e] = ok ? (p.gamma ? p.gamma[c] : 1.f) : 0.f;
+    bbe[e] = ok ? (p.beta ? p.beta[c] : 0.f) : 0.f;
+    bmu[e] = ok ? p.mean[c] : 0.f;
+    brs[e] = ok ? p.rstd[c] : 0.f;
+    bk0[e] = (ok && p.training) ? p.stats[c] * p.inv_n : 0.f;
+    bk1[e] = (ok && p.training) ? p.stats[p.m + c] * p.inv_n : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)        // consumed here: hipcc's wait for these loads must not land inside the stage loop
+    asm volatile("" : "+v"(bga[e]), "+v"(bbe[e]), "+v"(bmu[e]), "+v"(brs[e]), "+v"(bk0[e]), "+v"(bk1[e]));
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csa[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csa[e] = 0.f;
+  const int nta = p.m - 64 * wm <= 0 ? 0 : (p.m - 64 * wm > 32 ? 2 : 1);
+  const int ntb = p.k - 128 * wd <= 0 ? 0 : ((p.k - 128 * wd + 31) / 32 > 4 ? 4 : (p.k - 128 * wd + 31) / 32);
+  const bool act = nta > 0 && ntb > 0;
+
+#pragma unroll 1
+  for (int q = 0; q < NST - 1 && q < nq; ++q) issue(q);
+
+#pragma unroll 1
+  for (int q = 0; q < nq; ++q) {
+    // issued after stage q's requests: [stores of q - 2] [requests of q + 1] [stores of q - 1]; at the tail everything is waited for
+    if (q + 1 < nq) wait_vm(role == 0 ? (q >= 2 ? 10 : (q == 1 ? 8 : 6)) : 6);
+    else wait_vm(0);
+    __syncthreads();
+    if (q + NST - 1 < nq) issue(q + NST - 1);
+    unsigned char* st = smem + (q % NST) * kStage;
+    const int64_t row0 = (vblock + static_cast<int64_t>(q) * vgrid) * kGxRows;
+    const int valid = p.n - row0 < kGxRows ? static_cast<int>(p.n - row0) : kGxRows;
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = 4 * wave + 2 * j + hw;
+      const bool rok = rr < valid;
+      const int slot = (2 * wave + j) * 1024 + lane * 16;
+      const uint4 v0 = *reinterpret_cast<const uint4*>(st + slot);
+      const uint4 v2 = *reinterpret_cast<const uint4*>(st + kGxOpBytes + slot);
+      const uint32_t u0[4] = {v0.x, v0.y, v0.z, v0.w}, u2[4] = {v2.x, v2.y, v2.z, v2.w};
+      float dv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                     // sgf_bn_bwd_apply's arithmetic
+        const float gval = (e & 1) ? bf_hi(u0[e >> 1]) : bf_lo(u0[e >> 1]);
+        const float zval = (e & 1) ? bf_hi(u2[e >> 1]) : bf_lo(u2[e >> 1]);
+        const float xh = (zval - bmu[e]) * brs[e];
+        float gm = gval;
+        if (p.relu) gm = (xh * bga[e] + bbe[e]) > 0.f ? gm : 0.f;
+        gm -= bk0[e] + xh * bk1[e];
+        dv[e] = rok ? bga[e] * brs[e] * gm : 0.f;
+      }
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = pack_bf16(dv[2 * e], dv[2 * e + 1]);
+        csa[2 * e] += bf_lo(o[e]);
+        csa[2 * e + 1] += bf_hi(o[e]);
+      }
+      const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+      if (role == 0 && rok && col_ok)
+        *reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.dz) + (row0 + rr) * pitch_dz + 16 * cg) = ov;
+      const int r16 = rr & 15;
+      const int unit = (2 * (rr >> 4) + ((r16 >> 2) & 1)) * 8 + (cg >> 2);
+      const int u = 16 * (r16 >> 3) + 8 * ((cg >> 1) & 1) + 2 * (r16 & 3) + (cg & 1);
+      *reinterpret_cast<uint4*>(smem + kAimg + unit * 512 + u * 16) = ov;
+    }
+    __syncthreads();
+
+    if (act) {
+      const unsigned char* sa = smem + kAimg;
+      const unsigned char* sb = st + 2 * kGxOpBytes;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[2], bfr[4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const unsigned char* u = sa + ((2 * s) * 8 + 2 * wm + tm) * 512 + lane * 8;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u + 8 * 512));
+          af[tm][0] = r0[0]; af[tm][1] = r0[1]; af[tm][2] = r0[2]; af[tm][3] = r0[3];
+          af[tm][4] = r1[0]; af[tm][5] = r1[1]; af[tm][6] = r1[2]; af[tm][7] = r1[3];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          const unsigned char* u = sb + ((2 * s) * 8 + 4 * wd + tn) * 512 + lane * 8;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SGF_LDS(s16x4, u + 8 * 512));
+          bfr[tn][0] = r0[0]; bfr[tn][1] = r0[1]; bfr[tn][2] = r0[2]; bfr[tn][3] = r0[3];
+          bfr[tn][4] = r1[0]; bfr[tn][5] = r1[1]; bfr[tn][6] = r1[2]; bfr[tn][7] = r1[3];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          if (tn < ntb) {
+            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[tn], acc[0][tn], 0, 0, 0);
+            if (nta > 1) acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[tn], acc[1][tn], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  float* part = p.partial + (role * vgrid + vblock) * kRedPartialStride;
+  if (act) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          part[(64 * wm + 32 * tm + mfma32_row(r, lane)) * 256 + 128 * wd + 32 * tn + (lane & 31)] = acc[tm][tn][r];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* fl = reinterpret_cast<float*>(smem);
+  const int ridx = 2 * wave + hw;
+  *reinterpret_cast<float4*>(&fl[ridx * 256 + 8 * cg]) = make_float4(csa[0], csa[1], csa[2], csa[3]);
+  *reinterpret_cast<float4*>(&fl[ridx * 256 + 8 * cg + 4]) = make_float4(csa[4], csa[5], csa[6], csa[7]);
+  __syncthreads();
+  if (tid < 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += fl[r * 256 + tid];
+    part[kRedTileElems + tid] = s;
+  }
+  if (tid == 0) part[kRedTileElems + 256] = part[kRedTileElems + 257] = 0.f;
+}
+
 bool aligned16(const void* p, int64_t ld) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 8 == 0; }
 
 }  // namespace
@@ -693,6 +903,33 @@ int gramt_ln(const void* g, int64_t ldg, const void* xin, int64_t ldx, const flo
   const int grid = static_cast<int>(total < kRedMaxBlocks ? total : kRedMaxBlocks);
   *nblk = grid;
   hipLaunchKernelGGL((k_gramt<kGtLN>), dim3(grid), dim3(kGxThreads), 0, st, a);
+  SGF_LAUNCH_CHECK();
+  return SGF_OK;
+}
+
+bool gramb2_supported(int m, int k, int64_t n) {
+  static EnvInt on{"SGF_GRAMX", 1};
+  // OPT-IN (SGF_GRAM_BN2=1).  Measured on MI355X, products size (scripts/gramx_probe.py): sgf_bn_bwd_apply + sgf_gram2 1.519 ms,
+  // this kernel 1.512 ms — level.  The 256 x 512 fp32 result needs two CUs' register files, so the pair fetches (g, z) twice:
+  // unless the partner's copy is still in the XCD's L2 the launch moves 7 [n, d] tensors, not 5, and it runs at the
+  // fabric's rate on those (5.8 TB/s).  Kept: correct (tests/test_gpu_gramx.py), one launch less, and the shape to start from
+  // if the pair is ever made to run in step.
+  static EnvInt fuse{"SGF_GRAM_BN2", 0};
+  return on.get() != 0 && fuse.get() != 0 && m >= 8 && m <= 256 && m % 8 == 0 && k >= 8 && k <= 256 && k % 8 == 0 && n >= 16384;
+}
+
+int gramb2(const void* g, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd, const float* gamma,
+           const float* beta, int relu, const float* stats, float inv_n, int training, int m, const void* b1, int64_t ldb1,
+           const void* b2, int64_t ldb2, int k, int64_t n, void* dz, int64_t lddz, float* partial, int* nblk, hipStream_t st) {
+  const int64_t total = (n + kGxRows - 1) / kGxRows;
+  int64_t pairs = total / 2 < kRedMaxBlocks / 2 ? total / 2 : kRedMaxBlocks / 2;
+  pairs = pairs / 8 * 8;                                 // whole groups of 8 pairs (n >= 16384: >= 128)
+  Gramb2Args a{};
+  a.g = g; a.ldg = ldg; a.z = z; a.ldz = ldz; a.b = b1; a.ldb = ldb1; a.b2 = b2; a.ldb2 = ldb2; a.dz = dz; a.lddz = lddz;
+  a.n = n; a.m = m; a.k = k; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.stats = stats; a.inv_n = inv_n;
+  a.training = training; a.relu = relu; a.partial = partial;
+  *nblk = static_cast<int>(pairs);
+  hipLaunchKernelGGL(k_gramb2, dim3(static_cast<unsigned>(2 * pairs)), dim3(kGxThreads), 0, st, a);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
 }

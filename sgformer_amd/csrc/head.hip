@@ -139,7 +139,8 @@ constexpr int kHeadBwdThreads = 512;             // 8 waves, one 32-node tile ea
 template <int DP>
 __global__ __launch_bounds__(kHeadBwdThreads) void k_head_bwd_bf16(
     const float* __restrict__ dl, int64_t lddl, const float* __restrict__ w, int64_t n, int d, int c, float a, float b,
-    uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2, const int32_t* __restrict__ rmap) {
+    uint16_t* __restrict__ dx1, int64_t ld1, uint16_t* __restrict__ dx2, int64_t ld2, const int32_t* __restrict__ rmap,
+    uint16_t* __restrict__ gout, int64_t ldgo) {
   constexpr int PITCH = kMaxClasses + 8;           // bf16 elements per LDS row of W^T (+16 B)
   constexpr int HW = DP >= 128 ? DP / 2 : DP;      // features per pass: the tile leaves in two column halves
   constexpr int NH = DP / HW;                      // passes
@@ -193,6 +194,14 @@ __global__ __launch_bounds__(kHeadBwdThreads) void k_head_bwd_bf16(
   if (tile < ntiles) load_frags(tile, cur);
   for (; tile < ntiles; tile += step) {
     if (tile + step < ntiles) load_frags(tile + step, nxt);        // in flight while this tile is multiplied and stored
+    if (gout != nullptr && tile * 32 + i31 < n) {
+      // the logits' gradient in the storage dtype, zero-padded to 16 ks classes, in the MODULE's row order: the operand the
+      // weight gradient's node reduction (sgf_gram) reads — straight from the A fragments (lane = node, 8 classes each)
+      // instead of a cast and a pad pass over dlogits
+#pragma unroll
+      for (int s = 0; s < KSMAX; ++s)
+        if (s < ks) *reinterpret_cast<uint4*>(gout + (tile * 32 + i31) * ldgo + 16 * s + 8 * hi) = cur[s].u;
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       if (HW * h >= d) break;
@@ -342,7 +351,7 @@ extern "C" int sgf_combine_fc_fwd_mapped(const void* x1, int64_t ld1, float a, c
 
 static int combine_fc_bwd_impl(const char* fn, const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d,
                                int32_t classes, float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2,
-                               int64_t ld2, const int32_t* rmap, void* stream) {
+                               int64_t ld2, const int32_t* rmap, void* stream, void* gout = nullptr, int64_t ldgo = 0) {
   int rc = check_head(fn, n, d, classes, dtype);
   if (rc != SGF_OK) return rc;
   if (n == 0) return SGF_OK;
@@ -369,7 +378,8 @@ static int combine_fc_bwd_impl(const char* fn, const float* dlogits, int64_t ldd
   const dim3 grid(static_cast<unsigned>(nb)), block(kHeadBwdThreads);
 #define SGF_HEAD_BWD(DP_)                                                                                   \
   hipLaunchKernelGGL((k_head_bwd_bf16<DP_>), grid, block, 0, st, dlogits, lddl, w, n, d, classes, a, b,       \
-                     static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2, rmap)
+                     static_cast<uint16_t*>(dx1), ld1, static_cast<uint16_t*>(dx2), ld2, rmap,                \
+                     static_cast<uint16_t*>(gout), ldgo)
   if (d <= 64) SGF_HEAD_BWD(64);
   else if (d <= 128) SGF_HEAD_BWD(128);
   else SGF_HEAD_BWD(256);
@@ -383,6 +393,19 @@ extern "C" int sgf_combine_fc_bwd(const float* dlogits, int64_t lddl, const floa
                                   void* dx2, int64_t ld2, void* stream) {
   return combine_fc_bwd_impl("sgf_combine_fc_bwd", dlogits, lddl, w, n, d, classes, a, b, dtype, dx1, ld1, dx2, ld2, nullptr,
                              stream);
+}
+
+// the same (row_map may be null) that ALSO leaves the logits' gradient in the storage dtype: g_out[n, 16 ceil(classes / 16)]
+// (zero-padded, the module's row order) for the weight gradient's node reductions — bf16 storage, classes <= 64
+extern "C" int sgf_combine_fc_bwd_g(const float* dlogits, int64_t lddl, const float* w, int64_t n, int32_t d, int32_t classes,
+                                    float a, float b, int32_t dtype, void* dx1, int64_t ld1, void* dx2, int64_t ld2,
+                                    const int32_t* row_map, void* g_out, int64_t ldg, void* stream) {
+  const char* fn = "sgf_combine_fc_bwd_g";
+  SGF_REQUIRE(dtype == SGF_BF16 && classes >= 1 && classes <= kMaxClasses, SGF_E_UNSUPPORTED,
+              "%s: bf16 storage and at most %d classes", fn, kMaxClasses);
+  SGF_REQUIRE(n == 0 || (g_out && ldg >= (classes + 15) / 16 * 16 && ldg % 8 == 0 && reinterpret_cast<uintptr_t>(g_out) % 16 == 0),
+              SGF_E_INVALID, "%s: g_out must be 16-byte aligned with ldg %% 8 == 0 and ldg >= classes rounded up to 16", fn);
+  return combine_fc_bwd_impl(fn, dlogits, lddl, w, n, d, classes, a, b, dtype, dx1, ld1, dx2, ld2, row_map, stream, g_out, ldg);
 }
 
 // the same reading row row_map[j] of dlogits for row j of the gradients

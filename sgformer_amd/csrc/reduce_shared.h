@@ -35,4 +35,11 @@ int gramt_ln(const void* g, int64_t ldg, const void* xin, int64_t ldx, const flo
              const float* beta, int relu, int m, const void* b, int64_t ldb, int k, int64_t n, float* partial, int* nblk,
              hipStream_t st);
 
+// a GraphConv layer's BatchNorm backward + both weight-gradient blocks in one pass (k_gramb2): dz written to [n, m], partials
+// [role][pair]; every tensor operand 16-byte aligned with ld % 8 == 0
+bool gramb2_supported(int m, int k, int64_t n);
+int gramb2(const void* g, int64_t ldg, const void* z, int64_t ldz, const float* mean, const float* rstd, const float* gamma,
+           const float* beta, int relu, const float* stats, float inv_n, int training, int m, const void* b1, int64_t ldb1,
+           const void* b2, int64_t ldb2, int k, int64_t n, void* dz, int64_t lddz, float* partial, int* nblk, hipStream_t st);
+
 }  // namespace sgf

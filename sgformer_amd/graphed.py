@@ -43,6 +43,23 @@ from . import ops
 _F32 = torch.float32
 
 
+# Captured steps that are no longer used — a released entry (re-capture, least-recently-used size), a model that went away.
+# Their hipGraphs are NOT destroyed where Python happens to drop the last reference: on ROCm, destroying a graph (and freeing
+# its private pool) while a stream is capturing, or while another captured step is still executing, aborts the process, and
+# the cyclic collector runs at arbitrary allocations (seen as `Fatal Python error: Aborted` inside the NEXT batch's
+# `subset.to(device)`).  They wait here and are destroyed at a safe point: `collect()` — device idle, nothing capturing.
+_graveyard = []
+
+
+def collect():
+    """Destroy the captured steps nobody uses any more, with the device idle (called before every capture; a trainer that
+    wants the memory back earlier may call it between epochs)."""
+    if _graveyard and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        _graveyard.clear()
+        gc.collect()
+
+
 class _PerModel(OrderedDict):
     """{(n, f, x dtype, compute dtype, logits dtype, device): _Entry} of ONE model, kept in the module's __dict__ (so that it dies with
     the model: an entry holds the model through its captured callable, a cycle the garbage collector resolves — a global table
@@ -51,6 +68,13 @@ class _PerModel(OrderedDict):
 
     def __deepcopy__(self, memo):
         return _PerModel()
+
+    def __del__(self):                       # the model went away: its captures wait in the graveyard (see above)
+        try:
+            for e in self.values():
+                e.release()
+        except Exception:
+            pass
 
     def __reduce__(self):
         return (_PerModel, ())
@@ -120,6 +144,8 @@ class _Entry:
         return self.pending is not None and self.pending() is not None
 
     def release(self):
+        if self.core is not None:
+            _graveyard.append((self.core, self.graph))           # destroyed by collect(), not here
         self.core = self.graph = self.pending = None
         self.params, self.param_ptrs = (), None
 
@@ -132,8 +158,9 @@ def _eligible(model, x, edge_index) -> bool:
     csr = edge_index._sgf_csr
     if csr[0].numel() != x.shape[0] + 1 or csr[1].numel() != edge_index.shape[1]:
         return False          # (not the CSR of THIS call's graph: the eager path builds its own, as ops.CSRGraph decides too)
-    if not model.use_graph or model.graph_conv._shard is not None or getattr(model, "overlap_branches", False):
-        return False          # (two-stream branches inside a capture: tried in r05, does not survive hipStreamEndCapture)
+    if not model.use_graph or model.graph_conv._shard is not None:
+        return False          # (SGFormer._core keeps ONE stream while capturing: two-stream branches inside a capture do not
+                              #  survive hipStreamEndCapture, r05)
     for branch in (model.trans_conv, model.graph_conv):
         p = getattr(branch, "dropout", 1.0)        # (a branch without the attribute: unknown, stay eager)
         if p is not None and p > 0.0:
@@ -175,6 +202,7 @@ def _capture(model, entry: _Entry, x, edge_index, cdt, out_dtype):
     # Dead captures (a released entry, a model that went away) are reference cycles: the cyclic collector destroys their
     # hipGraphs at some later allocation — inside THIS capture, if it gets the chance, and destroying a graph / freeing its pool
     # while a stream is capturing crashes.  Collect them now, and keep the collector off until the capture has ended.
+    collect()
     gc.collect()
     gc_was_on = gc.isenabled()
     gc.disable()

@@ -746,6 +746,32 @@ class HipKernels:
         return out, cs
 
     @staticmethod
+    def gram2_bn_bwd_supported(g, z, b1, b2) -> bool:
+        """sgf_gram2_bn_bwd serves these operands (bf16, sizes, 16-byte aligned rows)?"""
+        n, m = z.shape
+        ok = all(t.dtype == _BF16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+                 for t in (g, z, b1, b2))
+        return (ok and b1.shape == b2.shape and g.shape == z.shape
+                and bool(_lib.load().sgf_gram2_bn_bwd_supported(int(m), int(b1.shape[1]), int(n), _lib.SGF_BF16)))
+
+    @staticmethod
+    def gram2_bn_bwd(g, z, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float, training: bool, b1, b2, out1, out2):
+        """(dz, colsum(dz)); out1 = dz^T b1, out2 = dz^T b2 (fp32, may be column slices of one matrix): the BatchNorm backward
+        and both weight-gradient blocks of a GraphConv layer from one pass over (g, z) (sgf_gram2_bn_bwd)."""
+        n, m = z.shape
+        k = b1.shape[1]
+        dev = z.device
+        dz = torch.empty((n, m), dtype=z.dtype, device=dev)
+        cs = torch.empty(m, dtype=_F32, device=dev)
+        ws = _workspace(dev, "attn", _lib.load().sgf_gram_workspace_bytes(n, m, k))
+        with torch.cuda.device(dev):
+            _lib.call("sgf_gram2_bn_bwd", _ptr(g), _ld(g), _ptr(z), _ld(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                      int(relu), _ptr(stats), float(inv_n), int(training), m, _ptr(b1), _ld(b1), _ptr(b2), _ld(b2), k, n,
+                      _code(z), _ptr(dz), dz.stride(0), _ptr(out1), out1.stride(0), _ptr(out2), out2.stride(0), _ptr(cs),
+                      _ptr(ws), ws.numel(), _stream(dev))
+        return dz, cs
+
+    @staticmethod
     def bn_bwd_apply(gy, x, mean, rstd, gamma, beta, relu: bool, stats, inv_n: float,
                      training: bool) -> torch.Tensor:
         n, d = x.shape
@@ -864,6 +890,21 @@ class HipKernels:
                           _lib.SGF_BF16, _ptr(dx1), dx1.stride(0), _ptr(dx2), dx2.stride(0), _ptr(row_map),
                           _stream(g.device))
         return dx1, dx2
+
+    @staticmethod
+    def combine_fc_bwd_g(g, w, a: float, b: float, row_map=None):
+        """(dx1, dx2, gp): combine_fc_bwd for bf16 storage and at most 64 classes that also returns gp = the logits' gradient
+        in bf16, [n, 16 ceil(c / 16)], zero-padded, in the module's row order (sgf_combine_fc_bwd_g)."""
+        n, c = g.shape
+        d = w.shape[1]
+        HipKernels._check_row_map(row_map, n, g.device)
+        dx1 = torch.empty((n, d), dtype=_BF16, device=g.device)
+        dx2 = torch.empty((n, d), dtype=_BF16, device=g.device)
+        gp = torch.empty((n, (c + 15) // 16 * 16), dtype=_BF16, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("sgf_combine_fc_bwd_g", _ptr(g), g.stride(0), _ptr(w), n, d, c, float(a), float(b), _lib.SGF_BF16, _ptr(dx1),
+                      dx1.stride(0), _ptr(dx2), dx2.stride(0), _ptr(row_map), _ptr(gp), gp.stride(0), _stream(g.device))
+        return dx1, dx2, gp
 
     @staticmethod
     def _check_row_map(row_map, n: int, device):

@@ -31,512 +31,22 @@ _F32 = torch.float32
 _BF16 = torch.bfloat16
 
 
-K = HipKernels()
-
-# Rows with more stored entries than this are reduced by whole workgroups, segment by segment
-# (sgf_spmm_split): one wave walking a 17 k-entry hub row of a power-law graph is a latency-bound tail.
-# LONG_ROW / _SEGMENT: the long-row threshold and segment length of the SpMM kernels (sgformer_amd/kernels.py)
-
-
-# Graphs with fewer stored entries than this are per-batch graphs (mini-batch trainers build one per step): their
-# long-row segment count is not read back from the device (a host sync per batch) but bounded from nnz alone.
-SMALL_GRAPH_NNZ = 1 << 23
-
-
-def long_row_segments(rowptr: torch.Tensor, nnz: Optional[int] = None, max_row_len: Optional[int] = None) -> int:
-    """sum over rows longer than LONG_ROW of ceil(len / segment): the `long_segments` argument of
-    sgf_spmm_split.  One tiny device reduction + host read per CSR (done once, when it is built) — or, for
-    small graphs whose nnz is known on the host, the bound  sum ceil(len/seg) <= nnz/seg + nnz/(LONG_ROW+1)
-    without any device read (0 when no row can be long at all).  `max_row_len`: a bound on the longest row the caller
-    GUARANTEES without looking (a sampled batch: its largest fan-out; NOT the node count — duplicate edges are kept) — at most LONG_ROW means no
-    split path at all (no memset, no extra launches) for that CSR."""
-    if rowptr.numel() <= 1:
-        return 0
-    if max_row_len is not None and max_row_len <= LONG_ROW:
-        return 0
-    if nnz is not None and nnz < SMALL_GRAPH_NNZ:
-        return 0 if nnz <= LONG_ROW else nnz // _SEGMENT + nnz // (LONG_ROW + 1) + 1
-    lens = rowptr[1:] - rowptr[:-1]
-    segs = torch.where(lens > LONG_ROW, (lens + (_SEGMENT - 1)) // _SEGMENT, torch.zeros_like(lens))
-    return int(segs.sum())
+from . import graph as _graph
+from .graph import *  # noqa: F401,F403,E402
+from .graph import K, graph_cache, _own_block_spmm, _sharded_spmm, _tile_params, _block_shape, _mode  # noqa: F401,E402
 
 
 def set_kernels(table):
     """Install a kernel table (tests only; see module docstring).  Returns the previous one."""
     global K
     prev, K = K, table
+    _graph.K = _linear.K = table             # ONE table: graph.py and linear.py look theirs up by the same name
     graph_cache.clear()
     return prev
 
 
 def _require_cuda(*tensors):
     K.check(*tensors)
-
-
-# ------------------------------------------------------------------------------------------------
-# T1: cached CSR of the normalised adjacency (large/ours.py:26-33)
-# ------------------------------------------------------------------------------------------------
-class CSRGraph:
-    """rowptr/colind/val of A = D^-1/2 (edge_index^T) D^-1/2 on the GPU, built by sgf_csr_build.
-
-    The reference rebuilds this (degree + argsort over nnz) in every layer of every forward;
-    here it is built once per `edge_index` and reused by all layers and by the backward.
-    """
-
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, validate: bool = True):
-        K.check(edge_index)
-        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
-            raise ValueError("edge_index must be an int64 tensor of shape [2, nnz]")
-        if num_nodes >= 2 ** 31:
-            raise ValueError("num_nodes must be < 2^31 (int32 column indices)")
-        ei = edge_index.contiguous()
-        n = int(num_nodes)
-        if getattr(edge_index, "_sgf_trusted", False):
-            validate = False      # produced by batching.subgraph / graph_prologue: ids are in range by construction
-        if validate and ei.shape[1] > 0:
-            lo, hi = torch.aminmax(ei)
-            if int(lo) < 0 or int(hi) >= n:
-                raise IndexError(f"edge_index has node ids outside [0, {n})")
-        self.n, self.nnz, self.device = n, int(ei.shape[1]), ei.device
-        self.edge_index = ei
-        pre = getattr(edge_index, "_sgf_csr", None)
-        if pre is not None and pre[0].numel() == n + 1 and pre[1].numel() == self.nnz:
-            # the producer of this edge list (batching.subgraph on the parent's CSR: sgf_subgraph_csr_*) built the normalised
-            # CSR in the same pass — bit for bit what sgf_csr_build would return for it (tests/test_gpu_r05.py)
-            self.rowptr, self.colind, self.val, self.deg = pre
-        else:
-            self.rowptr, self.colind, self.val, self.deg = K.csr_build(ei, n)
-        # longest possible row: only a bound the caller GUARANTEES (sampling.NeighborSampler marks its batches with their
-        # largest fan-out).  The node count is no bound: sgf_csr_build keeps duplicate edges (large/ours.py:33 does not
-        # coalesce), so a row of a small multigraph can exceed LONG_ROW entries (ADVICE r04) — without a hint the nnz-based
-        # bound (small graphs) or the exact count from rowptr applies.
-        hint = getattr(edge_index, "_sgf_max_in_degree", None)
-        self.long_segments = long_row_segments(self.rowptr, self.nnz, None if hint is None else int(hint))
-        self.t_long_segments = 0
-        self._t = None  # (rowptr, colind, val) of A^T, built on first backward
-        self.symmetric: Optional[bool] = None
-        if getattr(edge_index, "_sgf_symmetric", False):
-            # an induced subgraph of a graph whose A^T == A was verified once (batching.subgraph): symmetric by construction —
-            # no second sort, no comparison pass and no host read per batch in the first backward
-            self.symmetric, self._t, self.t_long_segments = True, (self.rowptr, self.colind, self.val), self.long_segments
-
-    def transposed(self):
-        """CSR of A^T for dX = A^T dY; the same arrays when A is symmetric."""
-        if self._t is None:
-            t_rowptr, t_colind, t_val, sym = K.csr_transpose(self.edge_index, self.n, self.deg,
-                                                             self.rowptr, self.colind)
-            self.symmetric = sym
-            self._t = (self.rowptr, self.colind, self.val) if sym else (t_rowptr, t_colind, t_val)
-            self.t_long_segments = self.long_segments if sym else long_row_segments(t_rowptr, self.nnz)
-        return self._t
-
-    # ---- LDS-staged row-block SpMM: one plan per (orientation, storage dtype) ----
-    blocked = False          # set by GraphView when the plan serves enough entries from LDS
-
-    def plan(self, dtype, transposed: bool = False):
-        """BlockedPlan for SpMMs with `dtype` storage on this CSR (or its transpose), or None."""
-        if not self.blocked:
-            return None
-        if not hasattr(self, "_plans"):
-            self._plans = {}
-        if transposed:
-            self.transposed()
-            if self.symmetric:
-                transposed = False
-        key = (bool(transposed), dtype)
-        if key not in self._plans:
-            rp, ci, va = self.transposed() if transposed else (self.rowptr, self.colind, self.val)
-            self._plans[key] = BlockedPlan(rp, ci, va, self.n, dtype)
-        return self._plans[key]
-
-    # ---- dense matrix-core tiles + gather remainder (sgf_spmm_tile): one plan per orientation ----
-    tiled = False            # set by GraphView when the tile plan covers enough of the stored entries
-    blk_row = None           # int32 [nb + 1] row blocks that follow the communities (GraphView)
-
-    def tile_plan(self, transposed: bool = False):
-        if not hasattr(self, "_tile_plans"):
-            self._tile_plans = {}
-        if transposed:
-            self.transposed()
-            if self.symmetric:
-                transposed = False
-        if transposed not in self._tile_plans:
-            rp, ci, va = self.transposed() if transposed else (self.rowptr, self.colind, self.val)
-            self._tile_plans[transposed] = TilePlan(rp, ci, va, self.n, self.blk_row,
-                                                   min_count=getattr(self, "tile_min_count", None))
-        return self._tile_plans[transposed]
-
-    def view(self, now: bool = False) -> "GraphView":
-        """How the model should run on this graph: the graph itself, or a re-ordered copy + the row
-        permutation to apply at the module boundary (decided once; see GraphView).  now=True: decide
-        at this call instead of waiting for the second forward."""
-        self.forward_calls = getattr(self, "forward_calls", 0) + 1
-        v = getattr(self, "_view", None)
-        if v is None:
-            v = GraphView.decide(self, now)
-            if v is not None:
-                self._view = v
-        return v if v is not None else GraphView(self, None, None)
-
-
-class WeightedCSRGraph:
-    """CSR of A[target, source] = value_e with EXPLICIT per-edge values — the edge-weighted variants of the
-    medium recipes: GCNConv(x, edge_index, edge_weight) (medium/models.py:55-62, gcn_norm with weights) and
-    DIFFormer's gcn_conv (medium/difformer.py:63-79, value = edge_weight * d_in * d_out).  The caller computes
-    the values (one elementwise expression); entries are ordered by (target, source) like sgf_csr_build's, the
-    transpose by (source, target).  No gradient flows to the values (edge weights are data, not parameters).
-    Same interface as CSRGraph towards ops.spmm."""
-
-    blocked = False
-
-    def __init__(self, edge_index: torch.Tensor, values: torch.Tensor, num_nodes: int):
-        K.check(edge_index, values)
-        n = int(num_nodes)
-        self.n, self.nnz, self.device = n, int(edge_index.shape[1]), edge_index.device
-        self._src, self._tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
-        self._values = values.detach().to(_F32).contiguous()
-        self.rowptr, self.colind, self.val = self._sorted(self._tgt, self._src)
-        self.long_segments = long_row_segments(self.rowptr, self.nnz)
-        self._t, self.t_long_segments, self.symmetric = None, 0, False
-
-    def _sorted(self, rows, cols):
-        perm = torch.argsort(rows * self.n + cols, stable=True)
-        counts = torch.bincount(rows, minlength=self.n)
-        rowptr = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(counts, 0, out=rowptr[1:])
-        return rowptr, cols[perm].to(torch.int32), self._values[perm]
-
-    def transposed(self):
-        if self._t is None:
-            self._t = self._sorted(self._src, self._tgt)
-            self.t_long_segments = long_row_segments(self._t[0], self.nnz)
-        return self._t
-
-    def plan(self, dtype, transposed=False):
-        return None
-
-
-def weighted_graph(edge_index: torch.Tensor, edge_weight: torch.Tensor, num_nodes: int, value_fn, tag: str):
-    """Cached WeightedCSRGraph; `value_fn(edge_index, edge_weight, n)` -> (edge_index', values) builds the
-    normalised values once per (edge_index, edge_weight) pair."""
-    key_tag = (tag, edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape))
-
-    def build(ei, n):
-        ei2, vals = value_fn(ei, edge_weight, n)
-        g = WeightedCSRGraph(ei2, vals, n)
-        g.edge_weight_ref = edge_weight          # pins the key tensor, like graph_cache pins edge_index
-        return g
-
-    return graph_cache.get(edge_index, num_nodes, factory=build, tag=key_tag)
-
-
-# SGF_SPMM_BLOCK = "rows_per_block,lds_rows" overrides the block shape (default: 128 rows, all 144 KiB of LDS)
-def _block_shape(dtype):
-    import os
-    cap = K.lds_rows_max(dtype)
-    env = os.environ.get("SGF_SPMM_BLOCK", "")
-    if env:
-        r, c = (int(t) for t in env.split(","))
-        return r, min(c, cap)
-    return 128, cap
-
-
-class BlockedPlan:
-    """Row-block plan of one CSR (sgf_spmm_plan): which neighbour rows each block of rows stages in
-    LDS, and the entry codes / values re-ordered so that the LDS entries lead every row."""
-
-    def __init__(self, rowptr, colind, val, n: int, dtype, rows_per_block=None, lds_rows=None):
-        r, c = _block_shape(dtype)
-        self.rows_per_block = int(rows_per_block or r)
-        self.lds_rows = int(lds_rows or c)
-        (self.ecode, self.eval, self.nlds, self.sh_ptr, self.sh_cols, st) = K.spmm_plan(
-            rowptr, colind, val, n, self.rows_per_block, self.lds_rows, LONG_ROW)
-        self.lds_entries, self.staged_rows, self.unique_pairs, self.nnz = st
-        self.lds_fraction = self.lds_entries / max(self.nnz, 1)
-
-
-# Tile plan parameters: at most TILE_CAP staged sources per block (whole 32-source chunks), a source is staged when at
-# least TILE_MIN_COUNT of the block's entries reference it (a staged source costs one 512-byte row of X plus one
-# 512-byte tile column per block, a gathered entry 520 bytes each time; measured at ogbn-products scale: 2 -> 2.16 ms,
-# 3 -> 2.21 ms), blocks of at most TILE_MAX_ROWS rows (256-row blocks of 8 waves, one per CU: 2.75 ms; 64: 4.4 ms).
-TILE_CAP = 512
-TILE_MIN_COUNT = 2
-TILE_MAX_ROWS = 128
-TILE_SPARSE_DENSITY = 0.12
-
-
-def _tile_params():
-    import os
-    env = os.environ.get("SGF_SPMM_TILE", "")          # "cap,min_count,max_rows" (experiments)
-    if env:
-        c, m, r = (int(t) for t in env.split(","))
-        return c, m, r
-    return TILE_CAP, TILE_MIN_COUNT, TILE_MAX_ROWS
-
-
-class TilePlan:
-    """Plan of sgf_spmm_tile for one CSR: row blocks, the sources each block stages, the dense tiles as matrix-core
-    fragments (hi + lo bf16; packed: sparse groups as entries, see K.tile_pack) and the CSR of the entries left on the
-    gather path.  keep_dense=True keeps the unpacked fragments as .tiles (tests)."""
-
-    def __init__(self, rowptr, colind, val, n: int, blk_row: torch.Tensor, cap=None, min_count=None, keep_dense=False):
-        c, m, _ = _tile_params()
-        self.blk_row, self.nb = blk_row, int(blk_row.numel()) - 1
-        self.block_rows = int((blk_row[1:] - blk_row[:-1]).max()) if self.nb > 0 else 1
-        self.cap, self.min_count = int(cap or c), int(min_count or m)
-        (self.sh_ptr, self.sh_cols, self.tile_ptr, self.tiles, self.rem_rowptr, self.rem_col, self.rem_val,
-         st) = K.tile_plan(rowptr, colind, val, n, blk_row, self.cap, self.min_count, LONG_ROW)
-        self.tile_entries, self.staged_rows, _, self.nnz, self.fragments, self.rem_entries = st[:6]
-        self.tile_fraction = self.tile_entries / max(self.nnz, 1)
-        # stored entries per tile cell: below ~2 % a tile column moves more bytes than the gathers it replaces
-        self.tile_density = self.tile_entries / max(self.fragments * 512, 1)
-        self.long_segments = long_row_segments(self.rem_rowptr, None)
-        self.grp, self.pool, units = K.tile_pack(blk_row, self.tile_ptr, self.tiles, self.fragments)
-        self.tile_bytes = units * 16                       # what a launch reads of them (dense: fragments * 2048)
-        if not keep_dense:
-            self.tiles = None
-        self.bytes = (self.pool.numel() + self.grp.numel() * 4 + self.rem_col.numel() * 8 + self.rem_rowptr.numel() * 8
-                      + self.sh_cols.numel() * 4)
-
-
-# When to re-order (SGF_REORDER): "auto" (default) tries once per cached graph with at least
-# REORDER_MIN_NODES nodes, at its second forward (a graph seen once is a mini-batch: planning would cost
-# more than it saves) or when prepare_graph() asks for it; "1" tries every graph at first use; "0" never.
-# The order is adopted only if the row-block plan on the re-ordered CSR then serves at least
-# REORDER_MIN_LDS_FRACTION of the stored entries from LDS — a uniform random graph is an expander, no order
-# helps it, and it keeps the plain kernel on its original CSR.
-REORDER_MIN_NODES = 100_000
-REORDER_MIN_LDS_FRACTION = 0.25
-REORDER_ITERS = (6, 6)
-_reorder_mode = None
-
-
-def set_reorder_mode(mode: Optional[str]):
-    """'auto' | 'always' | 'never' | None (= read SGF_REORDER).  Returns the previous setting."""
-    global _reorder_mode
-    prev, _reorder_mode = _reorder_mode, mode
-    return prev
-
-
-def _mode() -> str:
-    if _reorder_mode is not None:
-        return _reorder_mode
-    import os
-    return {"0": "never", "1": "always"}.get(os.environ.get("SGF_REORDER", "auto"), "auto")
-
-
-class GraphView:
-    """(graph, perm, inv): `graph` is the CSRGraph the layers multiply with; when perm is not None the
-    model's rows are in the re-ordered numbering: row p of every activation is original node perm[p],
-    and original node v sits at row inv[v]."""
-
-    def __init__(self, graph, perm, inv, stats=None):
-        self.graph, self.perm, self.inv, self.stats = graph, perm, inv, stats or {}
-
-    @staticmethod
-    def decide(g: "CSRGraph", now: bool):
-        mode = _mode()
-        if mode == "never" or K.name != "hip" or g.nnz == 0 or g.nnz >= 2 ** 32 - 1:
-            return GraphView(g, None, None, {"reordered": False, "why": "disabled"})
-        if mode == "auto":
-            if g.n < REORDER_MIN_NODES:
-                return GraphView(g, None, None, {"reordered": False, "why": "small graph"})
-            if not now and g.forward_calls < 2:
-                return None                    # undecided: wait for the second forward on this graph
-        import os
-        perm, inv, comm = K.reorder(g.edge_index, g.n, *REORDER_ITERS)
-        g2 = CSRGraph(inv.long()[g.edge_index], g.n, validate=False)
-        # how much neighbour sharing the new order exposes: the share of stored entries that fall into the dense
-        # tiles of community-aligned row blocks — the adoption criterion, whichever kernel then runs
-        _, _, max_rows = _tile_params()
-        g2.blk_row = K.tile_blocks(comm[perm.long()].contiguous(), g.n, max_rows, g.device)
-        try:
-            tp = g2.tile_plan(False)
-        except (ValueError, _lib.SgfError) as e:
-            # a plan the tile kernel cannot take (a row block out of range, nnz beyond its 32-bit offsets): keep the graph
-            # as given rather than fail the forward
-            return GraphView(g, None, None, {"reordered": False, "why": f"tile plan unsupported: {e}"})
-        if tp.tile_density < TILE_SPARSE_DENSITY and tp.min_count == TILE_MIN_COUNT and not os.environ.get("SGF_SPMM_TILE"):
-            # tiles this sparse (a skewed graph: many sources referenced just twice per block) move more fragment bytes
-            # than the gathers they replace: stage only sources with one more reference (power-law community graph at
-            # ogbn-products scale: density 0.08 -> 0.11, 3.08 -> 2.92 ms; profiles/r03_spmm_tile.md)
-            g2.tile_min_count = TILE_MIN_COUNT + 1
-            g2._tile_plans.clear()
-            tp = g2.tile_plan(False)
-        stats = {"lds_fraction": tp.tile_fraction, "tile_density": tp.tile_density, "blocks": tp.nb,
-                 "staged_rows_per_node": tp.staged_rows / max(g.n, 1), "plan_bytes": tp.bytes, "min_count": tp.min_count}
-        if tp.tile_fraction < REORDER_MIN_LDS_FRACTION and mode != "always":
-            return GraphView(g, None, None, {**stats, "reordered": False, "why": "no reuse to exploit"})
-        # Which kernel multiplies with the re-ordered CSR: dense matrix-core tiles + gather remainder (sgf_spmm_tile)
-        # for bf16 rows of 128 / 256 features; the flattened stream kernel (sgf_spmm_stream) otherwise and under
-        # SGF_SPMM_TILED=0; SGF_SPMM_BLOCKED=1 selects r02's LDS-staged row blocks (profiles/r02_spmm_structured.md).
-        g2.locality = True        # its gathers mostly hit in L2: ops.spmm_on picks sgf_spmm_stream
-        g2.blocked = os.environ.get("SGF_SPMM_BLOCKED", "0") == "1"
-        g2.tiled = os.environ.get("SGF_SPMM_TILED", "1") == "1" and not g2.blocked
-        if not g2.tiled:
-            g2._tile_plans.clear()
-        stats["kernel"] = ("row-block (LDS-staged)" if g2.blocked else
-                           "tiles (matrix cores) + gather remainder for bf16 rows of 128 / 256 features, else stream"
-                           if g2.tiled else "stream")
-        return GraphView(g2, perm, inv, {**stats, "reordered": True})
-
-
-def prepare_graph(edge_index: torch.Tensor, num_nodes: int) -> GraphView:
-    """Build everything that is per-graph, not per-step: the CSR, and (policy above) the node order and
-    row-block plan.  The trainers need not call this — the same work happens lazily in the first two
-    forwards — bench.py does, so that it stays outside the timed region like the CSR build."""
-    return graph_cache.get(edge_index, num_nodes).view(now=True)
-
-
-class _GraphCache:
-    """edge_index -> CSRGraph, keyed on tensor identity AND version: the
-    mini-batch trainers hand in a fresh edge_index every step, so entries are bounded (LRU) and each
-    entry pins its key tensor so a recycled data_ptr can never alias a stale graph."""
-
-    def __init__(self, capacity: int = 4):
-        self.capacity = capacity
-        self._d: "OrderedDict[tuple, CSRGraph]" = OrderedDict()
-
-    def get(self, edge_index: torch.Tensor, num_nodes: int, factory=None, tag=None):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-               tuple(edge_index.stride()), str(edge_index.device), int(num_nodes), tag)
-        g = self._d.get(key)
-        if g is not None:  # the entry pins its tensor, so an equal key means the same live memory
-            self._d.move_to_end(key)
-            return g
-        g = (factory or CSRGraph)(edge_index, num_nodes)
-        g.edge_index_ref = edge_index
-        self._d[key] = g
-        while len(self._d) > self.capacity:
-            self._d.popitem(last=False)
-        return g
-
-    def clear(self):
-        self._d.clear()
-
-
-graph_cache = _GraphCache()
-
-
-# ------------------------------------------------------------------------------------------------
-# T2: SpMM (large/ours.py:34)
-# ------------------------------------------------------------------------------------------------
-def _sharded_spmm(graph, x, shard, transposed: bool):
-    """Local rows of A (or of A^T) times the node-sharded operand.
-
-    Halo path (graph.halo(...).enabled): pack the rows the peers need, one all_to_all_single, product on
-    [own rows ; halo rows] with the block's relabelled columns — bytes on the links = the distinct cut-edge
-    sources only.  Fallback when the cut is (nearly) everything: all-gather of the operand PIPELINED against
-    the product — the operand is split into column chunks, every chunk's all-gather is issued up front
-    (asynchronously, on the collective's own stream), and the SpMM of chunk c starts as soon as chunk c has
-    arrived while chunks c+1.. are still on the xGMI links."""
-    rowptr, colind, val = graph.transposed() if transposed else (graph.rowptr, graph.colind, graph.val)
-    long_segments = graph.t_long_segments if transposed else graph.long_segments
-    n_local = graph.n_local
-    plan = graph.halo(shard, transposed) if hasattr(graph, "halo") else None
-    if plan is not None and plan.enabled:
-        if plan.n_halo == 0:                      # nothing to exchange (one rank, or a block without cut edges)
-            return _own_block_spmm(graph, plan, (rowptr, plan.colind, val, long_segments), x, n_local, transposed)
-        if getattr(shard, "overlap", False):
-            shard.overlapped_exchanges = getattr(shard, "overlapped_exchanges", 0) + 1
-            # the entries whose source this rank owns are multiplied while the halo rows are on the links; the halo
-            # entries follow when they have arrived (their sum is rounded to the storage dtype before it is added: bf16
-            # rows with cut edges carry two roundings more than the single-GPU product)
-            own, (rp_h, ci_h, va_h, seg_h) = plan.split(rowptr, val, n_local)
-            recv, work, keep = shard.halo_exchange_start(x, plan)
-            y = _own_block_spmm(graph, plan, own, x, n_local, transposed)
-            work.wait()
-            y.add_(K.spmm(rp_h, ci_h, va_h, recv, n_local, long_segments=seg_h))
-            del keep
-            return y
-        return K.spmm(rowptr, plan.colind, val, shard.halo_exchange(x, plan), n_local, long_segments=long_segments)
-    d = x.shape[1]
-    chunks = shard.gather_chunks(d)
-    if chunks <= 1:
-        return K.spmm(rowptr, colind, val, shard.all_gather_rows(x), n_local, long_segments=long_segments)
-    w = d // chunks
-    pending = [shard.all_gather_rows(x[:, c * w:(c + 1) * w].contiguous(), async_op=True) for c in range(chunks)]
-    y = torch.empty((n_local, d), dtype=x.dtype, device=x.device)
-    for c, (buf, work) in enumerate(pending):
-        work.wait()                                   # the compute stream waits for THIS chunk only
-        K.spmm(rowptr, colind, val, buf, n_local, out=y[:, c * w:(c + 1) * w], long_segments=long_segments)
-    return y
-
-
-def _own_block_spmm(graph, plan, own, x, n_local: int, transposed: bool):
-    """The square block of a rank's rows x the rank's OWN columns (the part of a node-sharded product that needs no
-    exchange).  When the partition follows sgf_reorder's order (dist.Repartition sets graph.locality / comm_local) this
-    block has the structure the re-ordered single-GPU graph has, and takes the same kernels: the matrix-core tile kernel
-    (sgf_spmm_tile, bf16 rows of 128 / 256 features; plan built once per block and direction) or the stream kernel; the
-    plain row kernel otherwise."""
-    rp, ci, va, segs = own
-    if getattr(graph, "locality", False):
-        import os
-        if (hasattr(K, "tile_supported") and K.tile_supported(x.shape[1], x.dtype) and getattr(graph, "comm_local", None) is not None
-                and os.environ.get("SGF_SPMM_TILED", "1") == "1" and n_local >= 256
-                and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32 - 2048):
-            plans = plan.__dict__.setdefault("_own_tile_plans", {})
-            tp = plans.get("plan")
-            if tp is None:
-                try:
-                    _, _, max_rows = _tile_params()
-                    blk_row = K.tile_blocks(graph.comm_local, n_local, max_rows, x.device)
-                    tp = TilePlan(rp, ci, va, n_local, blk_row)
-                    if tp.tile_fraction < REORDER_MIN_LDS_FRACTION:
-                        tp = False                              # too little to put on the matrix cores: stream kernel
-                except (ValueError, _lib.SgfError):
-                    tp = False
-                plans["plan"] = tp
-            if tp:
-                return K.spmm_tile(tp, x, n_local)
-        return K.spmm(rp, ci, va, x, n_local, long_segments=segs, stream_hint=True)
-    return K.spmm(rp, ci, va, x, n_local, long_segments=segs)
-
-
-class _SpMM(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, graph, shard):
-        K.check(x)
-        ctx.graph, ctx.shard = graph, shard
-        if shard is not None:
-            # node-sharded: rows of A local, X rows gathered from all ranks (halo all-gather)
-            return _sharded_spmm(graph, x, shard, False)
-        return spmm_on(graph, x, False)
-
-    @staticmethod
-    def backward(ctx, gy):
-        graph, shard = ctx.graph, ctx.shard
-        if shard is not None:
-            # dX_local = (A^T dY)[local rows]: local rows of the CSR of A^T times the sharded dY
-            return _sharded_spmm(graph, gy.contiguous(), shard, True), None, None
-        return spmm_on(graph, gy.contiguous(), True), None, None
-
-
-def spmm_on(graph, x: torch.Tensor, transposed: bool, out=None) -> torch.Tensor:
-    """A x or A^T x on one GPU: the LDS-staged row-block kernel when the graph carries a plan for this
-    storage dtype (GraphView adopted a re-ordered CSR), else the wave-per-row kernel."""
-    rp, ci, va = graph.transposed() if transposed else (graph.rowptr, graph.colind, graph.val)
-    segs = graph.t_long_segments if transposed else graph.long_segments
-    plan = graph.plan(x.dtype, transposed) if (getattr(graph, "blocked", False) and x.shape[1] <= 256) else None
-    if plan is not None:
-        return K.spmm_blocked(rp, plan, x, graph.n, out=out, long_segments=segs)
-    if getattr(graph, "tiled", False):
-        if (K.tile_supported(x.shape[1], x.dtype)
-                and x.shape[0] * max(x.stride(0), x.shape[1]) * 2 < 2 ** 32 - 2048      # = sgf_spmm_tile's own bound
-                and (out is None or (out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0))):
-            return K.spmm_tile(graph.tile_plan(transposed), x, graph.n, out=out)
-        if not K.tile_supported(x.shape[1], x.dtype) and getattr(graph, "_tile_plans", None):
-            # this graph is being multiplied in a storage dtype / width the tile kernel does not take (fp32 runs): the plan
-            # GraphView.decide built for its adoption statistics (about the size of the CSR) is dropped, not kept resident
-            graph._tile_plans.clear()
-    if getattr(graph, "locality", False):
-        return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs, stream_hint=True)
-    return K.spmm(rp, ci, va, x, graph.n, out=out, long_segments=segs)
-
-
-def spmm(graph, x: torch.Tensor, shard=None) -> torch.Tensor:
-    """Y = A X with A the cached normalised adjacency (torch_sparse.matmul(adj, x) in the reference)."""
-    return _SpMM.apply(x, graph, shard)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -845,36 +355,6 @@ def ln_res_act(x, res, a, b, gamma, beta, relu, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # T6: y = [relu](BatchNorm1d(x)) [+ res]   (large/ours.py:77-81, 87-93)
 # ------------------------------------------------------------------------------------------------
-_BN_SAMPLE_ROWS = 1024
-
-
-def batch_stats(x: torch.Tensor, shard=None):
-    """Column mean / biased variance over all rows (all ranks when sharded) in ONE pass over x.
-
-    Shifted single pass: the shift is the column mean of a small leading sample of rows (a ~10 us
-    kernel), then one streaming pass accumulates [sum (x - s) | sum (x - s)^2] in fp32;
-    mean = s + m1, var = m2 - m1^2 with m1 ~ sigma / sqrt(sample) — no cancellation, unlike the
-    unshifted E[x^2] - E[x]^2, and half the HBM traffic of the two-pass form.  Node-sharded runs
-    all-reduce the sample sums (so that every rank uses the same shift) and then the two sums."""
-    K.check(x)
-    x = _rows(x.detach())
-    n, d = x.shape
-    ns = min(n, _BN_SAMPLE_ROWS)
-    samp = torch.cat([K.colstats(x[:ns], None)[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
-    n_tot = float(n)
-    if shard is not None:
-        shard.all_reduce(samp)
-        n_tot = float(shard.n_global)
-    shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
-    st = K.colstats(x, shift)
-    if shard is not None:
-        shard.all_reduce(st)
-    m1 = st[:d] / max(n_tot, 1.0)
-    mean = shift + m1
-    var = (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0)
-    return mean, var, n_tot
-
-
 class _BNActRes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, mean, rstd, relu: bool, training: bool, n_tot: float,
@@ -1082,11 +562,19 @@ class _CombineFC(torch.autograd.Function):
             g = torch.nn.functional.pad(g, (0, w32.shape[0] - g.shape[1]))
         g = g.contiguous()
         row_map = ctx.row_map
+        c = c_true
+        if x1.dtype == _BF16 and hasattr(K, "combine_fc_bwd_g") and g.shape[1] <= 64:
+            # the kernel holds the logits' gradient as bf16 matrix-core fragments anyway: it leaves them as the [N, 48]
+            # operand of the weight gradient's node reductions (module row order), instead of a cast + a pad pass over g
+            dx1, dx2, gp = K.combine_fc_bwd_g(g, w32, a, b, row_map)
+            dw1, db = K.gram(gp, x1, want_colsum=True)
+            dw2, _ = K.gram(gp, x2, want_colsum=False)
+            dw = (a * dw1 + b * dw2)[:c]
+            return dx1, dx2, dw.to(wdtype), db[:c].to(bdtype), None, None, None
         dx1, dx2 = K.combine_fc_bwd(g, w32, a, b, x1.dtype) if row_map is None else K.combine_fc_bwd(g, w32, a, b, x1.dtype,
                                                                                                        row_map)
         # dW = a g^T x1 + b g^T x2, db = colsum(g): node reductions on sgf_gram (g in the activation dtype, its
         # width padded to a multiple of 4 — the same rounding the unfused path applies to the logits gradient)
-        c = c_true
         if row_map is not None:
             # g is in the CALLER's row order, x1 / x2 in the module's: one gather pass brings g over, cast included
             gp = K.gather_rows(g, row_map, x1.dtype)
@@ -1126,519 +614,11 @@ def combine_fc_supported(x: torch.Tensor, classes: int) -> bool:
     return x.dim() == 2 and K.combine_fc_supported(x.shape[1], classes, x.dtype)
 
 
-# ------------------------------------------------------------------------------------------------
-# T4: the Linear layers  y = x W^T + b  (large/ours.py:123-126, :36-40, :77, :198, :275).
-# bf16 storage, square layers of width 64 / 128 / 256 (and pairs [x1 | x2] of them): forward, the BatchNorm column sums of
-# the output and dX on the streaming row kernels (sgf_gcn_epilogue_*, csrc/rowgemm.hip); fp32 storage, widths % 4 up to 256:
-# the exact-fp32 streaming kernel (csrc/linear_f32.hip); EVERY other shape: the general matrix-core kernel sgf_gemm
-# (csrc/gemm.hip) — no Linear of the path is a library GEMM.  The weight / bias gradients
-#     dW = dY^T X   (a d x d <- [N x d]^T [N x d] reduction over all nodes),   db = colsum(dY)
-# always run on sgf_gram: hipBLASLt's kernels for that shape ran at 0.7 TB/s (3.6 ms per call at
-# ogbn-products scale, profiles/r01_products_bf16_kernel_stats.md) and ATen's column reduction for
-# the bias gradient at 18.6 ms for C = 47.  Master weights may be fp32 while activations are bf16.
-# ------------------------------------------------------------------------------------------------
-class _Linear(torch.autograd.Function):
-    """y = sum_i x_i W_i^T + b with W = [W_1 | W_2 | ...] split along its input dimension
-    (one operand for nn.Linear; two for GraphConvLayer's W [A x | x0], large/ours.py:36-38,
-    without materialising the concatenation)."""
-
-    @staticmethod
-    def forward(ctx, w, b, stats_req, *xs):
-        K.check(*xs)
-        dt = xs[0].dtype
-        wc = w if w.dtype == dt else w.to(dt)
-        widths = [x.shape[1] for x in xs]
-        if sum(widths) != w.shape[1]:
-            raise RuntimeError(f"linear: input widths {widths} do not add up to {w.shape[1]}")
-        offs = [sum(widths[:i]) for i in range(len(widths))]
-        fused = (len(xs) <= 2 and all(_streaming_linear_ok(x, wc[:, o:o + k]) for x, o, k in zip(xs, offs, widths)))
-        if fused:
-            # streaming passes with W resident in LDS (sgf_gcn_epilogue_*); the BatchNorm that follows gets its
-            # column sums from the same pass
-            xr = [_rows16(x) for x in xs]
-            b32 = None if b is None else b.detach().float().contiguous()
-            if stats_req is not None:
-                y = _linear_with_stats(xr, wc, b32, stats_req)
-            else:
-                y, _ = _streaming_linear(xr, wc, b32)
-        else:
-            # any other shape (input widths beyond 256 or not multiples of 4, odd hidden widths, multi-head projections):
-            # the general matrix-core kernel (sgf_gemm, csrc/gemm.hip) — first operand with the bias, the rest accumulated
-            # IN PLACE; W's column blocks are passed as strided views (no copy, no transposition)
-            b32 = None if b is None else b.detach().float().contiguous()
-            y = K.gemm(xs[0], wc[:, :widths[0]].t(), bias=b32)
-            off = widths[0]
-            for x, k in zip(xs[1:], widths[1:]):
-                K.gemm(x, wc[:, off:off + k].t(), out=y, beta=1.0, addend=y)
-                off += k
-        if stats_req is not None and not fused:
-            stats_req["out"] = batch_stats(y, stats_req.get("shard"))
-        ctx.save_for_backward(wc, *xs)
-        ctx.meta = (w.dtype, None if b is None else b.dtype, widths)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        wc, *xs = ctx.saved_tensors
-        wdtype, bdtype, widths = ctx.meta
-        g = g.contiguous()
-        need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and bdtype is not None
-        dxs, off = [], 0
-        for i, k in enumerate(widths):
-            if not ctx.needs_input_grad[3 + i]:
-                dxs.append(None)
-            elif _streaming_linear_ok(g, wc[:, off:off + k], dx=True):
-                dxs.append(K.gcn_epilogue_dx(_rows16(g), wc[:, off:off + k]))
-            else:
-                dxs.append(K.gemm(g, wc[:, off:off + k]))
-            off += k
-        dw, db = _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype)
-        return (dw, db, None, *dxs)
-
-
-def _linear_param_grads(g, xs, widths, need_w, need_b, wdtype, bdtype):
-    """dW = g^T [x_1 | x_2 | ...], db = sum_n g on sgf_gram (one node reduction per operand)."""
-    dw = db = None
-    if need_w or need_b:
-        # sgf_gram wants widths that are multiples of 4 elements: zero-pad the odd ones (e.g. the
-        # C = 47 logits gradient: one extra [N, 48] pass) and slice the result
-        m = g.shape[1]
-        gp = _rows(g if m % 4 == 0 else torch.nn.functional.pad(g, (0, 4 - m % 4)))
-        dw = torch.empty((gp.shape[1], sum(widths)), dtype=_F32, device=g.device)
-        off = 0
-        if (len(xs) == 2 and widths[0] == widths[1] and widths[0] % 4 == 0 and hasattr(K, "gram2") and gp.dtype == _BF16
-                and xs[0].dtype == _BF16 and xs[1].dtype == _BF16 and _pair_gram()):
-            # both blocks of dW = g^T [x_1 | x_2] from ONE read of g out of HBM (paired launch, sgf_gram2)
-            k = widths[0]
-            db = K.gram2(gp, _rows(xs[0]), _rows(xs[1]), dw[:, :k], dw[:, k:], want_colsum=need_b)
-            xs, widths = [], []
-        for i, (x, k) in enumerate(zip(xs, widths)):
-            if k % 4 == 0 and off % 4 == 0:   # sgf_gram stores float4s: the slice must stay 16-B aligned
-                _, cs = K.gram(gp, _rows(x), out=dw[:, off:off + k], want_colsum=(i == 0 and need_b))
-            elif k % 4 == 0:
-                blk, cs = K.gram(gp, _rows(x), want_colsum=(i == 0 and need_b))
-                dw[:, off:off + k] = blk
-            else:
-                xp = _rows(torch.nn.functional.pad(x, (0, 4 - k % 4)))
-                blk, cs = K.gram(gp, xp, want_colsum=(i == 0 and need_b))
-                dw[:, off:off + k] = blk[:, :k]
-            if i == 0:
-                db = cs
-            off += k
-        dw = dw[:m].to(wdtype) if need_w else None
-        db = db[:m].to(bdtype) if need_b else None
-    return dw, db
-
-
-class _StemPair(torch.autograd.Function):
-    """(y0, y1) = (x W0^T + b0, x W1^T + b1) from ONE pass over x — the first Linear of GraphConv and of TransConv
-    (large/ours.py:77, :198) read the same node features; y0's BatchNorm column sums ride along (stats_req)."""
-
-    @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, stats_req):
-        K.check(x)
-        dt = x.dtype
-        w0c, w1c = w0.to(dt), w1.to(dt)
-        f32 = [None if b is None else b.detach().float().contiguous() for b in (b0, b1)]
-        d = w0.shape[0]
-        shift = None
-        if stats_req is not None:
-            shard = stats_req.get("shard")
-            n = x.shape[0]
-            ns = min(n, _BN_SAMPLE_ROWS)
-            _, _, st_s = K.stem_pair(x[:ns], w0c, f32[0], None, None, None, want_stats0=True)
-            samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
-            n_tot = float(n)
-            if shard is not None:
-                shard.all_reduce(samp)
-                n_tot = float(shard.n_global)
-            shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
-        y0, y1, st = K.stem_pair(x, w0c, f32[0], w1c, f32[1], shift, want_stats0=stats_req is not None)
-        if stats_req is not None:
-            if shard is not None:
-                shard.all_reduce(st)
-            m1 = st[:d] / max(n_tot, 1.0)
-            stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
-        ctx.save_for_backward(x, w0c, w1c)
-        ctx.meta = (w0.dtype, None if b0 is None else b0.dtype, w1.dtype, None if b1 is None else b1.dtype)
-        return y0, y1
-
-    @staticmethod
-    def backward(ctx, g0, g1):
-        x, w0c, w1c = ctx.saved_tensors
-        wd0, bd0, wd1, bd1 = ctx.meta
-        k = [x.shape[1]]
-        dw0, db0 = _linear_param_grads(g0.contiguous(), [x], k, ctx.needs_input_grad[1],
-                                       ctx.needs_input_grad[2] and bd0 is not None, wd0, bd0)
-        dw1, db1 = _linear_param_grads(g1.contiguous(), [x], k, ctx.needs_input_grad[3],
-                                       ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = K.gemm(g0.contiguous(), w0c)
-            K.gemm(g1.contiguous(), w1c, out=dx, beta=1.0, addend=dx)
-        return dx, dw0, db0, dw1, db1, None
-
-
-class _StemPairBN(torch.autograd.Function):
-    """(x0, x0, y1): x0 = relu(BatchNorm(x W0^T + b0)) — GraphConv's stem, large/ours.py:77-80 — handed out TWICE (the first
-    SpMM and the layers' Linear / residual consume it; their gradients come back separately instead of through an add),
-    y1 = x W1^T + b1 (TransConv's stem, :198) from the same read of x.  Backward: the BatchNorm's two sums over both
-    gradients (sgf_bn_bwd_stats2), then dW0 / db0 straight from them — dz is formed inside the Gram kernel and never written
-    (sgf_gram_bn_bwd): x is data, nobody else needs dz."""
-
-    @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, gamma, beta, bn_hook, shard, ln_gamma=None, ln_beta=None, ln_cfg=None):
-        """ln_cfg = (eps, relu, affine) — not None: the third output is [relu](LayerNorm(y1)) (TransConv's stem, large/ours.py:
-        198-201) instead of y1, and its backward takes dW1 / db1 / d ln_gamma / d ln_beta from sgf_gram_ln_bwd."""
-        K.check(x)
-        dt = x.dtype
-        w0c, w1c = w0.to(dt), w1.to(dt)
-        f32 = [None if b is None else b.detach().float().contiguous() for b in (b0, b1)]
-        d = w0.shape[0]
-        n = x.shape[0]
-        want = bn_hook(None)
-        shift = None
-        if want:
-            ns = min(n, _BN_SAMPLE_ROWS)
-            _, _, st_s = K.stem_pair(x[:ns], w0c, f32[0], None, None, None, want_stats0=True)
-            n_tot = float(n)
-            if shard is None:
-                shift = st_s[:d] * (1.0 / float(max(ns, 1)))
-            else:
-                samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=x.device)])
-                shard.all_reduce(samp)
-                n_tot = float(shard.n_global)
-                shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
-        y0, y1, st = K.stem_pair(x, w0c, f32[0], w1c, f32[1], shift, want_stats0=want)
-        if want:
-            if shard is not None:
-                shard.all_reduce(st)
-            if hasattr(K, "bn_finalize"):
-                mean, rstd, n_tot, training = bn_hook(("raw", st, shift, n_tot))
-            else:
-                m1 = st[:d] / max(n_tot, 1.0)
-                mean, rstd, n_tot, training = bn_hook((shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot))
-        else:
-            mean, rstd, n_tot, training = bn_hook(False)
-        g32 = gamma.detach().float().contiguous() if gamma is not None else None
-        be32 = beta.detach().float().contiguous() if beta is not None else None
-        mean = mean.detach().float().contiguous()
-        rstd = rstd.detach().float().contiguous()
-        x0 = K.bn_apply(y0, mean, rstd, g32, be32, None, True)
-        out1, ln_saved = y1, (None, None, None, None, None)
-        if ln_cfg is not None:
-            eps, ln_relu, affine = ln_cfg
-            lg32 = ln_gamma.detach().float().contiguous() if affine else None
-            lb32 = ln_beta.detach().float().contiguous() if affine else None
-            out1, lmean, lrstd = K.ln_fwd(_rows(y1), None, 1.0, 0.0, lg32, lb32, bool(ln_relu), float(eps))
-            ln_saved = (y1, lmean, lrstd, lg32, lb32)
-        ctx.save_for_backward(x, w0c, w1c, y0, g32, be32, mean, rstd, *ln_saved)
-        ctx.meta = (w0.dtype, None if b0 is None else b0.dtype, w1.dtype, None if b1 is None else b1.dtype,
-                    None if gamma is None else gamma.dtype, bool(training), float(n_tot), shard,
-                    None if ln_cfg is None else (bool(ln_cfg[1]), None if ln_gamma is None else ln_gamma.dtype))
-        return x0, x0.view_as(x0), out1
-
-    @staticmethod
-    def backward(ctx, ga, gb, g1):
-        x, w0c, w1c, y0, g32, be32, mean, rstd, y1, lmean, lrstd, lg32, lb32 = ctx.saved_tensors
-        wd0, bd0, wd1, bd1, gdt, training, n_tot, shard, ln_meta = ctx.meta
-        d = y0.shape[1]
-        if ga is None:
-            ga, gb = gb, None
-        if ga is None:
-            ga = torch.zeros_like(y0)
-        ga = _rows(ga.contiguous())
-        gb = None if gb is None else _rows(gb.contiguous())
-        stats = K.bn_bwd_stats2(ga, gb, y0, mean, rstd, g32, be32, True)
-        if shard is not None:
-            shard.all_reduce(stats)
-        inv_n = 1.0 / max(n_tot, 1.0)
-        dw0, db0 = K.gram_bn_bwd(ga, gb, y0, mean, rstd, g32, be32, True, stats, inv_n, training, _rows(x))
-        dw0 = dw0.to(wd0) if ctx.needs_input_grad[1] else None
-        db0 = db0.to(bd0) if (ctx.needs_input_grad[2] and bd0 is not None) else None
-        dlg = dlb = None
-        if ln_meta is not None:
-            # TransConv's stem: LayerNorm backward inside the Gram (dl never written); row-local, no collective
-            ln_relu, lgdt = ln_meta
-            dw1, db1, dlg, dlb = K.gram_ln_bwd(_rows(g1.contiguous()), y1, lmean, lrstd, lg32, lb32, ln_relu, _rows(x))
-            dw1 = dw1.to(wd1) if ctx.needs_input_grad[3] else None
-            db1 = db1.to(bd1) if (ctx.needs_input_grad[4] and bd1 is not None) else None
-            dlg, dlb = (dlg.to(lgdt), dlb.to(lgdt)) if lg32 is not None else (None, None)
-        else:
-            dw1, db1 = _linear_param_grads(g1.contiguous(), [x], [x.shape[1]], ctx.needs_input_grad[3],
-                                           ctx.needs_input_grad[4] and bd1 is not None, wd1, bd1)
-        dgamma = stats[d:].to(gdt) if g32 is not None else None
-        dbeta = stats[:d].to(gdt) if be32 is not None else None
-        if shard is not None and g32 is not None:
-            dgamma, dbeta = shard.unsum(dgamma), shard.unsum(dbeta)
-        dx = None
-        if ctx.needs_input_grad[0]:                      # features that require a gradient (not in any recipe): explicit dz
-            g = ga if gb is None else ga + gb
-            dz = K.bn_bwd_apply(g, y0, mean, rstd, g32, be32, True, stats, inv_n, training)
-            gl = g1
-            if ln_meta is not None:
-                gl = K.ln_bwd(_rows(g1.contiguous()), None, y1, None, 1.0, 0.0, lg32, False, lmean, lrstd)[0] \
-                    if not ln_meta[0] else None
-                if gl is None:
-                    raise NotImplementedError("features that require a gradient behind the fused LayerNorm stem: set "
-                                              "SGF_STEM_LN_FUSED=0")
-            dx = K.gemm(dz, w0c)
-            K.gemm(gl.contiguous(), w1c, out=dx, beta=1.0, addend=dx)
-        return dx, dw0, db0, dw1, db1, dgamma, dbeta, None, None, dlg, dlb, None
-
-
-def stem_pair_bn_supported(x, w0, w1) -> bool:
-    return (stem_pair_supported(x, w0, w1) and hasattr(K, "gram_bn_bwd_supported")
-            and K.gram_bn_bwd_supported(w0.shape[0], x.shape[1], x.dtype))
-
-
-def stem_pair_bn(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard=None, ln=None):
-    """(x0 for the layers, x0 for the first SpMM, y1): see _StemPairBN.  ln = (LayerNorm weight, bias, eps, relu): the third
-    output is [relu](LayerNorm(y1)) — TransConv's stem — when the shapes allow (stem_ln_supported)."""
-    if ln is None:
-        return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard)
-    lg, lb, eps, relu = ln
-    return _StemPairBN.apply(x, w0, b0, w1, b1, gamma, beta, bn_hook, shard, lg, lb, (eps, relu, lg is not None))
-
-
-def stem_ln_supported(x, w1) -> bool:
-    import os
-    return (hasattr(K, "gram_ln_bwd_supported") and K.gram_ln_bwd_supported(w1.shape[0], x.shape[1], x.dtype)
-            and not x.requires_grad and os.environ.get("SGF_STEM_LN_FUSED", "1") != "0")
-
-
-def stem_pair_supported(x, w0, w1) -> bool:
-    return (x.dim() == 2 and x.shape[0] > 0 and w0.shape == w1.shape and x.stride(-1) == 1
-            and (x.stride(0) * x.element_size()) % 8 == 0 and x.data_ptr() % 8 == 0
-            and K.stem_pair_supported(x.shape[1], w0.shape[0], x.dtype))
-
-
-def stem_pair(x, w0, b0, w1, b1, want_stats0=False, shard=None):
-    """((y0, y1), stats0): both input stems from one read of x; stats0 = (mean, var, count) of y0 for its BatchNorm
-    when asked for, else None."""
-    req = {"shard": shard, "out": None} if want_stats0 else None
-    y0, y1 = _StemPair.apply(x, w0, b0, w1, b1, req)
-    return (y0, y1), (req["out"] if req is not None else None)
-
-
-def _streaming_linear_ok(x: torch.Tensor, wc: torch.Tensor, dx: bool = False) -> bool:
-    """x wc^T (or, dx=True, x wc) on the streaming kernels: bf16 square layers, fp32 layers of widths % 4 up to 256."""
-    return (x.dim() == 2 and x.shape[0] > 0 and wc.stride(-1) == 1 and (wc.stride(0) * wc.element_size()) % 16 == 0
-            and wc.data_ptr() % 16 == 0 and x.shape[1] == (wc.shape[0] if dx else wc.shape[1])
-            and K.gcn_epilogue_supported(wc.shape[1], wc.shape[0], x.dtype))
-
-
-def _streaming_linear(xr, wc, b32, shift=None, want_stats=False, rows=None):
-    """[x_1 | x_2] wc^T + b32 on the first `rows` rows (all by default): one or two streaming passes."""
-    xs = xr if rows is None else [x[:rows] for x in xr]
-    if len(xs) == 1:
-        return K.gcn_epilogue_stats(xs[0], wc, b32, shift, want_stats=want_stats)
-    return K.gcn_epilogue_cat(xs[0], xs[1], wc, b32, shift, want_stats=want_stats)
-
-
-def _linear_with_stats(xr, wc, b32, stats_req):
-    """y = [x_1 | x_2] wc^T + b32 AND BatchNorm's batch statistics of y, from the same pass.  Same shifted sums as
-    batch_stats: the shift is the column mean of the first rows of y, which a small launch over those rows provides."""
-    shard = stats_req.get("shard")
-    n, d = xr[0].shape[0], wc.shape[0]
-    ns = min(n, _BN_SAMPLE_ROWS)
-    _, st_s = _streaming_linear(xr, wc, b32, None, want_stats=True, rows=ns)
-    n_tot = float(n)
-    if shard is None:
-        shift = st_s[:d] * (1.0 / float(max(ns, 1)))          # one launch; the sharded form needs the global sample count
-    else:
-        samp = torch.cat([st_s[:d], torch.full((1,), float(ns), dtype=_F32, device=xr[0].device)])
-        shard.all_reduce(samp)
-        n_tot = float(shard.n_global)
-        shift = (samp[:d] / samp[d].clamp_min(1.0)).contiguous()
-    y, st = _streaming_linear(xr, wc, b32, shift, want_stats=True)
-    if shard is not None:
-        shard.all_reduce(st)
-    if stats_req.get("raw"):
-        stats_req["out"] = ("raw", st, shift, n_tot)              # the caller finalises (K.bn_finalize: one launch)
-        return y
-    m1 = st[:d] / max(n_tot, 1.0)
-    stats_req["out"] = (shift + m1, (st[d:] / max(n_tot, 1.0) - m1 * m1).clamp_min_(0.0), n_tot)
-    return y
-
 
 # ------------------------------------------------------------------------------------------------
-# T4 + T6 as ONE autograd node: out = [relu](BatchNorm(W [y | x0] + b)) [+ x0]   (large/ours.py:36-40, 87-93)
+# T4 / T6: the Linear layers, the stems and the GraphConv layer live in linear.py; every name is available here
 # ------------------------------------------------------------------------------------------------
-class GradChain:
-    """The gradient of x0 = layer_[0] of one GraphConv forward, collected across its layers' backward nodes (which run in
-    reverse layer order: layer i's input is layer i-1's output) and returned to autograd ONCE, by the first layer's node —
-    the last to run; the others return nothing for x0.  Two forms:
-      * fused kernel (SGF_GCN_BWD_FUSED=1): every layer's sgf_gcn_bn_bwd_dx adds its two contributions (the residual's gy
-        and dz W[:, d:]) to the running sum it is handed (`acc`, opaque);
-      * default: the contributions are kept (`parts`) and summed in one pass (sgf_sum_n) by the first layer's node."""
-
-    def __init__(self):
-        self.acc = None
-        self.parts = []
-
-
-def _fused_bwd() -> bool:
-    """sgf_gcn_bn_bwd_dx in the layers' backward.  Off by default: at d = 256 the four workgroups per row tile do not stay
-    inside the L2's window on their own (gy / z leave HBM four times) and with the per-tile rendezvous the launch is bound
-    by its own serial phases — 2.4-4.4 ms against 2.1 ms for the separate kernels (profiles/r04_bn_bwd_dx_*.md)."""
-    import os
-    return os.environ.get("SGF_GCN_BWD_FUSED", "0") == "1"
-
-
-def _acc_in_place(d: int, dtype) -> bool:
-    """sgf_gcn_epilogue_dx2_acc in the layers' backward (default on; SGF_GCN_DX_ACC=0: paired dx2 + one sgf_sum_n)."""
-    import os
-    return (hasattr(K, "gcn_epilogue_dx2_acc_supported") and K.gcn_epilogue_dx2_acc_supported(d, dtype)
-            and os.environ.get("SGF_GCN_DX_ACC", "1") != "0")
-
-
-def gcn_layer_fused_ok(x0: torch.Tensor, w: torch.Tensor) -> bool:
-    """bf16 storage, square blocks of 64 / 128 / 256, W = [W1 | W2] — what sgf_gcn_bn_bwd_dx / sgf_gcn_epilogue_cat take."""
-    import os
-    d = x0.shape[1] if x0.dim() == 2 else 0
-    return (x0.dim() == 2 and x0.shape[0] > 0 and x0.dtype == _BF16 and tuple(w.shape) == (d, 2 * d)
-            and hasattr(K, "gcn_bn_bwd_dx_supported") and K.gcn_bn_bwd_dx_supported(d, x0.dtype)
-            and os.environ.get("SGF_GCN_FUSED", "1") != "0")
-
-
-class _LinearBNActRes(torch.autograd.Function):
-    """y = A x (already multiplied), x0 -> z = [y | x0] W^T + b -> out = [relu](BatchNorm(z)) [+ x0].
-
-    Forward: one pass for the Linear and BatchNorm's batch sums (sgf_gcn_epilogue_cat), `bn_hook(stats)` — the module's
-    own bookkeeping (batch vs running statistics, running-stat update) — then sgf_bn_apply.
-    Backward: sgf_bn_bwd_stats (the one global reduction), then ONE launch for dz, d y and the running gradient of x0
-    (sgf_gcn_bn_bwd_dx), then the weight / bias gradients on sgf_gram."""
-
-    @staticmethod
-    def forward(ctx, y, x0, w, b, gamma, beta, bn_hook, relu: bool, use_res: bool, shard, chain, first: bool):
-        K.check(y, x0)
-        dt = x0.dtype
-        wc = w.detach().to(dt).contiguous()
-        b32 = None if b is None else b.detach().float().contiguous()
-        yr, xr = _rows16(y), _rows16(x0)
-        want = bn_hook(None)                         # does the BatchNorm normalise with batch statistics?
-        if want:
-            req = {"shard": shard, "out": None, "raw": hasattr(K, "bn_finalize")}
-            z = _linear_with_stats([yr, xr], wc, b32, req)
-            mean, rstd, n_tot, training = bn_hook(req["out"])
-        else:
-            z, _ = _streaming_linear([yr, xr], wc, b32)
-            mean, rstd, n_tot, training = bn_hook(False)
-        g32 = gamma.detach().float().contiguous() if gamma is not None else None
-        be32 = beta.detach().float().contiguous() if beta is not None else None
-        mean = mean.detach().float().contiguous()
-        rstd = rstd.detach().float().contiguous()
-        out = K.bn_apply(z, mean, rstd, g32, be32, xr if use_res else None, relu)
-        ctx.save_for_backward(yr, xr, z, wc, g32, be32, mean, rstd)
-        ctx.meta = (bool(relu), bool(use_res), bool(training), float(n_tot), shard, chain, bool(first), w.dtype,
-                    None if b is None else b.dtype, None if gamma is None else gamma.dtype)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        yr, xr, z, wc, g32, be32, mean, rstd = ctx.saved_tensors
-        relu, use_res, training, n_tot, shard, chain, first, wdt, bdt, gdt = ctx.meta
-        d = z.shape[1]
-        gout = _rows16(gout.contiguous())
-        stats = K.bn_bwd_stats(gout, z, mean, rstd, g32, be32, relu)
-        if shard is not None:
-            shard.all_reduce(stats)
-        inv_n = 1.0 / max(n_tot, 1.0)
-        if _fused_bwd():
-            dz, dy, acc = K.gcn_bn_bwd_dx(gout, z, mean, rstd, g32, be32, relu, stats, inv_n, training, wc, chain.acc,
-                                          last=first, add_gy=use_res)
-            chain.acc = None if first else acc
-            dx0 = acc if first else None
-        else:
-            # BatchNorm backward, then BOTH input gradients from one HBM read of dz (paired launch); x0's contributions wait
-            # in the chain for the one summation pass
-            dz = K.bn_bwd_apply(gout, z, mean, rstd, g32, be32, relu, stats, inv_n, training)
-            if _acc_in_place(d, dz.dtype) and not chain.parts:
-                # x0's gradient accumulated IN PLACE: this layer's dz W2 and residual gradient join the running sum inside
-                # the launch that produces dy (balanced pair of workgroups at d = 256) — no k-operand summation pass at the end
-                dy, chain.acc = K.gcn_epilogue_dx2_acc(dz, wc, _rows16(gout) if use_res else None, chain.acc)
-                dx0 = None
-                if first:
-                    dx0, chain.acc = chain.acc, None
-            else:
-                dy, dxi = K.gcn_epilogue_dx2(dz, wc[:, :d], wc[:, d:], True)
-                chain.parts.append(dxi)
-                if use_res:
-                    chain.parts.append(gout)
-                dx0 = None
-                if first:
-                    parts, chain.parts = chain.parts, []
-                    if chain.acc is not None:
-                        parts.append(chain.acc)
-                        chain.acc = None
-                    dx0 = parts[0] if len(parts) == 1 else (K.sum_n(parts) if len(parts) <= 8 else sum(parts[1:], parts[0]))
-        dw, db = _linear_param_grads(dz, [yr, xr], [d, d], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and bdt is not None,
-                                     wdt, bdt)
-        dgamma = stats[d:].to(gdt) if g32 is not None else None
-        dbeta = stats[:d].to(gdt) if be32 is not None else None
-        if shard is not None and g32 is not None:
-            dgamma, dbeta = shard.unsum(dgamma), shard.unsum(dbeta)
-        return dy, dx0, dw, db, dgamma, dbeta, None, None, None, None, None, None
-
-
-def linear_bn_act_res(y, x0, w, b, gamma, beta, bn_hook, relu, use_res, shard, chain, first):
-    return _LinearBNActRes.apply(y, x0, w, b, gamma, beta, bn_hook, relu, use_res, shard, chain, first)
-
-
-def linear(x, w, b):
-    """nn.Linear: square bf16 layers / fp32 layers up to 256 wide on the streaming row kernels (sgf_gcn_epilogue_stats / _dx),
-    every other shape on sgf_gemm; weight / bias gradients on sgf_gram."""
-    return _Linear.apply(w, b, None, x)
-
-
-def linear_bn_stats(xs, w, b, shard=None):
-    """(y, (mean, var, n_tot)): nn.Linear of x (or of [x_1 | x_2] for a tuple, GraphConvLayer's use_init) and the
-    batch statistics BatchNorm1d needs of its output (large/ours.py:36-40 followed by :87-88) — from the Linear's own
-    pass when its blocks are square bf16, else linear + batch_stats."""
-    req = {"shard": shard, "out": None}
-    xs = xs if isinstance(xs, (tuple, list)) else (xs,)
-    y = _Linear.apply(w, b, req, *xs)
-    return y, req["out"]
-
-
-def linear_cat(xs, w, b):
-    """[x_1 | x_2 | ...] W^T + b without the concatenation (GraphConvLayer with use_init)."""
-    return _Linear.apply(w, b, None, *xs)
-
-
-def out_linear_cat(xs, w, b):
-    """The output head of aggregate='cat' (large/ours.py:271-275: fc(cat(x1, x2))) WITHOUT the [N, 2 d] concatenation:
-    W = [W_1 | W_2] applied operand by operand (fp32 storage: two passes on the exact-fp32 matrix cores, the first product
-    parked as an [N, C] fp32 partial — small next to the [N, d] operands; bf16: GEMM + GEMM(beta = 1)).  Class counts that
-    are not multiples of 4 are padded with zero rows for the fp32 kernel, as in out_linear."""
-    m = w.shape[0]
-    if (xs[0].dtype == _F32 and xs[0].is_cuda and m % 4 != 0
-            and all(K.gcn_epilogue_supported(x.shape[1], (m + 3) // 4 * 4, _F32) for x in xs)):
-        pad = (m + 3) // 4 * 4 - m
-        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
-        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
-        return _Linear.apply(wp, bp, None, *xs)[:, :m]
-    return _Linear.apply(w, b, None, *xs)
-
-
-def out_linear(x, w, b):
-    """The output head (large/ours.py:275).  fp32 storage and a class count that is not a multiple of 4 (C = 47): W and b
-    are padded with zero rows to the next multiple and the result sliced, so that the layer still runs on the streaming
-    fp32 kernel (csrc/linear_f32.hip) instead of a library GEMM; autograd slices the gradients back."""
-    m = w.shape[0]
-    if (x.dtype == _F32 and x.is_cuda and x.dim() == 2 and m % 4 != 0
-            and K.gcn_epilogue_supported(w.shape[1], (m + 3) // 4 * 4, _F32)):
-        pad = (m + 3) // 4 * 4 - m
-        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
-        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
-        return _Linear.apply(wp, bp, None, x)[:, :m]
-    if x.dtype == _BF16 and x.dim() == 2 and m % 8 != 0 and not K.gcn_epilogue_supported(w.shape[1], m, _BF16):
-        # bf16 storage and a class count whose rows would not be 16-byte aligned (the 100M recipe: C = 172 -> 344-byte rows):
-        # W / b padded with zero rows to the next multiple of 8, so that sgf_gemm stages the logits' gradient with 16-byte
-        # loads in the backward (dx = g W) as it stages x in the forward; the result is sliced, autograd slices back
-        pad = (m + 7) // 8 * 8 - m
-        wp = torch.nn.functional.pad(w, (0, 0, 0, pad))
-        bp = None if b is None else torch.nn.functional.pad(b, (0, pad))
-        return _Linear.apply(wp, bp, None, x)[:, :m]
-    return _Linear.apply(w, b, None, x)
+from . import linear as _linear  # noqa: E402
+from .linear import *  # noqa: F401,F403,E402
+from .linear import (_BN_SAMPLE_ROWS, _Linear, _LinearBNActRes, _StemPair, _StemPairBN, _acc_in_place, _fused_bwd, _linear_param_grads,  # noqa: F401,E402
+                     _linear_with_stats, _streaming_linear, _streaming_linear_ok)

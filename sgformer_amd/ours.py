@@ -44,12 +44,17 @@ _NO_SHARD = None
 # torch.bfloat16 so that an unchanged trainer gets the bf16 mode of BASELINE.json config 3.
 DEFAULT_COMPUTE_DTYPE = None
 
-# Opt-in (SGF_OVERLAP=1): run the attention branch on a side HIP stream next to the GCN branch.
-# Measured +2 % in bf16 at ogbn-products scale, but OFF by default: an fp32 run with the two streams
-# hung on MI355X (a library GEMM whose workgroups wait on each other cannot make progress when
-# another stream's persistent one-block-per-CU kernel holds the CUs), and a hang costs more than 2 %.
+# The attention branch runs on a side HIP stream next to the GCN branch (SGF_OVERLAP=0 turns it off): the two are independent
+# until the combine, and autograd replays each backward node on its forward stream, so the backward overlaps too.  r06, MI355X,
+# same box back to back, bf16 ogbn-products shape: uniform graph 89.5 -> 86.2 ms per step, community graph 40.5 -> 39.5 ms,
+# ogbn-arxiv fp32 9.75 -> 9.32 ms, losses identical to the last bit (every reduction is per-launch deterministic).  It was
+# opt-in until r05 because an fp32 run had hung when a LIBRARY GEMM, whose workgroups wait on each other, shared the CUs with
+# a persistent one-block-per-CU kernel of the other stream; no library GEMM is left on the path (r05), and no default kernel
+# of libsgf waits on another workgroup (the opt-in SGF_GCN_BWD_FUSED rendezvous kernel keeps the single-stream path).
+# Full-graph steps of at least OVERLAP_MIN_NODES nodes only; never inside a stream capture (sgformer_amd/graphed.py).
 import os as _os
-OVERLAP_BRANCHES = _os.environ.get("SGF_OVERLAP", "0") == "1"
+OVERLAP_BRANCHES = _os.environ.get("SGF_OVERLAP", "1") == "1"
+OVERLAP_MIN_NODES = 65536
 _side_streams = {}
 
 
@@ -661,7 +666,8 @@ class SGFormer(nn.Module):
             (yg, yt), st = ops.stem_pair(x, wg, gc.fcs[0].bias, wt, tc.fcs[0].bias,
                                          want_stats0=want, shard=gc._shard)
             stem_t, stem_g = yt, (yg, st)
-        if self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None:
+        if (self.use_graph and self.overlap_branches and ops.K.name == "hip" and self.graph_conv._shard is None
+                and x.shape[0] >= OVERLAP_MIN_NODES and not torch.cuda.is_current_stream_capturing() and not ops._fused_bwd()):
             # The two branches are independent until the combine: run the attention branch on a side
             # HIP stream so that its latency-bound kernels fill the gaps of the GCN branch (autograd
             # replays each backward node on its forward stream, so the backward overlaps too).
@@ -671,8 +677,9 @@ class SGFormer(nn.Module):
             with torch.cuda.stream(side):
                 x1 = self.trans_conv(x) if stem_t is None else self.trans_conv(x, stem=stem_t)
             x.record_stream(side)
-            if stem_t is not None:
-                stem_t.record_stream(side)
+            for t in (stem_t if isinstance(stem_t, (tuple, list)) else (stem_t,)):
+                if torch.is_tensor(t):
+                    t.record_stream(side)
             x2 = self.graph_conv(x, edge_index) if stem_g is None else self.graph_conv(x, edge_index, stem=stem_g)
             cur.wait_stream(side)
             x1.record_stream(cur)

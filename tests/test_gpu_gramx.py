@@ -24,10 +24,18 @@ def _switch(on: bool):
     _lib.load().sgf_reload_env()
 
 
+def _bn2(on: bool):
+    """sgf_gram2_bn_bwd is opt-in (SGF_GRAM_BN2=1: measured level with the two kernels it replaces)"""
+    from sgformer_amd import _lib
+    os.environ["SGF_GRAM_BN2"] = "1" if on else "0"
+    _lib.load().sgf_reload_env()
+
+
 @pytest.fixture(autouse=True)
 def _restore():
     yield
     os.environ.pop("SGF_GRAMX", None)
+    os.environ.pop("SGF_GRAM_BN2", None)
     from sgformer_amd import _lib
     _lib.load().sgf_reload_env()
 
@@ -220,3 +228,88 @@ def test_gramt_ln(cuda, n, m, k, relu, affine):
     dw_old, db_old, dg_old, dbt_old = K.gram_ln_bwd(gr, xin, mean, rstd, gamma, beta, relu, x)
     assert _rel(dw, dw_old) <= 3e-4
     assert _rel(dg, dg_old) <= 1e-5 and _rel(dbt, dbt_old) <= 1e-5
+
+
+# ---- k_gramb2: a GraphConv layer's BatchNorm backward + both weight-gradient blocks in one pass (sgf_gram2_bn_bwd) ----------
+@pytest.mark.parametrize("n", [16384, 16384 + 1, 50001, 262144 + 33])
+@pytest.mark.parametrize("m,k", [(256, 256), (128, 128), (64, 64), (256, 104)])
+@pytest.mark.parametrize("relu,training", [(True, True), (False, True), (True, False)])
+def test_gramb2_matches_the_two_kernels_it_replaces(cuda, n, m, k, relu, training):
+    """large/ours.py:36-40,87-93 differentiated: dz = BatchNorm'(relu'(g)) — bit-equal (or one bf16 ulp on a vanishing
+    fraction: the two kernels contract their multiply-adds alike, not identically) to sgf_bn_bwd_apply's —, dW blocks
+    dz^T y, dz^T x0 and db = sum dz against fp64 of the kernel's own rounded dz (fp32 sums of exact products), and against
+    sgf_bn_bwd_apply + sgf_gram2 on the same inputs; identical run to run."""
+    from sgformer_amd import ops
+    if n > 50001 and (m, k) != (256, 256):
+        pytest.skip("large n: the production shape only")
+    K = ops.K
+    _bn2(True)
+    g_ = torch.Generator().manual_seed(n + m + k)
+    g = torch.randn(n, m, generator=g_).bfloat16().to(cuda)
+    z = (torch.randn(n, m, generator=g_) * 1.3 + 0.2).bfloat16().to(cuda)
+    y = torch.randn(n, k, generator=g_).bfloat16().to(cuda)
+    x0 = (torch.randn(n, k, generator=g_) + 0.3).bfloat16().to(cuda)
+    mean = (torch.randn(m, generator=g_) * 0.2 + 0.2).to(cuda)
+    rstd = (1.0 / (1.0 + torch.rand(m, generator=g_))).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(m, generator=g_)).to(cuda)
+    beta = (0.2 * torch.randn(m, generator=g_)).to(cuda)
+    stats = K.bn_bwd_stats(g, z, mean, rstd, gamma, beta, relu)
+    inv_n = 1.0 / n
+    assert K.gram2_bn_bwd_supported(g, z, y, x0)
+    dw = torch.empty(m, 2 * k, device=cuda)
+    dz, db = K.gram2_bn_bwd(g, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, y, x0, dw[:, :k], dw[:, k:])
+    dw2 = torch.empty_like(dw)
+    dz2, db2 = K.gram2_bn_bwd(g, z, mean, rstd, gamma, beta, relu, stats, inv_n, training, y, x0, dw2[:, :k], dw2[:, k:])
+    assert torch.equal(dz, dz2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    dz_ref = K.bn_bwd_apply(g, z, mean, rstd, gamma, beta, relu, stats, inv_n, training)
+    diff = (dz.float() - dz_ref.float()).abs()
+    ulp = dz_ref.float().abs() * 2.0 ** -7 + 1e-30
+    # (beyond one ulp only where relu's mask sits exactly at its threshold and the two kernels' contractions disagree)
+    assert float((diff > ulp).float().mean()) <= 2e-5 and float((diff > 0).float().mean()) <= 2e-3
+    dzd = dz.double()
+    assert _rel(dw[:, :k], dzd.t() @ y.double()) <= 5e-6
+    assert _rel(dw[:, k:], dzd.t() @ x0.double()) <= 5e-6
+    assert _rel(db, dzd.sum(0)) <= 5e-6 or float(dzd.sum(0).abs().max()) < 1e-2
+    dw3 = torch.empty_like(dw)
+    K.gram2(dz_ref, y, x0, dw3[:, :k], dw3[:, k:], want_colsum=False)
+    assert _rel(dw, dw3) <= 2e-4
+
+
+def test_gramb2_strided_operands_refuses_misaligned(cuda):
+    from sgformer_amd import ops
+    K = ops.K
+    _bn2(True)
+    n, d = 20000, 256
+    g_ = torch.Generator().manual_seed(1)
+    wide = torch.randn(n, 4 * d, generator=g_).bfloat16().to(cuda)
+    g, z, y, x0 = (wide[:, i * d:(i + 1) * d] for i in range(4))            # column slices: ld = 4 d
+    mean, rstd = torch.zeros(d, device=cuda), torch.ones(d, device=cuda)
+    stats = K.bn_bwd_stats(g.contiguous(), z.contiguous(), mean, rstd, None, None, True)
+    dw = torch.empty(d, 2 * d, device=cuda)
+    dz, db = K.gram2_bn_bwd(g, z, mean, rstd, None, None, True, stats, 1.0 / n, True, y, x0, dw[:, :d], dw[:, d:])
+    dz_ref = K.bn_bwd_apply(g.contiguous(), z.contiguous(), mean, rstd, None, None, True, stats, 1.0 / n, True)
+    assert float((dz.float() - dz_ref.float()).abs().max()) <= 2.0 ** -7 * float(dz_ref.float().abs().max())
+    assert _rel(dw[:, :d], dz.double().t() @ y.double()) <= 5e-6
+    assert not K.gram2_bn_bwd_supported(g[:, 4:], z[:, 4:], y[:, 4:], x0[:, 4:])     # 8-byte aligned rows only: the old pair
+
+
+@pytest.mark.parametrize("n,c", [(1, 47), (31, 7), (5000, 47), (70001, 40), (4097, 64), (3000, 2)])
+@pytest.mark.parametrize("mapped", [False, True])
+def test_head_backward_also_leaves_the_bf16_gradient_operand(cuda, n, c, mapped):
+    """sgf_combine_fc_bwd_g (large/ours.py:275 differentiated): dx1 / dx2 bit-equal to sgf_combine_fc_bwd[_mapped]'s, and
+    g_out == the logits' gradient cast to bf16, zero-padded to 16 ceil(c / 16) columns, in the module's row order — what the
+    cast + pad passes (and the row gather of a re-ordered graph) produced before."""
+    from sgformer_amd import ops
+    K = ops.K
+    d = 256
+    g_ = torch.Generator().manual_seed(n + c)
+    g = torch.randn(n, c, generator=g_).to(cuda)
+    w = (torch.randn(c, d, generator=g_) * 0.1).to(cuda)
+    rmap = torch.randperm(n, generator=g_).int().to(cuda) if mapped else None
+    dx1, dx2, gp = K.combine_fc_bwd_g(g, w, 0.5, 0.5, rmap)
+    r1, r2 = K.combine_fc_bwd(g, w, 0.5, 0.5, torch.bfloat16, rmap) if mapped else K.combine_fc_bwd(g, w, 0.5, 0.5, torch.bfloat16)
+    assert torch.equal(dx1, r1) and torch.equal(dx2, r2)
+    src = g[rmap.long()] if mapped else g
+    cp = (c + 15) // 16 * 16
+    assert gp.shape == (n, cp) and gp.dtype == torch.bfloat16
+    assert torch.equal(gp[:, :c], src.bfloat16()) and int(torch.count_nonzero(gp[:, c:])) == 0

@@ -243,15 +243,15 @@ def test_cached_batches_survive_replays_and_accumulation_stays_eager(cuda, monke
         assert torch.equal(eager[1][k], graph[1][k]), k
 
 
-def _two_region_graph(n, dense, seed):
-    """sparse uniform graph over n nodes + a DENSE block among the first `dense` nodes + node 0 as a hub of nodes 1..6000,
+def _two_region_graph(n, seed):
+    """sparse uniform graph over n nodes + a DENSE block among nodes [10, 8202) + node 0 as a hub of nodes [20000, 26000),
     symmetric, coalesced, one self-loop per node (the trainer's prologue)."""
     from sgformer_amd import synth
     g = torch.Generator().manual_seed(seed)
     sparse = synth.synthetic_graph(n, 6.0, seed=seed)
-    a = torch.randint(0, dense, (dense * 20,), generator=g)
-    b = torch.randint(0, dense, (dense * 20,), generator=g)
-    hub = torch.arange(1, 6001)
+    a = torch.randint(10, 8202, (8192 * 20,), generator=g)
+    b = torch.randint(10, 8202, (8192 * 20,), generator=g)
+    hub = torch.arange(20000, 26000)
     src = torch.cat([sparse[0], a, b, torch.zeros_like(hub), hub])
     dst = torch.cat([sparse[1], b, a, hub, torch.zeros_like(hub)])
     key = torch.unique(src * n + dst)
@@ -260,21 +260,27 @@ def _two_region_graph(n, dense, seed):
 
 def test_a_batch_beyond_the_captured_capacity_and_a_first_long_row(cuda, monkeypatch):
     """(a) a later batch of a captured size whose nnz exceeds StaticCSR.cap (the fixed-capacity arrays the
-    captured SpMM launches read) is a new capture, not a truncated graph; (b) a batch with a row of thousands of entries
-    after a capture that was made without the long-row path (graphed._long_bound: the first batches had no such row) stays
-    correct — the captured row kernel handles any row length.  Every step against the all-eager run: (a) bit for bit, (b)
-    within fp32 summation-order noise (the eager run reduces the hub row through the long-row queue)."""
+    captured SpMM launches read) is a new capture, not a truncated graph; (b) a batch with a row of 2 000 entries that FITS a
+    capture made without the long-row path (graphed._long_bound: the batches seen until then had no such row) replays it
+    and stays correct — the captured row kernel handles any row length.  Every step against the all-eager run: bit for bit
+    where both run the same kernels, within fp32 summation-order noise for the hub batches (the eager run reduces the hub row
+    through the long-row queue)."""
     from sgformer_amd import batching, graphed, ops, synth
     from sgformer_amd.ours import SGFormer
     n, f, c, d, m = 40000, 100, 47, 64, 8192
-    ei = _two_region_graph(n, 8192, 4)
+    ei = _two_region_graph(n, 4)
     gen = torch.Generator().manual_seed(9)
     tail = torch.arange(12000, n)
-    batches = [tail[torch.randperm(tail.numel(), generator=gen)[:m]] for _ in range(3)]            # sparse, no hub: the capture
-    batches.append(torch.arange(m))                                                                 # dense block + the hub row
-    batches.append(tail[torch.randperm(tail.numel(), generator=gen)[:m]])                          # and back
-    mix = torch.cat([torch.arange(0, 6100), tail[torch.randperm(tail.numel(), generator=gen)[:m - 6100]]])
-    batches.append(mix)                                                                             # hub row, modest nnz
+
+    def sparse():
+        return tail[torch.randperm(tail.numel(), generator=gen)[:m]]
+
+    def hubfit():                                      # node 0, 2 000 of its neighbours, the rest from the sparse region
+        rest = torch.arange(26000, n)
+        return torch.cat([torch.zeros(1, dtype=torch.long), torch.arange(20000, 22000),
+                          rest[torch.randperm(rest.numel(), generator=gen)[:m - 2001]]])
+
+    batches = [sparse(), sparse(), sparse(), hubfit(), torch.arange(10, 10 + m), sparse(), hubfit()]
     x = torch.randn(n, f, generator=gen).to(cuda)
 
     def run(graphs: bool):
@@ -297,13 +303,13 @@ def test_a_batch_beyond_the_captured_capacity_and_a_first_long_row(cuda, monkeyp
 
     eager, _, info = run(False)
     graph, used, _ = run(True)
-    nnz = [i[0] for i in info]
-    assert nnz[3] > 1.25 * max(nnz[:3]) + 4096, nnz             # the dense batch does not fit the first capture's arrays
-    assert info[3][1] > ops.LONG_ROW and info[5][1] > ops.LONG_ROW and max(i[1] for i in info[:3]) <= ops.LONG_ROW, info
-    assert nnz[5] <= 1.25 * nnz[3] + 4096                        # the mixed batch fits the SECOND capture's arrays: a replay
-    assert used["captures"] == 2 and used["replays"] == 5, used
-    for i in (0, 1, 2, 4):                                       # same kernels, same order: bit-identical
+    nnz, longest = [i[0] for i in info], [i[1] for i in info]
+    cap1 = int(nnz[1] * 1.25) + 4096                             # graphed._capture's capacity rule, from the capture batch
+    assert nnz[3] <= cap1 < nnz[4], (nnz, cap1)                  # the hub batch fits the first capture, the dense one does not
+    assert longest[3] > ops.LONG_ROW and longest[6] > ops.LONG_ROW and max(longest[:3] + [longest[4]]) <= ops.LONG_ROW, info
+    assert used == {"captures": 2, "replays": 6}, used
+    for i in (0, 1, 2, 4, 5):                                    # same kernels, same order: bit-identical
         assert torch.equal(eager[i], graph[i]), i
-    for i in (3, 5):                                             # the hub row: long-row queue (eager) vs row kernel (captured)
+    for i in (3, 6):                                             # the hub row: long-row queue (eager) vs row kernel (captured)
         scale = float(eager[i].abs().max())
         assert float((eager[i] - graph[i]).abs().max()) <= 2e-5 * max(1.0, scale), i

@@ -73,8 +73,22 @@ def _use_parent_csr() -> bool:
     return hasattr(ops.K, "subgraph_csr") and os.environ.get("SGF_SUBGRAPH_CSR", "1") != "0"
 
 
-def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
-             num_nodes: Optional[int] = None):
+def subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False, num_nodes: Optional[int] = None):
+    """torch_geometric.utils.subgraph — see _subgraph.  On the GPU the whole call (the index's H2D copy, the kernels, the one
+    device -> host read of the edge count) runs on the PREP stream (sgformer_amd/staging.py): the host read then waits for
+    the batch's own few kernels, not for the previous batch's backward; the compute stream takes the results through an event."""
+    from . import staging
+    if (ops.K.name == "hip" and staging.enabled() and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing()):
+        dev = edge_index.device if edge_index.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        with staging.on_prep(dev) as hand_over:
+            out, attr = _subgraph(subset, edge_index, edge_attr, relabel_nodes, num_nodes)
+            hand_over(out, attr, *(getattr(out, "_sgf_csr", None) or ()))
+        return out, attr
+    return _subgraph(subset, edge_index, edge_attr, relabel_nodes, num_nodes)
+
+
+def _subgraph(subset, edge_index, edge_attr=None, relabel_nodes: bool = False,
+              num_nodes: Optional[int] = None):
     """torch_geometric.utils.subgraph(subset, edge_index, edge_attr, relabel_nodes, num_nodes).
 
     relabel_nodes=True without edge attributes — the mini-batch trainer's call (large/main-batch.py:139) — takes the parent's

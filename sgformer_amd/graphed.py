@@ -136,6 +136,7 @@ class _Entry:
         self.params = ()
         self.param_ptrs = None
         self.failed = False
+        self.scratch = None        # the workspaces of the captured launches (kernels.begin_capture_scope)
         self.pending = None        # weakref to the last replay's backward hook until that backward has run
 
     def busy(self) -> bool:
@@ -145,8 +146,8 @@ class _Entry:
 
     def release(self):
         if self.core is not None:
-            _graveyard.append((self.core, self.graph))           # destroyed by collect(), not here
-        self.core = self.graph = self.pending = None
+            _graveyard.append((self.core, self.graph, self.scratch))           # destroyed by collect(), not here
+        self.core = self.graph = self.pending = self.scratch = None
         self.params, self.param_ptrs = (), None
 
 
@@ -206,6 +207,8 @@ def _capture(model, entry: _Entry, x, edge_index, cdt, out_dtype):
     gc.collect()
     gc_was_on = gc.isenabled()
     gc.disable()
+    from . import kernels as _kernels
+    entry.scratch = _kernels.begin_capture_scope()       # the captured launches' workspaces live (and die) with this entry
     try:
         # the sample input becomes the graphs' STATIC input, into which every later replay copies its batch: a private
         # buffer, not the caller's tensor (a trainer that keeps same-sized device batches across epochs would otherwise find
@@ -213,6 +216,7 @@ def _capture(model, entry: _Entry, x, edge_index, cdt, out_dtype):
         x_static = x.detach().clone()
         fn = torch.cuda.make_graphed_callables(step, (x_static,) + aliases, num_warmup_iters=0, allow_unused_input=True)
     finally:
+        _kernels.end_capture_scope()
         if gc_was_on:
             gc.enable()
         with torch.no_grad():           # (captured launches do not execute; kept in case a torch version warms up anyway)

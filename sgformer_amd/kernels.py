@@ -56,8 +56,35 @@ def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _workspaces: "dict[tuple, torch.Tensor]" = {}
 
 
+_capture_scope = None      # {(device index, name): tensor} while sgformer_amd.graphed captures a step, else None
+
+
+def begin_capture_scope() -> dict:
+    """Scratch requested while a step is being captured comes out of the graph's PRIVATE pool and its address is baked into
+    the captured launches: it must live exactly as long as those graphs.  A process-wide cache keyed on the stream does the
+    opposite — every capture runs on torch's one capture stream, so a later capture (another model, another batch size)
+    would be handed scratch from an earlier graph's pool, and once that graph is destroyed the captured kernels write into
+    unmapped memory (r06: `Memory access fault` in the eighth test of tests/test_gpu_graphed.py, never in isolation).  The
+    caller keeps the returned dict with the captured step."""
+    global _capture_scope
+    _capture_scope = {}
+    return _capture_scope
+
+
+def end_capture_scope():
+    global _capture_scope
+    _capture_scope = None
+
+
 def _workspace(device, name: str, nbytes: int) -> torch.Tensor:
     """Per-device, per-stream scratch reused across calls (users run on that stream, in order)."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if _capture_scope is None:           # somebody else's capture: fresh scratch from ITS pool, not cached here
+            return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        ws = _capture_scope.get((device.index, name))
+        if ws is None or ws.numel() < nbytes:
+            ws = _capture_scope[(device.index, name)] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return ws
     key = (device.index, name, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:

@@ -165,7 +165,13 @@ def patch_resident_features():
     def load_dataset(*args, **kwargs):
         ds = orig(*args, **kwargs)
         if torch.cuda.is_available() and torch.is_tensor(ds.graph.get("node_feat")):
-            ds.graph["node_feat"] = ds.graph["node_feat"].to(torch.device("cuda", torch.cuda.current_device()))
+            from . import staging
+            # ... as ResidentRows: `x[idx_i]` with the trainer's HOST index gathers on the prep stream, and the labels as
+            # StagedHost (still a host tensor): `true_label[idx_i].to(device)` copies there too — neither waits for the previous
+            # batch's backward (sgformer_amd/staging.py; SGF_PREP_STREAM=0: plain tensors, every copy on the current stream)
+            ds.graph["node_feat"] = staging.resident(ds.graph["node_feat"].to(torch.device("cuda", torch.cuda.current_device())))
+            if staging.enabled() and torch.is_tensor(getattr(ds, "label", None)):
+                ds.label = staging.staged(ds.label)
         return ds
 
     ds_mod.load_dataset = load_dataset

@@ -120,7 +120,8 @@ class LazyLogSoftmax(_torch.Tensor):
             # check.  nonzero() runs where the mask is (ATen's own indexing does the same), only the positions cross over.
             idx = args[1].nonzero().view(-1)
             if idx.numel() > 0:                 # (an empty selection: ATen's path and its nan)
-                return LazyLogSoftmax(args[0]._sgf_logits, idx.to(args[0]._sgf_logits.device), args[0]._sgf_orig)
+                from .staging import h2d        # (a host mask's positions cross over on the prep stream: no wait for the forward)
+                return LazyLogSoftmax(args[0]._sgf_logits, h2d(idx, args[0]._sgf_logits.device), args[0]._sgf_orig)
         with _torch._C.DisableTorchFunctionSubclass():
             if func in _META:                  # shape / dtype / device ... live on the wrapper: nothing is computed for them
                 return func(*args, **kwargs)

@@ -50,7 +50,7 @@ if ROOT not in sys.path:
 from sgformer_amd import ops, synth  # noqa: E402,F401  (tests/bench_modes.py reaches ops through this module)
 from benchlib.cpu import cpu_baseline  # noqa: E402
 from benchlib.model import per_rank_memory_model, scaling_model  # noqa: E402
-from benchlib.timers import SpmmTimer, step_roofline  # noqa: E402,F401
+from benchlib.timers import SpmmTimer, pmc_traffic, spmm_source_sha16, step_roofline  # noqa: E402,F401  (scripts/pmc_summarise.py reads the hash here)
 from benchlib.workloads import _sharded, make_inputs, run_minibatch, run_workload  # noqa: E402,F401
 
 def parse():

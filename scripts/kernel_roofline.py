@@ -111,7 +111,8 @@ def main(path: str, elem: int):
         ("k_sum_n_bf16x8<7>", ("k_sum_n_bf16x8<7>",), 8 * T, "fan-out hub gradient", find),
         ("k_sum_n_bf16x8<6>", ("k_sum_n_bf16x8<6>",), 7 * T, "x0's gradient: three dz W2 and three residual gradients", find),
         ("k_head_fwd_bf16  (sgf_combine_fc_fwd)", ("k_head_fwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "x1, x2 -> logits", find),
-        ("k_head_bwd_bf16  (sgf_combine_fc_bwd)", ("k_head_bwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9, "dlogits -> dx1, dx2", find),
+        ("k_head_bwd_bf16  (sgf_combine_fc_bwd_g)", ("k_head_bwd_bf16<256>",), 2 * T + N * 47 * 4 / 1e9 + (GC if find("k_gramx<0>")[0] else 0.0),
+         "dlogits -> dx1, dx2" + (" and (r06) the bf16 [N, 48] operand of the head's dW" if find("k_gramx<0>")[0] else ""), find),
         ("k_axpby", ("k_axpby<" + tname,), 3 * T, "", find),
     ]
     if find("k_rowgemm_bf16<")[0]:    # r02 on: the square layers run on k_rowgemm_bf16, the library keeps the two input stems

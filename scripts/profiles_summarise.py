@@ -57,6 +57,8 @@ def counters(src, tag):
             continue
         for r in csv.DictReader(open(path)):
             agg[short(r["Kernel_Name"]).split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not agg:
+        return
     names = sorted({c for k in agg.values() for c in k})
     rows = []
     for k, cs in sorted(agg.items()):
@@ -88,11 +90,10 @@ def counters(src, tag):
         f.write(m[cols].to_markdown(index=False) + "\n\n")
         f.write("Reading: every MFMA kernel of the bf16 step is HBM-bound by design (DESIGN.md §3: 2 N d^2 flop per [N, d] pass at "
                 "2.5 PF is 0.13 ms against 0.4-0.6 ms of HBM time), so the matrix pipe is busy 5-30 % of the time.  The per-wave "
-                "streaming kernels of csrc/rowgemm.hip (`k_rowgemm_bf16`, `k_hrow_bf16`) and the 16-wave Gram reduce carry the "
-                "same MFMA count per byte as hipBLASLt's GEMM did and finish sooner (profiles/"
-                f"{tag}_products_bf16_kernel_roofline.md), i.e. their matrix pipe is busier; `k_reduce_bf16<256, 4, 8>` "
-                "(the attention backward reduce, 8 waves, one staging pass in flight) is the one "
-                f"left waiting.  Full table: profiles/{tag}_mfma_sq_counters.csv.\n")
+                "streaming kernels of csrc/rowgemm.hip (`k_rowgemm_bf16`, `k_hrow_bf16`) and the node reductions of csrc/gramx.hip "
+                "(`k_gramx`, `k_gramt`: tiles by LDS-DMA, r06) carry the same MFMA count per byte as hipBLASLt's GEMM did and "
+                f"finish sooner (profiles/{tag}_products_bf16_kernel_roofline.md), i.e. their matrix pipe is busier.  "
+                f"Full table: profiles/{tag}_mfma_sq_counters.csv.\n")
 
 
 def main():

@@ -298,3 +298,32 @@ def test_minimal_mode_installs_the_module_and_nothing_else(tmp_path, monkeypatch
         torch.optim.Adam.__init__ = adam0
         launch.unpatch_nll_loss()
         torch.set_num_threads(threads)
+
+
+def test_staging_wrappers_are_plain_tensors_without_a_gpu():
+    """sgformer_amd/staging.py on a host without CUDA (or with SGF_PREP_STREAM=0): the wrappers the launcher puts around the
+    mini-batch trainer's features / labels behave as the tensors they wrap — same values, plain results, host semantics of
+    the labels untouched (large/main-batch.py:45-46, :66, :102-107, :115-116 all run on them)."""
+    from sgformer_amd import staging
+    lab = torch.randint(0, 5, (50,))
+    ls = staging.staged(lab)
+    assert isinstance(ls, staging.StagedHost) and not ls.is_cuda and torch.equal(ls.as_subclass(torch.Tensor), lab)
+    ls = ls.unsqueeze(1)                                        # :46
+    assert isinstance(ls, staging.StagedHost) and ls.shape == (50, 1)
+    assert int(max(ls.max().item() + 1, ls.shape[1])) == int(lab.max()) + 1      # :66
+    one_hot = F.one_hot(ls, int(ls.max()) + 1).squeeze(1)      # :103
+    assert type(one_hot) is torch.Tensor and one_hot.shape == (50, int(lab.max()) + 1)
+    idx = torch.randperm(50)[:20]
+    rows = ls[idx]
+    assert isinstance(rows, staging.StagedHost) and torch.equal(rows.as_subclass(torch.Tensor), lab.unsqueeze(1)[idx])
+    assert type(rows.to(torch.float)) is torch.Tensor and type(rows.to("cpu")) in (torch.Tensor, staging.StagedHost)
+    mask = torch.zeros(50, dtype=torch.bool)
+    mask[ls.squeeze(1) == 2] = True                             # comparisons / mask building on the host
+    assert int(mask.sum()) == int((lab == 2).sum())
+    assert rows.numpy().shape == (20, 1) and type(ls + 1) is torch.Tensor
+    x = torch.randn(50, 8)
+    assert staging.resident(x) is x                             # a host tensor is left alone
+    assert staging._cuda_target((ls, torch.device("cuda", 0)), {}) == torch.device("cuda", 0)
+    assert staging._cuda_target((ls, "cuda:1"), {"non_blocking": True}) == torch.device("cuda", 1)
+    assert staging._cuda_target((ls, torch.float32), {}) is None and staging._cuda_target((ls, "cpu"), {}) is None
+    assert staging._cuda_target((ls, torch.device("cuda", 0), torch.float16), {}) is None

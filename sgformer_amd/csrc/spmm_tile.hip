@@ -148,6 +148,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
       const uint32_t dst = smem_lds + static_cast<uint32_t>(slot * kSlotBytes + (unit0_w + 2 * pc) * 512);
       const unsigned char* gp = g + pc * 128;
       uint32_t keep;
+      if (dbg & 4)                                         // timing experiment: the staged rows as a non-temporal stream
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gp), "s"(dst)
+            : "memory");
+      else
       asm volatile(
           "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
           : "=&s"(keep)
@@ -281,6 +288,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
       const uint32_t d = dst + static_cast<uint32_t>(i * 1024);
       const unsigned char* gp = g + i * 1024;
       uint32_t keep;
+      if (dbg & 512)                                       // timing experiment: the packed tiles as a non-temporal stream
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gp), "s"(d)
+            : "memory");
+      else
       asm volatile(                                        // (LDS reads of what is being replaced have completed)
           "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
           "s_mov_b32 m0, %0"
@@ -410,6 +425,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
   };
   uint16_t* __restrict__ yl = y + r_base * ldy + (active ? fc : 0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs =
+      __builtin_amdgcn_make_buffer_rsrc(y + r_base * ldy, 0, static_cast<int>(32 * ldy * 2), 0x00020000);
 
   for (uint64_t mk = long_mask; mk != 0; mk &= mk - 1) {   // hubs: queued for the workgroup-per-segment kernels
     const int j = __builtin_ctzll(mk);
@@ -459,8 +476,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
     auto issue = [&](int b0, u32x4 (&rg)[B]) {
       const uint32_t* so = stash_off + 2 * b0 + half;
 #pragma unroll
-      for (int j = 0; j < B; ++j)
-        rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
+      for (int j = 0; j < B; ++j) {
+        if (dbg & 4096) {                                  // traffic experiment: far sources (> 16384 rows away) non-temporal
+          const uint32_t o0 = __builtin_amdgcn_readfirstlane(stash_off[2 * (b0 + j)]);
+          const uint32_t here = static_cast<uint32_t>(row0) * pitch;
+          const uint32_t dist = o0 > here ? o0 - here : here - o0;
+          if (dist > 16384u * pitch)
+            rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 2);
+          else
+            rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
+        } else
+        if (dbg & 1024)                                    // timing experiment: every gather a non-temporal load
+          rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 2);
+        else if (dbg & 2048)                               // ... an sc1 load
+          rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 16);
+        else
+          rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(so[2 * j] + lanebase), 0, 0);
+      }
     };
     // THREE register sets of B pair loads: the fabric answers a gather in ~1.3 us under load while a set is consumed in
     // ~0.45 us, so with two sets (16 KiB in flight per wave, 8 waves per CU) the loop ran at the memory latency:
@@ -543,6 +575,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_spmm_tile_bf16(
         o.z = pack_bf16(p1.x, p1.y);
         o.w = pack_bf16(p1.z, p1.w);
         if (dbg & 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(yl + (16 * h + lr) * ldy));
+        else if (dbg & 256)                                // timing experiment: write-through stores, the line leaves the L2
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs,
+                                                 static_cast<int>(((16 * h + lr) * ldy + fc) * 2), 0, 16);
         else *reinterpret_cast<uint4*>(yl + (16 * h + lr) * ldy) = o;
       }
     }
@@ -599,7 +634,7 @@ extern "C" int sgf_spmm_tile(const int32_t* blk_row, int64_t nb, int32_t block_r
   }
   TilePlanArgs P{blk_row, sh_ptr, sh_cols, tile_ptr, grp, static_cast<const uint4*>(pool), rem_rowptr, rem_col, rem_val};
   // SGF_SPMM_TILE_DEBUG (timing experiments only, results are then wrong): 1 = skip the tile phase, 2 = skip the gathers,
-  // 4 / 8 = nt fragment loads / y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
+  // 4 / 512 = nt staged rows / packed tiles, 8 / 256 = nt / write-through (sc1) y stores, 16 = gathers clamped to 4096 rows (L2 hits), 32 = no multiply-adds in the gather
   // loop, 128 = no matrix-core work in the tile phase
   // (both switches are cached: a launch costs no environment look-up; sgf_reload_env() re-reads them)
   static EnvInt chunk_env{"SGF_SPMM_TILE_CHUNK", 64};

@@ -543,6 +543,201 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
   }
 }
 
+// ---- bf16 rows of d = 8 k elements, 16-byte aligned: 16 bytes per lane and load ---------------------------------------
+// The kernels above move a bf16 row as 8 bytes per lane (4 columns): 512 bytes per wave instruction.  On MI355X that form
+// streams at 4.5-4.8 TB/s where ATen's 16-byte elementwise kernels reach 5.7-6.0 on the same read : write mix
+// (scripts/hbm_mix_probe.py).  Same thread map — a thread keeps its column chunk, so the coefficients stay in registers —
+// with 8 columns per thread and a CONTIGUOUS run of rpp * kRowUnroll rows per block pass.  Per-element arithmetic is the
+// x4 kernels' (the reference's order of operations); only the vector width and, for the statistics, the order in which
+// rows are added differ.
+typedef __bf16 ew_bf16v2 __attribute__((ext_vector_type(2)));
+typedef float ew_f32v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ew_pack(float a, float b) {      // v_cvt_pk_bf16_f32: round-to-nearest-even
+  const ew_f32v2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ew_bf16v2));
+}
+__device__ __forceinline__ void ew_unpack(const uint4& r, float (&v)[8]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ew_pack8(const float (&o)[8]) {
+  return make_uint4(ew_pack(o[0], o[1]), ew_pack(o[2], o[3]), ew_pack(o[4], o[5]), ew_pack(o[6], o[7]));
+}
+struct BnCoeffs8 {
+  float mu[8], rs[8], ga[8], be[8];
+};
+__device__ __forceinline__ void bn_coeffs8(const BnParams& p, int col, BnCoeffs8& c) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    c.mu[e] = p.mean[col + e];
+    c.rs[e] = p.rstd[col + e];
+    c.ga[e] = p.gamma ? p.gamma[col + e] : 1.f;
+    c.be[e] = p.beta ? p.beta[col + e] : 0.f;
+  }
+}
+
+template <bool kRes>
+__global__ __launch_bounds__(kThreads) void k_bn_apply_bf16x8(const uint16_t* __restrict__ x, int64_t ldx, BnParams p,
+                                                              const uint16_t* __restrict__ res, int64_t ldr, int relu,
+                                                              int64_t n, int d, uint16_t* __restrict__ y, int64_t ldy) {
+  const int f8 = d / 8;
+  const int rpp = kThreads / f8;
+  const int sr = threadIdx.x / f8;
+  if (sr >= rpp) return;
+  const int col = (threadIdx.x % f8) * 8;
+  BnCoeffs8 c;
+  bn_coeffs8(p, col, c);
+  const int64_t rpb = static_cast<int64_t>(rpp) * kRowUnroll;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * rpb + sr; row0 < n; row0 += static_cast<int64_t>(gridDim.x) * rpb) {
+    uint4 xv[kRowUnroll], rv[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * rpp;
+      if (row < n) {
+        xv[u] = *reinterpret_cast<const uint4*>(x + row * ldx + col);
+        if (kRes) rv[u] = *reinterpret_cast<const uint4*>(res + row * ldr + col);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * rpp;
+      if (row < n) {
+        float v[8], r[8], o[8];
+        ew_unpack(xv[u], v);
+        if (kRes) ew_unpack(rv[u], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = fmaf((v[e] - c.mu[e]) * c.rs[e], c.ga[e], c.be[e]);   // (explicitly what hipcc contracts the x4 kernel to)
+          if (relu) o[e] = fmaxf(o[e], 0.f);
+          if (kRes) o[e] += r[e];
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + col) = ew_pack8(o);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply_bf16x8(
+    const uint16_t* __restrict__ dy, int64_t lddy, const uint16_t* __restrict__ x, int64_t ldx, BnParams p, int relu,
+    const float* __restrict__ stats, float inv_n, int training, int64_t n, int d, uint16_t* __restrict__ dx, int64_t lddx) {
+  const int f8 = d / 8;
+  const int rpp = kThreads / f8;
+  const int sr = threadIdx.x / f8;
+  if (sr >= rpp) return;
+  const int col = (threadIdx.x % f8) * 8;
+  BnCoeffs8 c;
+  bn_coeffs8(p, col, c);
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s0[e] = training ? stats[col + e] : 0.f;
+    s1[e] = training ? stats[d + col + e] : 0.f;
+  }
+  const int64_t rpb = static_cast<int64_t>(rpp) * kRowUnroll;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * rpb + sr; row0 < n; row0 += static_cast<int64_t>(gridDim.x) * rpb) {
+    uint4 xv[kRowUnroll], gv[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * rpp;
+      if (row < n) {
+        xv[u] = *reinterpret_cast<const uint4*>(x + row * ldx + col);
+        gv[u] = *reinterpret_cast<const uint4*>(dy + row * lddy + col);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const int64_t row = row0 + u * rpp;
+      if (row < n) {
+        float v[8], g[8], o[8];
+        ew_unpack(xv[u], v);
+        ew_unpack(gv[u], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[e] - c.mu[e]) * c.rs[e];
+          float ge = g[e];
+          if (relu) ge = fmaf(xh, c.ga[e], c.be[e]) > 0.f ? ge : 0.f;
+          if (training) ge -= s0[e] * inv_n + xh * s1[e] * inv_n;
+          o[e] = c.ga[e] * c.rs[e] * ge;
+        }
+        *reinterpret_cast<uint4*>(dx + row * lddx + col) = ew_pack8(o);
+      }
+    }
+  }
+}
+
+// BnBwdStatsF over bf16 rows, 8 columns per thread: part[blk][2][d] like k_colreduce
+template <bool kTwo>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_stats_bf16x8(
+    const uint16_t* __restrict__ dy, int64_t lddy, const uint16_t* __restrict__ dy2, int64_t lddy2,
+    const uint16_t* __restrict__ x, int64_t ldx, BnParams p, int relu, int64_t n, int d, float* __restrict__ part) {
+  __shared__ float red[2 * kThreads * 8];
+  const int f8 = d / 8;
+  const int rpp = kThreads / f8;
+  const int c8 = threadIdx.x % f8;
+  const int sr = threadIdx.x / f8;
+  const bool act = sr < rpp;
+  const int col = c8 * 8;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (act) {
+    BnCoeffs8 c;
+    bn_coeffs8(p, col, c);
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    auto add_row = [&](const uint4& xr, const uint4& gr, const uint4& g2r) {
+      float v[8], g[8], g2[8];
+      ew_unpack(xr, v);
+      ew_unpack(gr, g);
+      if (kTwo) ew_unpack(g2r, g2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float ge = kTwo ? g[e] + g2[e] : g[e];
+        const float xh = (v[e] - c.mu[e]) * c.rs[e];
+        if (relu) ge = fmaf(xh, c.ga[e], c.be[e]) > 0.f ? ge : 0.f;
+        s0[e] += ge;
+        s1[e] += ge * xh;
+      }
+    };
+    int64_t row = r0 + sr;
+    for (; row + (kRowUnroll - 1) * static_cast<int64_t>(rpp) < r1; row += kRowUnroll * static_cast<int64_t>(rpp)) {
+      uint4 xv[kRowUnroll], gv[kRowUnroll], hv[kRowUnroll];
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        const int64_t rr = row + u * static_cast<int64_t>(rpp);
+        xv[u] = *reinterpret_cast<const uint4*>(x + rr * ldx + col);
+        gv[u] = *reinterpret_cast<const uint4*>(dy + rr * lddy + col);
+        if (kTwo) hv[u] = *reinterpret_cast<const uint4*>(dy2 + rr * lddy2 + col);
+      }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) add_row(xv[u], gv[u], kTwo ? hv[u] : gv[u]);
+    }
+    for (; row < r1; row += rpp) {
+      const uint4 xr = *reinterpret_cast<const uint4*>(x + row * ldx + col);
+      const uint4 gr = *reinterpret_cast<const uint4*>(dy + row * lddy + col);
+      const uint4 hr = kTwo ? *reinterpret_cast<const uint4*>(dy2 + row * lddy2 + col) : gr;
+      add_row(xr, gr, hr);
+    }
+  }
+  // red[which][slot sr][column]: the same fixed-order sum over the row slots as k_colreduce
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(0 * kThreads + threadIdx.x) * 8 + e] = s0[e];
+    red[(1 * kThreads + threadIdx.x) * 8 + e] = s1[e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * d; j += kThreads) {
+    const int which = j / d, cc = j % d;
+    float s = 0.f;
+    for (int r = 0; r < rpp; ++r) s += red[(which * kThreads + r * f8 + cc / 8) * 8 + (cc & 7)];
+    part[static_cast<int64_t>(blockIdx.x) * 2 * d + j] = s;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_axpby(const T* __restrict__ x1, int64_t ld1, float a,
                                                     const T* __restrict__ x2, int64_t ld2, float b,
@@ -1025,6 +1220,22 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const voi
   return SGF_OK;
 }
 
+// bf16 rows the 16-byte-per-lane kernels take: d a multiple of 8 with at most kThreads chunks, every row 16-byte aligned
+// (SGF_EW8=0: the 8-byte kernels, for A/B)
+inline bool ew8_rows(int d, std::initializer_list<std::pair<const void*, int64_t>> ops) {
+  static EnvInt ew8{"SGF_EW8", 1};
+  if (ew8.get() == 0 || d % 8 != 0 || d / 8 > kThreads) return false;
+  for (const auto& o : ops)
+    if (o.first && (reinterpret_cast<uintptr_t>(o.first) % 16 != 0 || o.second % 8 != 0)) return false;
+  return true;
+}
+inline int rowwalk8_grid(int64_t n, int d) {
+  const int64_t rpb = static_cast<int64_t>(kThreads / (d / 8)) * kRowUnroll;
+  int64_t b = (n + rpb - 1) / rpb;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  return static_cast<int>(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
 template <typename F>
 int colreduce(F f, int64_t n, int d, float* stats, void* ws, hipStream_t st) {
   const int nblk = stat_blocks(n);
@@ -1158,6 +1369,17 @@ extern "C" int sgf_bn_apply(const void* x, int64_t ldx, const float* mean, const
               "sgf_bn_apply: leading dims must be multiples of 4");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BnParams p{mean, rstd, gamma, beta};
+  if (dtype == SGF_BF16 && ew8_rows(d, {{x, ldx}, {res, ldr}, {y, ldy}})) {
+    const dim3 g8(rowwalk8_grid(n, d));
+    if (res)
+      hipLaunchKernelGGL((k_bn_apply_bf16x8<true>), g8, dim3(kThreads), 0, st, static_cast<const uint16_t*>(x), ldx, p,
+                         static_cast<const uint16_t*>(res), ldr, relu, n, d, static_cast<uint16_t*>(y), ldy);
+    else
+      hipLaunchKernelGGL((k_bn_apply_bf16x8<false>), g8, dim3(kThreads), 0, st, static_cast<const uint16_t*>(x), ldx, p,
+                         static_cast<const uint16_t*>(res), ldr, relu, n, d, static_cast<uint16_t*>(y), ldy);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const dim3 grid(rowwalk_grid(n, d));
   if (dtype == SGF_F32)
     hipLaunchKernelGGL((k_bn_apply<float>), grid, dim3(kThreads), 0, st,
@@ -1188,6 +1410,22 @@ extern "C" int sgf_bn_bwd_stats2(const void* dy, int64_t lddy, const void* dy2, 
   SGF_REQUIRE(workspace && workspace_bytes >= sgf_colstats_workspace_bytes(n, d), SGF_E_WORKSPACE,
               "sgf_bn_bwd_stats2: workspace too small");
   const BnParams p{mean, rstd, gamma, beta};
+  if (dtype == SGF_BF16 && ew8_rows(d, {{dy, lddy}, {dy2, lddy2}, {x, ldx}})) {
+    const int nblk = stat_blocks(n);
+    float* part = static_cast<float*>(workspace);
+    if (dy2)
+      hipLaunchKernelGGL((k_bn_bwd_stats_bf16x8<true>), dim3(nblk), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dy),
+                         lddy, static_cast<const uint16_t*>(dy2), lddy2, static_cast<const uint16_t*>(x), ldx, p, relu, n, d,
+                         part);
+    else
+      hipLaunchKernelGGL((k_bn_bwd_stats_bf16x8<false>), dim3(nblk), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dy),
+                         lddy, static_cast<const uint16_t*>(dy2), lddy2, static_cast<const uint16_t*>(x), ldx, p, relu, n, d,
+                         part);
+    SGF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 7) / 8), dim3(256), 0, st, part, nblk, 2 * d, stats, stats + d, d);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   if (dtype == SGF_F32)
     return colreduce(BnBwdStatsF<float>{static_cast<const float*>(dy), lddy, static_cast<const float*>(x), ldx, p, relu,
                                         static_cast<const float*>(dy2), lddy2},
@@ -1220,6 +1458,13 @@ extern "C" int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int
               "sgf_bn_bwd_apply: leading dims must be multiples of 4");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BnParams p{mean, rstd, gamma, beta};
+  if (dtype == SGF_BF16 && ew8_rows(d, {{dy, lddy}, {x, ldx}, {dx, lddx}})) {
+    hipLaunchKernelGGL(k_bn_bwd_apply_bf16x8, dim3(rowwalk8_grid(n, d)), dim3(kThreads), 0, st,
+                       static_cast<const uint16_t*>(dy), lddy, static_cast<const uint16_t*>(x), ldx, p, relu, stats, inv_n,
+                       training, n, d, static_cast<uint16_t*>(dx), lddx);
+    SGF_LAUNCH_CHECK();
+    return SGF_OK;
+  }
   const dim3 grid(rowwalk_grid(n, d));
   if (dtype == SGF_F32)
     hipLaunchKernelGGL((k_bn_bwd_apply<float>), grid, dim3(kThreads), 0, st,

@@ -56,6 +56,8 @@ def main():
     setenv(1)
     stats = K.bn_bwd_stats(gy, x, mean, rstd, gamma, beta, True)
     cases["bn_bwd_apply (2R:1W)"] = (lambda: K.bn_bwd_apply(gy, x, mean, rstd, gamma, beta, True, stats, 1.0 / n, True), 3 * T)
+    y_ln, mu_ln, rs_ln = K.ln_fwd(x, res, 0.5, 0.5, gamma, beta, True, 1e-5)
+    cases["ln_bwd, shared dx (4R:1W)"] = (lambda: K.ln_bwd(gy, y_ln, x, res, 0.5, 0.5, gamma, True, mu_ln, rs_ln)[0], 5 * T)
     out = []
     for name, (fn, gb) in cases.items():
         row = {"case": name}

@@ -667,6 +667,117 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply_bf16x8(
   }
 }
 
+// k_ln_bwd for bf16 rows of d = 8 * LPR elements, 16-byte aligned: 16 bytes per lane and load, R rows per lane in flight.
+// Per-element arithmetic as in k_ln_bwd; a row's two sums are taken 8 per lane, then over the LPR lanes.
+template <int LPR, int R>
+__global__ __launch_bounds__(kThreads) void k_ln_bwd_bf16x8(
+    const uint16_t* __restrict__ dy, int64_t lddy, const uint16_t* __restrict__ y, int64_t ldy, const uint16_t* __restrict__ x,
+    int64_t ldx, const uint16_t* __restrict__ res, int64_t ldr, float a, float b, const float* __restrict__ gamma, int relu,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int64_t n, uint16_t* __restrict__ dxo, int64_t lddx,
+    uint16_t* __restrict__ dro, int64_t lddr, float* __restrict__ part) {
+  constexpr int RPS = kThreads / LPR;
+  constexpr int RPB = RPS * R;
+  constexpr int D = 8 * LPR;
+  constexpr float inv_d = 1.0f / static_cast<float>(D);
+  __shared__ float red[2 * RPS * D];
+  const int sl = threadIdx.x % LPR;
+  const int sr = threadIdx.x / LPR;
+  const int col = sl * 8;
+  const bool ln = gamma != nullptr;
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gm[e] = ln ? gamma[col + e] : 1.f;
+    dg[e] = db[e] = 0.f;
+  }
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * RPB; row0 < n; row0 += static_cast<int64_t>(gridDim.x) * RPB) {
+    uint4 gv[R], yv[R], xv[R], rv[R];
+    float mu[R], rs[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int64_t row = row0 + q * RPS + sr;
+      const int64_t rr = row < n ? row : n - 1;
+      gv[q] = *reinterpret_cast<const uint4*>(dy + rr * lddy + col);
+      if (relu) yv[q] = *reinterpret_cast<const uint4*>(y + rr * ldy + col);
+      if (ln) {
+        xv[q] = *reinterpret_cast<const uint4*>(x + rr * ldx + col);
+        if (res) rv[q] = *reinterpret_cast<const uint4*>(res + rr * ldr + col);
+      }
+      mu[q] = ln ? mean[rr] : 0.f;
+      rs[q] = ln ? rstd[rr] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int64_t row = row0 + q * RPS + sr;
+      const bool rok = row < n;
+      float g[8], h[8];
+      ew_unpack(gv[q], g);
+      if (relu) {
+        float yy[8];
+        ew_unpack(yv[q], yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+      }
+      float s1 = 0.f, s2 = 0.f;
+      if (ln) {
+        float v[8];
+        ew_unpack(xv[q], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a;
+        if (res) {
+          float r[8];
+          ew_unpack(rv[q], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(b, r[e], v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          h[e] = (v[e] - mu[q]) * rs[q];
+          if (rok) {
+            dg[e] += g[e] * h[e];
+            db[e] += g[e];
+          }
+          g[e] *= gm[e];                                   // dxhat
+          s1 += g[e];
+          s2 += g[e] * h[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = 0.f;
+      }
+      float m1 = 0.f, m2 = 0.f;
+      if (ln) {
+        m1 = group_sum<LPR>(s1) * inv_d;
+        m2 = group_sum<LPR>(s2) * inv_d;
+      }
+      if (rok) {
+        float o[8], o2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dp = ln ? rs[q] * (g[e] - m1 - h[e] * m2) : g[e];
+          o[e] = a * dp;
+          o2[e] = b * dp;
+        }
+        *reinterpret_cast<uint4*>(dxo + row * lddx + col) = ew_pack8(o);
+        if (dro != nullptr) *reinterpret_cast<uint4*>(dro + row * lddr + col) = ew_pack8(o2);
+      }
+    }
+  }
+  if (!ln) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(0 * RPS + sr) * D + col + e] = dg[e];
+    red[(1 * RPS + sr) * D + col + e] = db[e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * D; j += kThreads) {
+    const int which = j / D, cc = j % D;
+    float s = 0.f;
+    for (int r = 0; r < RPS; ++r) s += red[(which * RPS + r) * D + cc];
+    part[static_cast<int64_t>(blockIdx.x) * 2 * D + j] = s;
+  }
+}
+
 // BnBwdStatsF over bf16 rows, 8 columns per thread: part[blk][2][d] like k_colreduce
 template <bool kTwo>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats_bf16x8(
@@ -1165,6 +1276,22 @@ inline int ln_bwd_grid(int64_t n, int lpr) {
   return static_cast<int>(b);
 }
 
+// bf16 rows the 16-byte-per-lane kernels take: d a multiple of 8 with at most kThreads chunks, every row 16-byte aligned
+// (SGF_EW8=0: the 8-byte kernels, for A/B)
+inline bool ew8_rows(int d, std::initializer_list<std::pair<const void*, int64_t>> ops) {
+  static EnvInt ew8{"SGF_EW8", 1};
+  if (ew8.get() == 0 || d % 8 != 0 || d / 8 > kThreads) return false;
+  for (const auto& o : ops)
+    if (o.first && (reinterpret_cast<uintptr_t>(o.first) % 16 != 0 || o.second % 8 != 0)) return false;
+  return true;
+}
+inline int rowwalk8_grid(int64_t n, int d) {
+  const int64_t rpb = static_cast<int64_t>(kThreads / (d / 8)) * kRowUnroll;
+  int64_t b = (n + rpb - 1) / rpb;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  return static_cast<int>(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
 template <typename T>
 int ln_fwd_t(const void* x, int64_t ldx, const void* res, int64_t ldr, float a, float b,
              const float* gamma, const float* beta, int relu, float eps, int64_t n, int d, void* y,
@@ -1203,10 +1330,36 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const voi
              const void* res, int64_t ldr, float a, float b, const float* gamma, int relu,
              const float* mean, const float* rstd, int64_t n, int d, void* dx, int64_t lddx,
              void* dres, int64_t lddres, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+  float* part = static_cast<float*>(ws);
+  if (sizeof(T) == 2 && (d == 64 || d == 128 || d == 256 || d == 512) &&
+      ew8_rows(d, {{dy, lddy}, {relu ? y : nullptr, ldy}, {gamma ? x : nullptr, ldx}, {gamma ? res : nullptr, ldr}, {dx, lddx},
+                   {dres, lddres}})) {
+    constexpr int R = 2;
+    const int l8 = d / 8;
+    const int rpb = kThreads / l8 * R;
+    int64_t nb = (n + rpb - 1) / rpb;
+    if (nb > kMaxStatBlocks) nb = kMaxStatBlocks;
+    const int nblk8 = static_cast<int>(nb < 1 ? 1 : nb);
+#define SGF_LNB8(L)                                                                                                    \
+  hipLaunchKernelGGL((k_ln_bwd_bf16x8<L, R>), dim3(nblk8), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dy), lddy, \
+                     static_cast<const uint16_t*>(y), ldy, static_cast<const uint16_t*>(x), ldx,                        \
+                     static_cast<const uint16_t*>(res), ldr, a, b, gamma, relu, mean, rstd, n, static_cast<uint16_t*>(dx), \
+                     lddx, static_cast<uint16_t*>(dres), lddres, part)
+    if (l8 == 8) SGF_LNB8(8);
+    else if (l8 == 16) SGF_LNB8(16);
+    else if (l8 == 32) SGF_LNB8(32);
+    else SGF_LNB8(64);
+#undef SGF_LNB8
+    SGF_LAUNCH_CHECK();
+    if (gamma != nullptr && (dgamma || dbeta)) {
+      hipLaunchKernelGGL(k_sum_partials, dim3((2 * d + 7) / 8), dim3(256), 0, st, part, nblk8, 2 * d, dgamma, dbeta, d);
+      SGF_LAUNCH_CHECK();
+    }
+    return SGF_OK;
+  }
   const int lpr = lanes_per_row(d);
   const int nc = (d + 4 * lpr - 1) / (4 * lpr);
   const int nblk = ln_bwd_grid(n, lpr);
-  float* part = static_cast<float*>(ws);
   int rc = launch_ln_bwd<T>(lpr, nc, dim3(nblk), st, static_cast<const T*>(dy), lddy,
                             static_cast<const T*>(y), ldy, static_cast<const T*>(x), ldx,
                             static_cast<const T*>(res), ldr, a, b, gamma, relu, mean, rstd, n, d,
@@ -1218,22 +1371,6 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* y, int64_t ldy, const voi
     SGF_LAUNCH_CHECK();
   }
   return SGF_OK;
-}
-
-// bf16 rows the 16-byte-per-lane kernels take: d a multiple of 8 with at most kThreads chunks, every row 16-byte aligned
-// (SGF_EW8=0: the 8-byte kernels, for A/B)
-inline bool ew8_rows(int d, std::initializer_list<std::pair<const void*, int64_t>> ops) {
-  static EnvInt ew8{"SGF_EW8", 1};
-  if (ew8.get() == 0 || d % 8 != 0 || d / 8 > kThreads) return false;
-  for (const auto& o : ops)
-    if (o.first && (reinterpret_cast<uintptr_t>(o.first) % 16 != 0 || o.second % 8 != 0)) return false;
-  return true;
-}
-inline int rowwalk8_grid(int64_t n, int d) {
-  const int64_t rpb = static_cast<int64_t>(kThreads / (d / 8)) * kRowUnroll;
-  int64_t b = (n + rpb - 1) / rpb;
-  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
-  return static_cast<int>(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 template <typename F>

@@ -111,3 +111,51 @@ def test_bn_backward_bf16_rows(cuda, both_paths, n, d, pad, relu, training, two)
     ref = gamma.double() * rstd.double() * ge
     err = (dx8.double() - ref).abs()
     assert bool((err <= 0.51 * _ulp(ref) + 1e-5).all())
+
+
+@pytest.mark.parametrize("n", [1, 33, 1531, 70001])
+@pytest.mark.parametrize("d,pad", [(256, 0), (64, 0), (128, 8), (512, 0), (100, 0), (256, 4)])
+@pytest.mark.parametrize("relu,use_ln,use_res,a,b", [(True, True, True, 0.5, 0.5), (False, True, True, 0.3, 0.7),
+                                                    (True, True, False, 1.0, 0.0), (True, False, True, 0.5, 0.5)])
+def test_ln_backward_bf16_rows(cuda, both_paths, n, d, pad, relu, use_ln, use_res, a, b):
+    """k_ln_bwd_bf16x8 (large/ours.py:205-211 differentiated: residual mix, LayerNorm, relu) against the 8-byte kernel and
+    against fp64 autograd of the same bf16 inputs."""
+    from sgformer_amd import ops
+    K = ops.K
+    x, gy, _, res, *_ = _inputs(cuda, n, d, pad, 11 * n + d)
+    g = torch.Generator(device=cuda).manual_seed(d)
+    gamma = (torch.rand(d, device=cuda, generator=g) + 0.5) if use_ln else None
+    beta = (torch.randn(d, device=cuda, generator=g) * 0.1) if use_ln else None
+    r = res if use_res else None
+    _ew8(1)
+    y, mean, rstd = K.ln_fwd(x, r, a, b, gamma, beta, relu, 1e-5)
+    out = {}
+    for v in (1, 0):
+        _ew8(v)
+        out[v] = K.ln_bwd(gy, y, x, r, a, b, gamma, relu, mean, rstd)
+    # fp64 autograd of the same computation (mask from the forward's stored y, as the kernels take it)
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True)
+    pre = a * xd + (b * rd if use_res else 0.0)
+    gd = gamma.double().requires_grad_(True) if use_ln else None
+    bd = beta.double().requires_grad_(True) if use_ln else None
+    z = torch.nn.functional.layer_norm(pre, (d,), gd, bd, 1e-5) if use_ln else pre
+    gyd = gy.double()
+    if relu:
+        gyd = torch.where(y.double() > 0, gyd, torch.zeros_like(gyd))
+    z.backward(gyd)
+    for v in (1, 0):
+        dx, dres, dgamma, dbeta = out[v]
+        tol = 0.51 * _ulp(xd.grad) + 3e-5 * (gy.double().abs().amax() + 1)
+        assert bool(((dx.double() - xd.grad).abs() <= tol).all()), v
+        if use_res:
+            tol = 0.51 * _ulp(rd.grad) + 3e-5 * (gy.double().abs().amax() + 1)
+            assert bool(((dres.double() - rd.grad).abs() <= tol).all()), v
+        if use_ln:
+            scale = gyd.abs().sum(0) + 1
+            assert bool(((dbeta.double() - bd.grad).abs() <= 2e-6 * scale).all()), v
+            assert bool(((dgamma.double() - gd.grad).abs() <= 3e-5 * scale * 4).all()), v
+    # the two kernels differ in the order of a row's sums only: one bf16 step at most (values near zero: the fp32 noise), rarely
+    d8, d4 = out[1][0].double(), out[0][0].double()
+    assert bool(((d8 - d4).abs() <= 1.01 * _ulp(torch.maximum(d8.abs(), d4.abs())) + 1e-4).all())
+    assert float((d8 != d4).double().mean()) <= 0.02

@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                   the launch stream inside the timed region, against 8 TB/s; `gather_bytes` is the no-reuse
                   traffic of the same launch (each stored entry fetching a d-wide row), the bound for a
                   uniform random graph (profiles/r02_gather_probe.md).  `traffic` = HBM bytes per launch
-                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r05_spmm_pmc.json,
+                  from the rocprofv3 PMC passes of THIS kernel on THIS workload (profiles/r06_spmm_pmc.json,
                   written by scripts/pmc_passes.sh; null when no pass has been recorded).
   structured    — the same training step and the same SpMM roofline on a graph of the same size WITH
                   community structure and RANDOMLY PERMUTED node ids (synth.synthetic_graph_community): the

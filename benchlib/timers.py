@@ -21,7 +21,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 # scripts/spmm_pmc_target.py; FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM).  PMC
 # counters cannot be collected from inside this process, so the figures live in a tracked file written
 # from those passes, keyed on graph kind / dtype / kernel.
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_spmm_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_spmm_pmc.json")
 SPMM_SOURCES = ("spmm.hip", "spmm_tile.hip", "spmm_pack.hip", "spmm_plan.hip", "spmm_shared.h")
 
 
@@ -43,7 +43,7 @@ def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
     except (OSError, ValueError):
         return None, None
     if table.get("_source_sha16") != spmm_source_sha16():
-        return None, "profiles/r05_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
+        return None, "profiles/r06_spmm_pmc.json is older than csrc/spmm*.hip: re-run scripts/pmc_passes.sh"
     tag = "reordered" if reordered else "given"
     e = table.get(f"{graph_kind}/{dtype}/{kernel}/{tag}")
     if not e:
@@ -56,7 +56,7 @@ def pmc_traffic(graph_kind: str, dtype: str, kernel: str, reordered: bool):
             x = table.get(f"{graph_kind}/{dtype}/{extra}/{tag}") or table.get(f"{graph_kind}/{dtype}/{extra}/given")
             if x:
                 total += x["hbm_bytes_per_launch"]
-    return total, "profiles/r05_spmm_pmc.json"
+    return total, "profiles/r06_spmm_pmc.json"
 
 
 class SpmmTimer:

@@ -107,6 +107,12 @@ def main(path: str, elem: int):
         ("k_colreduce<BnBwdStats>", ("BnBwdStatsF<" + tname,), 2.25 * T if r04 else 2 * T,
          "three layers (g, z) and the stem (g1, g2, z)" if r04 else "", find),
         ("k_bn_bwd_apply", ("k_bn_bwd_apply<" + tname,), 3 * T, "", find),
+        ("k_ln_bwd_bf16x8", ("k_ln_bwd_bf16x8<",), 4 * T, "post-attention only (g, x, res in — no activation follows, so y is not read; one shared dx out: 4T, as the PMC pass measures); 16 B per lane (r06)", find),
+        ("k_bn_apply_bf16x8<residual>", ("k_bn_apply_bf16x8<true",), 3 * T, "the three layers: z, residual -> x'; 16 B per lane (r06)", find),
+        ("k_bn_apply_bf16x8<no residual>", ("k_bn_apply_bf16x8<false",), 2 * T, "the stem", find),
+        ("k_bn_bwd_stats_bf16x8<one gradient>", ("k_bn_bwd_stats_bf16x8<false",), 2 * T, "the three layers (g, z)", find),
+        ("k_bn_bwd_stats_bf16x8<two gradients>", ("k_bn_bwd_stats_bf16x8<true",), 3 * T, "the stem (g1, g2, z)", find),
+        ("k_bn_bwd_apply_bf16x8", ("k_bn_bwd_apply_bf16x8<",), 3 * T, "g, z -> dz", find),
         ("k_sum_n (7 operands)", ("k_sum_n<" + tname,), 8 * T, "fan-out hub gradient", find),
         ("k_sum_n_bf16x8<7>", ("k_sum_n_bf16x8<7>",), 8 * T, "fan-out hub gradient", find),
         ("k_sum_n_bf16x8<6>", ("k_sum_n_bf16x8<6>",), 7 * T, "x0's gradient: three dz W2 and three residual gradients", find),

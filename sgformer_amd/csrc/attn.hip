@@ -290,31 +290,38 @@ __global__ void k_attn_finalize(const float* __restrict__ partial, int nblk, int
 }
 
 // sgf_gram: C[mb x kb] block (row stride ldc) and column sums of A from the per-block partials,
-// summed in a fixed order.  FOUR threads per output element (blocks b = q, q + 4, ...; the four chains are
-// added in order q = 0..3 by shuffles): one thread per element walked 256 partial tiles (64 MiB) in a single
-// dependent chain and ran 91 us per call, 11 calls per step.
+// summed in a fixed order.  kFinChains threads per output element (blocks b = q, q + kFinChains, ...; the chains are
+// added by a fixed shuffle tree): one thread per element walked 256 partial tiles (64 MiB) in a single dependent chain and
+// ran 91 us per call, 11 calls per step; four chains 23 us — still the memory latency times nblk / 4 (it is 7 % of a
+// mini-batch's kernel time); sixteen chains: see profiles/r06_README.md.
+constexpr int kFinChains = 16;
+__device__ __forceinline__ float fin_chain_sum(float s) {   // lanes 16 k .. 16 k + 15 hold the chains of one element
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 8, 64);
+  return s;
+}
 __global__ void k_gram_finalize(const float* __restrict__ partial, int nblk, int mb, int kb, int DP,
                                 int RG, float* __restrict__ c, int64_t ldc,
                                 float* __restrict__ colsum) {
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t idx = tid >> 2;
-  const int q = static_cast<int>(tid & 3);
+  const int64_t idx = tid / kFinChains;
+  const int q = static_cast<int>(tid % kFinChains);
   const int64_t nmat = static_cast<int64_t>(mb) * kb;
   float s = 0.f;
   if (idx < nmat) {
     const int m = static_cast<int>(idx / kb);
     const int dd = static_cast<int>(idx % kb);
-    for (int b = q; b < nblk; b += 4) {
+    for (int b = q; b < nblk; b += kFinChains) {
       const float* part = partial + static_cast<int64_t>(b) * kPartialStride;
       for (int g = 0; g < RG; ++g) s += part[(g * DP + m) * DP + dd];
     }
   } else if (idx < nmat + mb && colsum != nullptr) {
     const int j = static_cast<int>(idx - nmat);
-    for (int b = q; b < nblk; b += 4) s += partial[static_cast<int64_t>(b) * kPartialStride + kTileElems + j];
+    for (int b = q; b < nblk; b += kFinChains) s += partial[static_cast<int64_t>(b) * kPartialStride + kTileElems + j];
   }
-  // lanes 4k .. 4k+3 hold the four chains of one element: (s0 + s1) + (s2 + s3), the same order in every run
-  const float s01 = s + __shfl_xor(s, 1, 64);
-  const float t = s01 + __shfl_xor(s01, 2, 64);
+  const float t = fin_chain_sum(s);
   if (q == 0) {
     if (idx < nmat) {
       const int m = static_cast<int>(idx / kb);
@@ -332,24 +339,23 @@ __global__ void k_gram_finalize(const float* __restrict__ partial, int nblk, int
 __global__ void k_hbwd_finalize(const float* __restrict__ partial, int nblk, int d, int DP, int RG,
                                 float* __restrict__ out) {
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t idx = tid >> 2;
-  const int q = static_cast<int>(tid & 3);
+  const int64_t idx = tid / kFinChains;
+  const int q = static_cast<int>(tid % kFinChains);
   const int64_t nmat = static_cast<int64_t>(d) * d;
   float s = 0.f;
   if (idx < nmat) {
     const int m = static_cast<int>(idx / d);
     const int dd = static_cast<int>(idx % d);
-    for (int b = q; b < nblk; b += 4) {
+    for (int b = q; b < nblk; b += kFinChains) {
       const float* part = partial + static_cast<int64_t>(b) * kPartialStride;
       for (int g = 0; g < RG; ++g) s += part[(g * DP + m) * DP + dd];
     }
   } else if (idx < nmat + 2 * d + 1) {
     const int j = static_cast<int>(idx - nmat);
     const int off = j < d ? kTileElems + j : (j < 2 * d ? kVecB + (j - d) : kTileElems + DP);
-    for (int b = q; b < nblk; b += 4) s += partial[static_cast<int64_t>(b) * kPartialStride + off];
+    for (int b = q; b < nblk; b += kFinChains) s += partial[static_cast<int64_t>(b) * kPartialStride + off];
   }
-  const float s01 = s + __shfl_xor(s, 1, 64);
-  const float t = s01 + __shfl_xor(s01, 2, 64);
+  const float t = fin_chain_sum(s);
   if (q == 0 && idx < nmat + 2 * d + 1) out[idx] = t;
 }
 
@@ -1362,7 +1368,7 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
         if (rc != SGF_OK) return rc;
         const int64_t len = static_cast<int64_t>(mb) * kb + mb;
         float* cs = (colsum_a != nullptr && ki == 0) ? colsum_a + mi : nullptr;
-        hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st,
                            static_cast<const float*>(ws), nblk, mb, kb, 256, 1, c + static_cast<int64_t>(mi) * ldc + ki, ldc, cs);
         SGF_LAUNCH_CHECK();
         continue;
@@ -1382,7 +1388,7 @@ int gram_t(const void* a, int64_t lda, int m, const void* b, int64_t ldb, int k,
       const int RG = reduce_row_groups<T, kModeGram>(DP);
       const int64_t len = static_cast<int64_t>(mb) * kb + mb;
       float* cs = (colsum_a != nullptr && ki == 0) ? colsum_a + mi : nullptr;
-      hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0,
+      hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0,
                          st, r.partial, nblk, mb, kb, DP, RG, c + static_cast<int64_t>(mi) * ldc + ki,
                          ldc, cs);
       SGF_LAUNCH_CHECK();
@@ -1427,7 +1433,7 @@ extern "C" int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int
                       &nb, st);
     if (rc != SGF_OK) return rc;
     const int64_t len = static_cast<int64_t>(m) * k + m;
-    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
+    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
                        1, c, ldc, colsum);
     SGF_LAUNCH_CHECK();
     return SGF_OK;
@@ -1446,7 +1452,7 @@ extern "C" int sgf_gram_bn_bwd(const void* g1, int64_t ldg1, const void* g2, int
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<uint16_t, kModeGramBN>(DP);
   const int64_t len = static_cast<int64_t>(m) * k + m;
-  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
+  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
                      k, DP, RG, c, ldc, colsum);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -1486,7 +1492,7 @@ extern "C" int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int6
     int rc = gramt_ln(g, ldg, xin, ldx, mean, rstd, gamma, beta, relu, m, b, ldb, k, n, part, &nb, st);
     if (rc != SGF_OK) return rc;
     const int64_t len = static_cast<int64_t>(m) * k + m;
-    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
+    hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st, part, nb, m, k, 256,
                        1, c, ldc, colsum);
     if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, part, nb, kVecB, m, dbeta);
     if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, part, nb, kVecC, m, dgamma);
@@ -1506,7 +1512,7 @@ extern "C" int sgf_gram_ln_bwd(const void* g, int64_t ldg, const void* xin, int6
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<uint16_t, kModeGramLN>(DP);
   const int64_t len = static_cast<int64_t>(m) * k + m;
-  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
+  hipLaunchKernelGGL(k_gram_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st, r.partial, nblk, m,
                      k, DP, RG, c, ldc, colsum);
   if (dbeta) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, r.partial, nblk, kVecB, m, dbeta);
   if (dgamma) hipLaunchKernelGGL(k_vec_finalize, dim3((m + 31) / 32), dim3(256), 0, st, r.partial, nblk, kVecC, m, dgamma);
@@ -1542,7 +1548,7 @@ extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, 
     int rc = gramx_gram(a, lda, m, b1, ldb1, b2, ldb2, k, n, part, &np, st);
     if (rc != SGF_OK) return rc;
     const int64_t len = static_cast<int64_t>(m) * k + m;
-    const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+    const unsigned fb = static_cast<unsigned>((kFinChains * len + 255) / 256);
     hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part, np, m, k, 256, 1, c1, ldc1, colsum_a);
     hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part + static_cast<int64_t>(np) * kPartialStride, np, m, k,
                        256, 1, c2, ldc2, static_cast<float*>(nullptr));
@@ -1561,7 +1567,7 @@ extern "C" int sgf_gram2(const void* a, int64_t lda, int32_t m, const void* b1, 
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<uint16_t, kModeGram>(DP);
   const int64_t len = static_cast<int64_t>(m) * k + m;
-  const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+  const unsigned fb = static_cast<unsigned>((kFinChains * len + 255) / 256);
   hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, r.partial, static_cast<int>(pairs), m, k, DP, RG, c1, ldc1,
                      colsum_a);
   hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, r.partial + pairs * kPartialStride, static_cast<int>(pairs),
@@ -1596,7 +1602,7 @@ extern "C" int sgf_gram2_bn_bwd(const void* g, int64_t ldg, const void* z, int64
                   part, &np, st);
   if (rc != SGF_OK) return rc;
   const int64_t len = static_cast<int64_t>(m) * k + m;
-  const unsigned fb = static_cast<unsigned>((4 * len + 255) / 256);
+  const unsigned fb = static_cast<unsigned>((kFinChains * len + 255) / 256);
   hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part, np, m, k, 256, 1, c1, ldc1, colsum);
   hipLaunchKernelGGL(k_gram_finalize, dim3(fb), dim3(256), 0, st, part + static_cast<int64_t>(np) * kPartialStride, np, m, k, 256,
                      1, c2, ldc2, static_cast<float*>(nullptr));
@@ -1669,7 +1675,7 @@ int h_bwd_reduce_t(const void* h, int64_t ldh, const void* g, int64_t ldg, const
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<T, kModeBwdH>(DP);
   const int64_t len = sgf_attn_h_bstats_len(d);
-  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st,
                      a.partial, nblk, d, DP, RG, hstats);
   SGF_LAUNCH_CHECK();
   return SGF_OK;
@@ -1805,7 +1811,7 @@ extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const vo
     rc = gramx_bwdhs(h, ldh, g, ldg, rowscal, d, n, static_cast<float*>(workspace), &nb, st);
     if (rc != SGF_OK) return rc;
     const int64_t len = sgf_attn_h_bstats_len(d);
-    hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st,
                        static_cast<const float*>(workspace), nb, d, 256, 1, hstats);
     SGF_LAUNCH_CHECK();
     return SGF_OK;
@@ -1824,7 +1830,7 @@ extern "C" int sgf_attn_h_bwd_reduce_scaled(const void* h, int64_t ldh, const vo
   if (rc != SGF_OK) return rc;
   const int RG = reduce_row_groups<uint16_t, kModeBwdHS>(DP);
   const int64_t len = sgf_attn_h_bstats_len(d);
-  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((4 * len + 255) / 256)), dim3(256), 0, st, a.partial, nblk, d,
+  hipLaunchKernelGGL(k_hbwd_finalize, dim3(static_cast<unsigned>((kFinChains * len + 255) / 256)), dim3(256), 0, st, a.partial, nblk, d,
                      DP, RG, hstats);
   SGF_LAUNCH_CHECK();
   return SGF_OK;

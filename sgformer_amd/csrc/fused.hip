@@ -1166,12 +1166,15 @@ __global__ __launch_bounds__(kThreads) void k_nll_bwd16(const T* __restrict__ lo
   }
 }
 
+// one wave: lane l adds partials l, l + 64, ... in order, then a fixed shuffle tree (deterministic).  (One thread walking
+// all partials ran 38 us — longer than the loss kernel it follows.)
 __global__ void k_nll_sum(const float* __restrict__ part, int nblk, float* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[b];
-    out[0] = s;
-  }
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += part[b];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) out[0] = s;
 }
 
 // dlogits[row] = scale * (softmax(logits[row]) - onehot(label[row])) on the training rows (the rest of

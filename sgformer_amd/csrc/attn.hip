@@ -292,8 +292,8 @@ __global__ void k_attn_finalize(const float* __restrict__ partial, int nblk, int
 // sgf_gram: C[mb x kb] block (row stride ldc) and column sums of A from the per-block partials,
 // summed in a fixed order.  kFinChains threads per output element (blocks b = q, q + kFinChains, ...; the chains are
 // added by a fixed shuffle tree): one thread per element walked 256 partial tiles (64 MiB) in a single dependent chain and
-// ran 91 us per call, 11 calls per step; four chains 23 us — still the memory latency times nblk / 4 (it is 7 % of a
-// mini-batch's kernel time); sixteen chains: see profiles/r06_README.md.
+// ran 91 us per call, 11 calls per step; four chains 23 us, sixteen 19 us: what is left is reading nblk x 264 KB of
+// partials (64 MB at 256 blocks, 3.5 TB/s), not the chain.
 constexpr int kFinChains = 16;
 __device__ __forceinline__ float fin_chain_sum(float s) {   // lanes 16 k .. 16 k + 15 hold the chains of one element
   s += __shfl_xor(s, 1, 64);

@@ -652,6 +652,7 @@ int sgf_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
  *   dW = a dlogits^T x1 + b dlogits^T x2 and db are node reductions: sgf_gram.
  * W: fp32 [classes, d] row-major, bias fp32 [classes].  Implemented for bf16 storage, d % 32 == 0,
  * d <= 256, classes <= 64 (sgf_combine_fc_supported); anything else: sgf_axpby + a library GEMM.
+ * bf16 storage, backward: n < 2^31 (SGF_E_UNSUPPORTED beyond).
  * ------------------------------------------------------------------------------------------ */
 int32_t sgf_combine_fc_supported(int32_t d, int32_t classes, int32_t dtype);
 int sgf_combine_fc_fwd(const void* x1, int64_t ld1, float a, const void* x2, int64_t ld2, float b,

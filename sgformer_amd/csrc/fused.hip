@@ -547,9 +547,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
 // The kernels above move a bf16 row as 8 bytes per lane (4 columns): 512 bytes per wave instruction.  On MI355X that form
 // streams at 4.5-4.8 TB/s where ATen's 16-byte elementwise kernels reach 5.7-6.0 on the same read : write mix
 // (scripts/hbm_mix_probe.py).  Same thread map — a thread keeps its column chunk, so the coefficients stay in registers —
-// with 8 columns per thread and a CONTIGUOUS run of rpp * kRowUnroll rows per block pass.  Per-element arithmetic is the
+// with 8 columns per thread and a CONTIGUOUS run of rpp * kEw8Unroll rows per block pass.  Per-element arithmetic is the
 // x4 kernels' (the reference's order of operations); only the vector width and, for the statistics, the order in which
-// rows are added differ.
+// rows are added differ.  (Rounding is the hardware's v_cvt_pk_bf16_f32: the same round-to-nearest-even as f32_to_bf16 on every
+// finite value and infinity; a NaN stays a NaN, its payload bits may differ from the software rounding's.)
 typedef __bf16 ew_bf16v2 __attribute__((ext_vector_type(2)));
 typedef float ew_f32v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t ew_pack(float a, float b) {      // v_cvt_pk_bf16_f32: round-to-nearest-even

@@ -39,7 +39,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument` otherwise); the
+# boxes export it already — kept here so that a launcher with a scrubbed environment still works
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 import torch.distributed as dist
 import torch.nn.functional as F
 
